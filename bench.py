@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py — frames/s of the MI355X-native cost-volume hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
+
+One "step" = one pass of the hot path over one batch of B synthetic frames per GPU (weak
+scaling: per-GPU batch fixed).  Inputs are generated once and are resident in HBM before the
+timed region.  For N>1 launch with torch.distributed.run (one rank per GPU, RCCL); the batch
+dimension is sharded, there is no data-path collective, and the only message is an
+all-gather of per-frame metric vectors after the timed region.
+
+Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
+  roofline     — dominant kernel, algorithmic bytes(flops)/launch ÷ HIP-event-measured
+                 average launch time vs the gfx950 peak
+  cpu_baseline — the oracle (CPU restatement) timed on this host's cores on a bounded
+                 sample of the same workload (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak (no xf32/TF32 on gfx950)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="auto", help="auto | warp_match_dot | hot_path")
+    ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
+    ap.add_argument("--views", type=int, default=8, help="source views K (BASELINE.json: 8; reference-native tuples: 7)")
+    ap.add_argument("--planes", type=int, default=64)
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------
+class WarpMatchDot:
+    """BASELINE.json configs[1]: fused warp+match HIP kernel, 512x384 image -> 96x128 matching
+    map, K source views, D planes, random-init N(0,1) matching features (NHWC, resident)."""
+
+    name = "warp_match_dot"
+    dominant_kernel = "cv_dot_k"
+    bound = "hbm"
+
+    def __init__(self, args, device, rank):
+        import implicit_depth_amd.synthetic as syn
+        from implicit_depth_amd import _lib
+        from implicit_depth_amd.cost_volume import to_nhwc
+
+        self.L = _lib.lib()
+        self._lib = _lib
+        self.B, self.K, self.D = args.batch, args.views, args.planes
+        self.H, self.W, self.C = args.height // 4, args.width // 4, 16
+        inp = syn.cost_volume_inputs(self.B, self.K, self.C, self.H, self.W, seed=rank)
+        self.host_inputs = inp
+        d = {k: v.to(device) for k, v in inp.items()}
+        self.cur = to_nhwc(d["cur_feats"])
+        self.src = to_nhwc(d["src_feats"])
+        self.Ks, self.E, self.invK = d["src_Ks"].contiguous(), d["src_extrinsics"].contiguous(), d["cur_invK"].contiguous()
+        self.cost = torch.empty(self.B, self.D, self.H, self.W, device=device)
+        self.lowest = torch.empty(self.B, self.H, self.W, device=device)
+        self.planes = torch.empty(self.D, device=device)
+        self.kernel_ms = []
+
+    def config(self):
+        return {"workload": f"{self.name}: fused plane-sweep warp+match, {self.W * 4}x{self.H * 4} image, matching map {self.W}x{self.H}, "
+                            f"K={self.K} source views, D={self.D} planes, C=16, fp32",
+                "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D}
+
+    def step(self, ev=None):
+        p, L = self._lib.ptr, self.L
+        if ev is not None:
+            ev[0].record()
+        rc = L.idh_cost_volume_dot_fwd(p(self.cur), p(self.src), p(self.Ks), p(self.E), p(self.invK), 0.25, 5.0,
+                                       self.B, self.K, self.C, self.H, self.W, self.D, p(self.cost), p(self.lowest),
+                                       p(self.planes), self._lib.stream_ptr())
+        if ev is not None:
+            ev[1].record()
+        self._lib.check(rc, "idh_cost_volume_dot_fwd")
+
+    def algorithmic_bytes_per_launch(self):
+        # compulsory traffic per frame = every input read once + every output
+        # written once = 4*[C*N + K*C*N + D*N + N] + 64*(2K+1) bytes; one launch processes B frames.
+        N = self.H * self.W
+        per_frame = 4 * (self.C * N + self.K * self.C * N + self.D * N + N) + 64 * (2 * self.K + 1)
+        return per_frame * self.B
+
+    def metrics(self):
+        # per-frame vector that is all-gathered (stand-in for the reference's per-frame
+        # metric dict, test_bd.py:288-339): mean cost, mean arg-max depth
+        return torch.stack([self.cost.mean((1, 2, 3)), self.lowest.mean((1, 2))], 1)
+
+    def cpu_baseline(self, seconds):
+        from oracle import cost_volume as ocv
+
+        i = self.host_inputs
+        one = {k: (v[:1] if v.shape[0] == self.B and v.ndim > 1 and k not in ("min_depth", "max_depth") else v) for k, v in i.items()}
+        n, t0 = 0, time.perf_counter()
+        with torch.inference_mode():
+            while True:
+                ocv.cost_volume_dot(one["cur_feats"], one["src_feats"], one["src_extrinsics"], one["src_Ks"], one["cur_invK"], 0.25, 5.0, self.D)
+                n += 1
+                if time.perf_counter() - t0 > seconds and n >= 2:
+                    break
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} frames of the same workload through oracle/cost_volume.py (torch CPU fp32), {dt:.1f} s"}
+
+
+def make_workload(args, device, rank):
+    name = args.workload
+    if name == "auto":
+        try:
+            from implicit_depth_amd import pipeline  # noqa: F401
+
+            name = "hot_path"
+        except Exception:
+            name = "warp_match_dot"
+    if name == "warp_match_dot":
+        return WarpMatchDot(args, device, rank)
+    if name == "hot_path":
+        from implicit_depth_amd.pipeline import HotPathWorkload
+
+        return HotPathWorkload(args, device, rank)
+    raise SystemExit(f"unknown workload {name}")
+
+
+# ------------------------------------------------------------------------------------------
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    wl = make_workload(args, device, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            wl.step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            wl.step(evs[i])
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        torch.cuda.synchronize()
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+
+    # the path's only collective: all-gather of per-frame metric vectors (RCCL over xGMI)
+    m = wl.metrics().float().contiguous()
+    if world > 1:
+        gathered = [torch.empty_like(m) for _ in range(world)]
+        dist.all_gather(gathered, m)
+        m = torch.cat(gathered, 0)
+    frames_total = wl.B * world * args.steps
+
+    if rank == 0:
+        rl_alg = wl.algorithmic_bytes_per_launch() if wl.bound == "hbm" else wl.algorithmic_flops_per_launch()
+        if wl.bound == "hbm":
+            achieved = rl_alg / (kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "kernel": wl.dominant_kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": rl_alg}
+        else:
+            achieved = rl_alg / (kernel_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": None, "kernel": wl.dominant_kernel, "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": rl_alg}
+        traffic = getattr(wl, "pmc_traffic_bytes", None)
+        if traffic is not None:
+            roof["traffic"] = traffic
+        out = {
+            "metric": "frames/sec (BDModel.forward, 512x384, 64 planes, 8 views)",
+            "value": frames_total / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": wl.config(),
+            "roofline": roof,
+            "gathered_metric_rows": int(m.shape[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

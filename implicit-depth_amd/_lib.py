@@ -1,0 +1,84 @@
+"""ctypes binding of lib/libidh.so (the C ABI in include/idh.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails the product
+path raises.  ``import torch`` happens before the CDLL load so that libidh.so's
+``libamdhip64.so.7`` dependency resolves to the HIP runtime PyTorch-ROCm already mapped
+(one runtime per process: device pointers and streams are then interchangeable).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libidh.so")
+
+_lib = None
+
+f32p = C.c_void_p  # device pointers travel as integers
+
+
+class IdhError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    "idh_version": (C.c_int, []),
+    "idh_error_string": (C.c_char_p, [C.c_int]),
+    "idh_nchw_to_nhwc_f32": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "idh_nhwc_to_nchw_f32": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "idh_cost_volume_dot_fwd": (
+        C.c_int,
+        [f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_float] + [C.c_int] * 6 + [f32p, f32p, f32p, C.c_void_p],
+    ),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises IdhError if the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IdhError(
+                f"{LIB_PATH} not found — the gfx950 HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)."
+            )
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().idh_error_string(code).decode()
+        raise IdhError(f"{what} failed: {msg} ({code})")
+
+
+def ptr(t: "torch.Tensor | None"):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda_f32(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise IdhError("implicit_depth_amd kernels need tensors on the MI355X (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.float32:
+            raise IdhError(f"implicit_depth_amd kernels are fp32 (got {t.dtype})")

@@ -1,0 +1,14 @@
+#include "idh_common.h"
+
+extern "C" int idh_version(void) { return 100; }
+
+extern "C" const char *idh_error_string(int code) {
+    switch (code) {
+        case IDH_OK: return "ok";
+        case IDH_EINVAL: return "invalid argument (shape, null pointer or parameter)";
+        case IDH_EUNSUPPORTED: return "configuration not covered by the gfx950 kernels";
+        case IDH_ELAUNCH: return "HIP kernel launch failed";
+        case IDH_EWORKSPACE: return "workspace missing or too small";
+        default: return "unknown idh error";
+    }
+}

@@ -1,0 +1,195 @@
+// Fused plane-sweep warp + dot-product matching (gfx950).
+//
+// Replaces the reference's per-plane Python loop (modules/cost_volume.py:287-313) —
+// BackprojectDepth -> repeat_interleave -> Project3D -> grid_sample -> mul/sum/mask/sum ->
+// cat -> argmax/gather — with ONE launch that never materialises a warped feature map.
+//
+// Arithmetic follows SURVEY.md §8(a'):
+//   q_k   = (P_k[:3,:3] invK[:3,:3]) (x+.5, y+.5, 1)^T         (homography, per pixel & view)
+//   c     = depth_d * q_k + P_k[:3,3];  z = max(c_z, 1e-5);  (u,v) = c_xy / z
+//   (sx,sy) = (u-.5, v-.5)  -> 4 bilinear taps, taps outside the image contribute 0
+//   cost[b,d,y,x] = sum_k sum_c cur[c] * tap-blend(src_k)[c]
+// The reference's "mask = depth > 0" is identically 1 because depth is clamped to >= 1e-5
+// first (geometry_utils.py:86, cost_volume.py:216) — reproduced by construction.
+//
+// Data layout: features are NHWC with C = 16, so one tap = one 64-byte line segment read as
+// 4 x dwordx4.  Work decomposition: a 256-thread workgroup owns 32 consecutive pixels and ALL
+// D planes: thread (px, g) sweeps planes [g*DP, (g+1)*DP) for its pixel, g = 0..7, so the
+// arg-max over planes finishes inside the workgroup (LDS reduce, first maximum wins) and the
+// cost volume is written exactly once.  The per-(b,k) 3x4 homographies are wave-uniform and
+// come through the scalar cache.
+#include "idh_common.h"
+
+namespace {
+
+constexpr int kC = 16;
+constexpr int kTilePx = 32;
+constexpr int kGroups = 8;
+constexpr int kMaxPlanes = 512;
+
+// ---- per-workgroup prologue: homographies + depth planes into LDS ------------------------
+// One thread per source view builds the 3x4 map  [M | t] = [P[:3,:3] invK[:3,:3] | P[:3,3]],
+// P = K_src E (geometry_utils.py:82); ~100 flops per view, redundant per workgroup but it
+// removes a separate launch and any workspace.
+__device__ __forceinline__ void build_homography(const float *__restrict__ Km, const float *__restrict__ Em,
+                                                 const float *__restrict__ iK, float *__restrict__ o) {
+    float P[3][4];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+            for (int m = 0; m < 4; ++m) s = fmaf(Km[i * 4 + m], Em[m * 4 + j], s);
+            P[i][j] = s;
+        }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.f;
+            for (int m = 0; m < 3; ++m) s = fmaf(P[i][m], iK[m * 4 + j], s);
+            o[i * 3 + j] = s;
+        }
+        o[9 + i] = P[i][3];
+    }
+}
+
+// depth planes: exp(log(dmin) + log(dmax/dmin) * linspace(0,1,D)) (cost_volume.py:123-126);
+// torch's linspace is evaluated from both ends (start + i*step below the middle,
+// end - (D-1-i)*step above it).
+__device__ __forceinline__ float depth_plane(int i, int D, float dmin, float dmax) {
+    float ramp = 0.f;
+    if (D > 1) {
+        const float step = 1.0f / (float)(D - 1);
+        ramp = (i < D / 2) ? step * (float)i : 1.0f - step * (float)(D - 1 - i);
+    }
+    return expf(logf(dmin) + logf(dmax / dmin) * ramp);
+}
+
+__device__ __forceinline__ float dot16(const float4 &a0, const float4 &a1, const float4 &a2,
+                                       const float4 &a3, const float4 *__restrict__ p) {
+    const float4 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    float s = a0.x * b0.x;
+    s = fmaf(a0.y, b0.y, s); s = fmaf(a0.z, b0.z, s); s = fmaf(a0.w, b0.w, s);
+    s = fmaf(a1.x, b1.x, s); s = fmaf(a1.y, b1.y, s); s = fmaf(a1.z, b1.z, s); s = fmaf(a1.w, b1.w, s);
+    s = fmaf(a2.x, b2.x, s); s = fmaf(a2.y, b2.y, s); s = fmaf(a2.z, b2.z, s); s = fmaf(a2.w, b2.w, s);
+    s = fmaf(a3.x, b3.x, s); s = fmaf(a3.y, b3.y, s); s = fmaf(a3.z, b3.z, s); s = fmaf(a3.w, b3.w, s);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,   // B,N,16
+                                                const float *__restrict__ src,   // B,K,N,16
+                                                const float *__restrict__ src_K, // B,K,4,4
+                                                const float *__restrict__ src_E, // B,K,4,4
+                                                const float *__restrict__ cur_invK,  // B,4,4
+                                                float dmin, float dmax,
+                                                int B, int K, int H, int W, int D, int tiles_per_img,
+                                                float *__restrict__ cost,        // B,D,N
+                                                float *__restrict__ lowest,      // B,N or null
+                                                float *__restrict__ planes_out) {  // D or null
+    __shared__ float s_planes[kMaxPlanes];
+    __shared__ __attribute__((aligned(16))) float s_h[IDH_MAX_SOURCE_VIEWS][12];
+    __shared__ float s_best[kGroups][kTilePx];
+    __shared__ int s_bidx[kGroups][kTilePx];
+
+    const int N = H * W;
+    const unsigned lin = idh_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lin / tiles_per_img;
+    const int tile = lin - b * tiles_per_img;
+    const int px = threadIdx.x & (kTilePx - 1);
+    const int g = threadIdx.x >> 5;
+
+    if (threadIdx.x < K)
+        build_homography(src_K + (size_t)(b * K + threadIdx.x) * 16, src_E + (size_t)(b * K + threadIdx.x) * 16,
+                         cur_invK + (size_t)b * 16, s_h[threadIdx.x]);
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float dp = depth_plane(i, D, dmin, dmax);
+        s_planes[i] = dp;
+        if (planes_out != nullptr && blockIdx.x == 0) planes_out[i] = dp;
+    }
+    __syncthreads();
+
+    const int p_raw = tile * kTilePx + px;
+    const bool live = p_raw < N;
+    const int p = live ? p_raw : N - 1;
+    const int y = p / W, x = p - y * W;
+    const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
+
+    const float4 *cp = reinterpret_cast<const float4 *>(cur + ((size_t)b * N + p) * kC);
+    const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+
+    const int DP = (D + kGroups - 1) / kGroups;
+    const int d0 = g * DP;
+    const int d1 = min(D, d0 + DP);
+    const float Wf = (float)W, Hf = (float)H;
+
+    float best = -INFINITY;
+    int bidx = d0 < D ? d0 : 0;
+    for (int d = d0; d < d1; ++d) {
+        const float depth = s_planes[d];
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float *hm = s_h[k];  // same address in every lane: LDS broadcast read
+            const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+            const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+            const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+            const float cx = fmaf(depth, qx, hm[9]);
+            const float cy = fmaf(depth, qy, hm[10]);
+            const float cz = fmaf(depth, qz, hm[11]);
+            const float z = fmaxf(cz, 1e-5f);
+            float r = __builtin_amdgcn_rcpf(z);
+            r = r * fmaf(-z, r, 2.0f);  // one Newton step: <= 1 ulp
+            // clamp in float BEFORE any int conversion: behind-camera points give |u| ~ 1e8
+            const float sx = fminf(fmaxf(fmaf(cx, r, -0.5f), -1.0f), Wf);
+            const float sy = fminf(fmaxf(fmaf(cy, r, -0.5f), -1.0f), Hf);
+            const float x0f = floorf(sx), y0f = floorf(sy);
+            const float fx = sx - x0f, fy = sy - y0f;
+            const int x0 = (int)x0f, y0 = (int)y0f;  // in [-1, W] / [-1, H]
+            const float wx0 = (x0 >= 0 && x0 < W) ? 1.0f - fx : 0.f;
+            const float wx1 = (x0 + 1 < W) ? fx : 0.f;
+            const float wy0 = (y0 >= 0 && y0 < H) ? 1.0f - fy : 0.f;
+            const float wy1 = (y0 + 1 < H) ? fy : 0.f;
+            const int xa0 = min(max(x0, 0), W - 1), xa1 = min(x0 + 1, W - 1);
+            const int ya0 = min(max(y0, 0), H - 1), ya1 = min(y0 + 1, H - 1);
+            const float *sb = src + (size_t)(b * K + k) * N * kC;
+            const float t00 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya0 * W + xa0) * kC));
+            const float t01 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya0 * W + xa1) * kC));
+            const float t10 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya1 * W + xa0) * kC));
+            const float t11 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya1 * W + xa1) * kC));
+            const float top = fmaf(wx1, t01, wx0 * t00);
+            const float bot = fmaf(wx1, t11, wx0 * t10);
+            acc += fmaf(wy1, bot, wy0 * top);
+        }
+        if (live) cost[((size_t)b * D + d) * N + p] = acc;
+        if (acc > best) { best = acc; bidx = d; }
+    }
+    if (lowest == nullptr) return;
+    s_best[g][px] = best;
+    s_bidx[g][px] = bidx;
+    __syncthreads();
+    if (g == 0 && live) {
+        float bv = s_best[0][px];
+        int bi = s_bidx[0][px];
+#pragma unroll
+        for (int j = 1; j < kGroups; ++j) {
+            const float v = s_best[j][px];
+            if (v > bv) { bv = v; bi = s_bidx[j][px]; }  // strict: first maximum wins
+        }
+        lowest[(size_t)b * N + p] = s_planes[bi];
+    }
+}
+
+}  // namespace
+
+extern "C" int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                                       const float *src_E_44, const float *cur_invK_44, float dmin,
+                                       float dmax, int B, int K, int C, int H, int W, int D,
+                                       float *cost_bdhw, float *lowest_bhw, float *planes_d, void *stream) {
+    if (B < 0 || K < 0 || H <= 0 || W <= 0 || D <= 0 || !(dmin > 0.f) || !(dmax > 0.f)) return IDH_EINVAL;
+    if (C != kC || D > kMaxPlanes || K > IDH_MAX_SOURCE_VIEWS) return IDH_EUNSUPPORTED;
+    if (B == 0) return IDH_OK;
+    if (!cur_nhwc || !cost_bdhw || !cur_invK_44 || (K > 0 && (!src_nhwc || !src_K_44 || !src_E_44)))
+        return IDH_EINVAL;
+    const int tiles = idh_cdiv((long long)H * W, kTilePx);
+    hipLaunchKernelGGL(cv_dot_k, dim3((unsigned)(B * tiles)), dim3(256), 0, idh_stream(stream), cur_nhwc,
+                       src_nhwc, src_K_44, src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles, cost_bdhw,
+                       lowest_bhw, planes_d);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}

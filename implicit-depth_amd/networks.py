@@ -1,0 +1,132 @@
+"""Drop-ins for the conv / MLP blocks around the cost volume (reference modules/networks.py).
+
+Module trees and parameter names are identical to the reference's (``convs.ds_conv_0.conv1``,
+``convs.in_conv_01.conv_0.conv2``, ``mlps.s0.0`` …) so reference checkpoints load with
+``load_state_dict`` unchanged; every forward runs hand-written gfx950 kernels on NHWC
+activations (see nhwc.py for the execution plans).
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+import torch
+from torch import nn
+
+from .layers import BasicBlock
+
+
+def double_basic_block(num_ch_in, num_ch_out, num_repeats=2):
+    layers = nn.Sequential(BasicBlock(num_ch_in, num_ch_out))
+    for i in range(num_repeats - 1):
+        layers.add_module(f"conv_{i}", BasicBlock(num_ch_out, num_ch_out))
+    return layers
+
+
+class CVEncoder(nn.Module):
+    """reference modules/networks.py:186-215"""
+
+    def __init__(self, num_ch_cv, num_ch_enc, num_ch_outs):
+        super().__init__()
+        self.convs = nn.ModuleDict()
+        self.num_ch_enc = []
+        self.num_blocks = len(num_ch_outs)
+        self.num_ch_img = list(num_ch_enc)
+        for i in range(self.num_blocks):
+            cin = num_ch_cv if i == 0 else num_ch_outs[i - 1]
+            cout = num_ch_outs[i]
+            self.convs[f"ds_conv_{i}"] = BasicBlock(cin, cout, stride=1 if i == 0 else 2)
+            self.convs[f"conv_{i}"] = nn.Sequential(BasicBlock(num_ch_enc[i] + cout, cout), BasicBlock(cout, cout))
+            self.num_ch_enc.append(cout)
+
+    def forward(self, x, img_feats):
+        from .nhwc import cv_encoder_forward_nchw
+
+        return cv_encoder_forward_nchw(self, x, img_feats)
+
+
+class _DecoderPP(nn.Module):
+    """UNet++ grid shared by BDDecoderPP / DepthDecoderPP (reference :20-84 / :118-183)."""
+
+    depth_head = False
+    out_key = "feature_s{}_b1hw"
+
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = "nearest"
+        self.scales = scales
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([64, 64, 128, 256])
+        self.convs = nn.ModuleDict()
+        for j in range(1, 5):
+            for i in range(4 - j, -1, -1):
+                cout = int(self.num_ch_dec[i])
+                total = 0
+                cin = num_ch_enc[i + 1] if j == 1 else int(self.num_ch_dec[i + 1])
+                self.convs[f"diag_conv_{i + 1}{j - 1}"] = BasicBlock(cin, cout)
+                total += cout
+                cin = num_ch_enc[i] if j == 1 else int(self.num_ch_dec[i])
+                self.convs[f"right_conv_{i}{j - 1}"] = BasicBlock(cin, cout)
+                total += cout
+                if i + j != 4:
+                    self.convs[f"up_conv_{i + 1}{j}"] = BasicBlock(int(self.num_ch_dec[i + 1]), cout)
+                    total += cout
+                self.convs[f"in_conv_{i}{j}"] = double_basic_block(total, cout)
+                head = [BasicBlock(cout, cout) if i != 0 else nn.Identity()]
+                if self.depth_head:
+                    head.append(nn.Conv2d(cout, self.num_output_channels, 1))
+                self.convs[f"output_{i}"] = nn.Sequential(*head)
+
+    def forward(self, input_features):
+        from .nhwc import decoder_forward_nchw
+
+        return decoder_forward_nchw(self, input_features)
+
+
+class BDDecoderPP(_DecoderPP):
+    depth_head = False
+    out_key = "feature_s{}_b1hw"
+
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=16, use_skips=True):
+        super().__init__(num_ch_enc, scales, num_output_channels, use_skips)
+
+
+class DepthDecoderPP(_DecoderPP):
+    depth_head = True
+    out_key = "log_depth_pred_s{}_b1hw"
+
+
+class MLP(nn.Module):
+    """reference modules/networks.py:218-233 (LeakyReLU default slope 0.01)."""
+
+    def __init__(self, channel_list, disable_final_activation=False):
+        super().__init__()
+        layers = []
+        for i in range(len(channel_list) - 1):
+            layers.append(nn.Linear(channel_list[i], channel_list[i + 1]))
+            layers.append(nn.LeakyReLU(inplace=True))
+        if disable_final_activation:
+            layers = layers[:-1]
+        self.net = nn.Sequential(*layers)
+
+
+class BinaryMLPNetwork(nn.Module):
+    """reference modules/networks.py:87-115 (only scale 0 is evaluated at test time)."""
+
+    def __init__(self, input_channels, mlp_size=128, use_prior=False):
+        super().__init__()
+        self.scales = list(range(4))
+        self.use_prior = use_prior
+        extra = 2 if use_prior else 1
+        self.mlps = nn.ModuleDict()
+        for scale, ch in enumerate(input_channels):
+            self.mlps[f"s{scale}"] = nn.Sequential(
+                nn.Linear(int(ch) + extra, mlp_size), nn.ELU(inplace=True), nn.Linear(mlp_size, mlp_size), nn.ELU(inplace=True), nn.Linear(mlp_size, 1)
+            )
+
+    def forward(self, inputs: List[torch.Tensor], max_scale_only: bool = False) -> Dict[str, torch.Tensor]:
+        from .nhwc import binary_mlp_forward
+
+        return binary_mlp_forward(self, inputs, max_scale_only)

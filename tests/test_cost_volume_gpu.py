@@ -1,0 +1,111 @@
+"""HIP fused warp+match kernel vs the oracle, the golden vectors, and size-independent
+properties at BASELINE.json's full size.  Calls go through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+import torch
+
+import implicit_depth_amd.synthetic as syn
+from conftest import TOL, load_golden, rel_err
+from oracle import cost_volume as ocv
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(inp, D):
+    from implicit_depth_amd.cost_volume import CostVolumeManager
+
+    B, K, C, H, W = inp["src_feats"].shape
+    m = CostVolumeManager(H, W, D).cuda()
+    dev = {k: v.cuda() for k, v in inp.items()}
+    cv, low, planes, mask = m(**dev)
+    torch.cuda.synchronize()
+    assert mask is None and planes.shape == (B, D, H, W)
+    return cv.cpu(), low.cpu(), planes[0, :, 0, 0].cpu()
+
+
+def _lowest_mismatch(low, ref_low):
+    return ((low.double() - torch.as_tensor(ref_low).double()).abs() > 1e-5).float().mean().item()
+
+
+@pytest.mark.parametrize("name", ["g1_small", "g1_b2k7", "g1_ragged"])
+def test_matches_reference_golden(name):
+    g = load_golden(name)
+    B, K, C, H, W, D, seed, bv, rv = [int(v) for v in g["dims"]]
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed, bv, rv)
+    cv, low, planes = _run(inp, D)
+    assert rel_err(cv, g["cost_volume"]) < TOL
+    assert rel_err(planes, g["planes"]) < 1e-6
+    assert _lowest_mismatch(low, g["lowest_cost"]) < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 16, 8, 8, 1), (2, 3, 16, 17, 23, 7), (1, 8, 16, 33, 31, 9), (3, 7, 16, 24, 32, 64), (1, 16, 16, 12, 20, 5)])
+def test_matches_oracle_fp64(shape):
+    B, K, C, H, W, D = shape
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed=B + K, behind_view=K - 1 if K > 2 else -1, big_rotation_view=0 if K > 3 else -1)
+    cv, low, planes = _run(inp, D)
+    d = {k: v.double() for k, v in inp.items()}
+    ref, rlow, rplanes = ocv.cost_volume_dot(d["cur_feats"], d["src_feats"], d["src_extrinsics"], d["src_Ks"], d["cur_invK"], 0.25, 5.0, D)
+    assert rel_err(cv, ref) < TOL
+    assert rel_err(planes, rplanes) < 1e-6
+    assert _lowest_mismatch(low, rlow) < 5e-3
+
+
+def test_full_size_golden_and_properties():
+    """BASELINE config 2 (96x128, K=8, D=64): reference checksums/slices + linearity."""
+    g = load_golden("g1_full_k8d64")
+    B, K, C, H, W, D = [int(v) for v in g["dims"][:6]]
+    inp = syn.cost_volume_inputs(B, K, C, H, W, 0)
+    cv, low, _ = _run(inp, D)
+    assert rel_err(cv[:, ::4, ::6, ::8], g["cost_slice"]) < TOL
+    s = cv.double()
+    np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["cost_chk"][1:], rtol=1e-4)
+    assert _lowest_mismatch(low[:, ::3, ::4], g["lowest_slice"]) < 5e-3
+    # linearity in the current features: cv(a*cur) == a*cv(cur); additivity over source views
+    inp2 = dict(inp)
+    inp2["cur_feats"] = inp["cur_feats"] * 2.0
+    cv2, _, _ = _run(inp2, D)
+    assert rel_err(cv2, 2 * cv) < 1e-6
+    parts = torch.zeros_like(cv)
+    for k0, k1 in ((0, 3), (3, 8)):
+        sub = dict(inp)
+        for key in ("src_feats", "src_extrinsics", "src_poses", "src_Ks"):
+            sub[key] = inp[key][:, k0:k1].contiguous()
+        parts += _run(sub, D)[0]
+    assert rel_err(parts, cv) < 1e-5
+    # zero source features -> zero cost; lowest = first plane (argmax of zeros is index 0)
+    z = dict(inp)
+    z["src_feats"] = torch.zeros_like(inp["src_feats"])
+    cvz, lowz, planes = _run(z, D)
+    assert cvz.abs().max().item() == 0.0
+    assert torch.all(lowz == planes[0])
+
+
+def test_identity_pose_is_self_correlation():
+    """Source == current view with identity relative pose: every plane samples the pixel
+    centre exactly, so cost[b,d,y,x] = K * |cur[b,:,y,x]|^2 for all d."""
+    B, K, C, H, W, D = 1, 2, 16, 16, 24, 6
+    inp = syn.cost_volume_inputs(B, K, C, H, W, 3)
+    eye = torch.eye(4).expand(B, K, 4, 4).contiguous()
+    inp["src_extrinsics"], inp["src_poses"] = eye, eye
+    inp["src_feats"] = inp["cur_feats"].unsqueeze(1).expand(B, K, C, H, W).contiguous()
+    cv, _, _ = _run(inp, D)
+    expect = K * (inp["cur_feats"] ** 2).sum(1, keepdim=True).expand(B, D, H, W)
+    assert rel_err(cv, expect) < 1e-4
+
+
+def test_layout_round_trip():
+    from implicit_depth_amd.cost_volume import to_nchw, to_nhwc
+
+    for shape in [(2, 3, 16, 9, 11), (1, 24, 7, 5), (3, 70, 13, 17)]:
+        x = syn.randn(shape, 5, "lay").cuda()
+        n = to_nhwc(x)
+        assert torch.equal(n.cpu(), x.cpu().movedim(-3, -1).contiguous())
+        assert torch.equal(to_nchw(n).cpu(), x.cpu())
+
+
+def test_zero_cost_volume_manager():
+    from implicit_depth_amd.cost_volume import ZeroCostVolumeManager
+
+    inp = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 2, 16, 8, 8, 0).items()}
+    cv, low, planes, mask = ZeroCostVolumeManager(8, 8, 4).cuda()(**inp)
+    assert cv.abs().max().item() == 0 and mask is None and low.shape == (1, 8, 8)

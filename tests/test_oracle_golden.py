@@ -1,0 +1,186 @@
+"""Pin the oracle (oracle/*.py) against vectors produced by the reference's own modules
+(tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import implicit_depth_amd.synthetic as syn
+from conftest import TOL, chk, load_golden, rel_err
+from oracle import cost_volume as ocv
+from oracle import networks as onet
+
+
+def _inputs(g):
+    B, K, C, H, W, D, seed, bv, rv = [int(v) for v in g["dims"]]
+    return syn.cost_volume_inputs(B, K, C, H, W, seed, bv, rv), D
+
+
+@pytest.mark.parametrize("name", ["g1_small", "g1_b2k7", "g1_ragged"])
+def test_cost_volume_dot_matches_reference(name):
+    g = load_golden(name)
+    inp, D = _inputs(g)
+    # the synthetic inputs must be the ones the reference saw
+    np.testing.assert_allclose(chk(inp["cur_feats"]), g["in_chk"][0], rtol=1e-12)
+    np.testing.assert_allclose(chk(inp["src_feats"]), g["in_chk"][1], rtol=1e-12)
+    assert float(g["fast_maxabs"]) < 1e-4  # reference's own slow-vs-fast cross-check
+    for dt, tol in ((torch.float32, 2e-5), (torch.float64, 2e-5)):
+        cv, low, planes = ocv.cost_volume_dot(
+            inp["cur_feats"].to(dt), inp["src_feats"].to(dt), inp["src_extrinsics"].to(dt),
+            inp["src_Ks"].to(dt), inp["cur_invK"].to(dt), 0.25, 5.0, D)
+        assert rel_err(cv, g["cost_volume"]) < tol
+        assert rel_err(planes, g["planes"]) < 1e-6
+        # argmax can flip on near ties: compare by mismatch rate
+        mism = (torch.as_tensor(g["lowest_cost"]).double() - low.double()).abs() > 1e-5
+        assert mism.float().mean().item() < 5e-3
+
+
+def test_cost_volume_dot_full_size_checksums():
+    g = load_golden("g1_full_k8d64")
+    inp, D = _inputs(g)
+    cv, low, _ = ocv.cost_volume_dot(inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"],
+                                     inp["src_Ks"], inp["cur_invK"], 0.25, 5.0, D)
+    assert rel_err(cv[:, ::4, ::6, ::8], g["cost_slice"]) < 2e-5
+    np.testing.assert_allclose(chk(cv)[1:], g["cost_chk"][1:], rtol=1e-5)
+    mism = (torch.as_tensor(g["lowest_slice"]) - low[:, ::3, ::4]).abs() > 1e-5
+    assert mism.float().mean().item() < 5e-3
+
+
+def _mlp_weights(K, seed):
+    m = torch.nn.Sequential()
+    dims = [16 * (K + 1) + 10 * K + 4, 128, 128, 1]
+    net = torch.nn.Sequential()
+    for i in range(3):
+        net.add_module(str(2 * i), torch.nn.Linear(dims[i], dims[i + 1]))
+    holder = torch.nn.Module()
+    holder.net = net
+    syn.fill_state_dict(holder, seed=seed, gain=1.4)
+    return {k: v for k, v in holder.state_dict().items()}
+
+
+@pytest.mark.parametrize("name", ["g2_small", "g2_b2", "g2_k2"])
+def test_feature_volume_matches_reference(name):
+    g = load_golden(name)
+    inp, D = _inputs(g)
+    K = int(g["dims"][1])
+    w = _mlp_weights(K, int(g["mlp_seed"]))
+    np.testing.assert_allclose(np.stack([chk(v) for v in w.values()]), g["mlp_chk"], rtol=1e-12)
+    assert float(g["fast_maxabs"]) < 1e-4 and bool(g["fast_mask_equal"])
+    fv, low, planes, mask = ocv.feature_volume(
+        inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
+        inp["cur_invK"], 0.25, 5.0, D, w, return_mask=True)
+    assert rel_err(fv, g["feature_volume"]) < 5e-5
+    mm = (mask != torch.as_tensor(g["overall_mask"])).float().mean().item()
+    assert mm < 2e-3  # threshold at 2 px: a coordinate within 1e-5 of it may flip
+    mism = (torch.as_tensor(g["lowest_cost"]) - low).abs() > 1e-5
+    assert mism.float().mean().item() < 5e-3
+
+
+def _sd(module_ctor, seed, gain=1.0):
+    m = module_ctor()
+    syn.fill_state_dict(m, seed=seed, gain=gain)
+    return dict(m.state_dict())
+
+
+class _BB(torch.nn.Module):
+    """Parameter container with the reference BasicBlock's key names (layers.py:59-75)."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv1 = torch.nn.Conv2d(cin, cout, 3, stride, 1)
+        self.conv2 = torch.nn.Conv2d(cout, cout, 3, 1, 1)
+        if cin != cout or stride != 1:
+            k = 1 if stride == 1 else 3
+            self.downsample = torch.nn.Sequential(torch.nn.Conv2d(cin, cout, k, stride, k // 2), torch.nn.Identity())
+
+
+@pytest.mark.parametrize("tag", ["id", "proj", "down"])
+def test_basic_block_matches_reference(tag):
+    g = load_golden(f"g3_basicblock_{tag}")
+    cin, cout, stride = [int(v) for v in g["dims"]]
+    w = _sd(lambda: _BB(cin, cout, stride), 10)
+    assert sorted(w) == list(g["keys"])
+    x = syn.randn((2, 24, 12, 20), 7, "bb_x")
+    assert rel_err(onet.basic_block(x, w, stride), g["y"]) < 1e-5
+
+
+def test_upsample2_is_bilinear_x2():
+    x = syn.randn((2, 3, 5, 7), 3, "up")
+    ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    assert rel_err(onet.upsample2(x), ref) < 1e-6
+
+
+def test_cvencoder_and_decoders_match_reference():
+    from implicit_depth_amd import networks as net  # drop-in modules carry the reference key names
+
+    Hm, Wm, Dcv = 24, 32, 16
+    pyr = syn.encoder_pyramid(1, Hm * 4, Wm * 4, seed=11)
+    cvol = syn.randn((1, Dcv, Hm, Wm), 11, "cv_in")
+    g = load_golden("g3_cvencoder")
+    cve = net.CVEncoder(num_ch_cv=Dcv, num_ch_enc=[48, 64, 160, 256], num_ch_outs=[64, 128, 256, 384])
+    syn.fill_state_dict(cve, seed=12)
+    w = dict(cve.state_dict())
+    assert sorted(w) == list(g["keys"])
+    outs = onet.cv_encoder(cvol, list(pyr[1:]), w)
+    for i, o in enumerate(outs):
+        assert rel_err(o, g[f"o{i}"]) < 2e-5
+    dec_in = [pyr[0]] + outs
+    for cls, nm, head, key in ((net.BDDecoderPP, "g3_bddecoder", False, "feature_s{}_b1hw"),
+                               (net.DepthDecoderPP, "g3_depthdecoder", True, "log_depth_pred_s{}_b1hw")):
+        g = load_golden(nm)
+        dec = cls([24, 64, 128, 256, 384])
+        syn.fill_state_dict(dec, seed=13)
+        w = dict(dec.state_dict())
+        assert sorted(w) == list(g["keys"])
+        out = onet.unetpp_decoder(dec_in, w, depth_head=head)
+        for i in range(4):
+            assert rel_err(out[key.format(i)], g[f"s{i}"]) < 5e-5
+
+
+@pytest.mark.parametrize("use_prior", [False, True])
+def test_binary_mlp_matches_reference(use_prior):
+    from implicit_depth_amd import networks as net
+
+    g = load_golden(f"g4_binarymlp_prior{int(use_prior)}")
+    feat = torch.as_tensor(load_golden("g3_bddecoder")["s0"])
+    Bq, Hq, Wq, P = 1, 48, 64, 3
+    rd = syn.rendered_depth_planes(Bq, Hq, Wq, P)
+    rd[:, 1, :5, :7] = 0.0
+    prior = torch.sigmoid(syn.randn((Bq, 1, Hq, Wq), 14, "prior"))
+    m = net.BinaryMLPNetwork([64, 64, 128, 256], mlp_size=128, use_prior=use_prior)
+    syn.fill_state_dict(m, seed=15, gain=1.2)
+    w = dict(m.state_dict())
+    assert sorted(w) == list(g["keys"])
+    pri = None
+    if use_prior:
+        pri = torch.cat([prior * 2 - 1] + [-torch.ones_like(prior)] * (P - 1), 1)
+    out = onet.occlusion_logits(feat, rd, w, pri)
+    assert rel_err(out, g["logits"]) < 2e-5
+
+
+def test_sample_prior_matches_reference():
+    g = load_golden("g4_sample_prior")
+    Hq, Wq = [int(v) for v in g["dims"]]
+    rd = syn.rendered_depth_planes(1, Hq, Wq, 3)
+    rd[:, 1, :5, :7] = 0.0
+    prior = torch.sigmoid(syn.randn((1, 1, Hq, Wq), 14, "prior"))
+    Ks0 = syn.intrinsics(Wq, Hq).float()[None]
+    cur_pose = syn.source_pose(0).float()[None]
+    prev_pose = syn.source_pose(1).float()[None]
+    sp = onet.sample_prior(rd[:, 1:2], prior, cur_pose, torch.linalg.inv(prev_pose), Ks0, torch.linalg.inv(Ks0))
+    mism = (sp - torch.as_tensor(g["sampled"])).abs() > 1e-6
+    assert mism.float().mean().item() < 2e-3  # nearest-neighbour: a .5 tie may round the other way
+
+
+def test_geometry_unit_vectors():
+    g = load_golden("g6_geometry")
+    assert rel_err(ocv.depth_planes(0.25, 5.0, 64), g["planes64"]) < 1e-6
+    assert rel_err(ocv.depth_planes(0.25, 5.0, 96), g["planes96"]) < 1e-6
+    poses = torch.stack([syn.source_pose(k).float() for k in range(8)])
+    pd = torch.stack(ocv.pose_distance(poses))
+    assert rel_err(pd, g["pose_dist"]) < 1e-6
+    invK = torch.linalg.inv(syn.intrinsics(8, 6)).float()[None]
+    rays = ocv._pixel_rays(invK, 6, 8)
+    P = ocv._P(syn.intrinsics(8, 6).float()[None, None], torch.linalg.inv(poses[2])[None, None])
+    X, u, v, z = ocv.project_plane(rays, torch.tensor(1.7), P)
+    assert rel_err(X, g["backproject"][:, :3]) < 1e-6
+    assert rel_err(torch.stack([u[0, 0], v[0, 0], z[0, 0]]), g["project"][0]) < 1e-5
