@@ -29,6 +29,10 @@ _SIGS = {
     "idh_error_string": (C.c_char_p, [C.c_int]),
     "idh_nchw_to_nhwc_f32": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idh_nhwc_to_nchw_f32": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "idh_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "idh_pack_conv_weight": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "idh_sizeof_op": (C.c_size_t, []),
+    "idh_run_ops": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "idh_cost_volume_dot_fwd": (
         C.c_int,
         [f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_float] + [C.c_int] * 6 + [f32p, f32p, f32p, C.c_void_p],

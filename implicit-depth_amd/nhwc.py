@@ -1,0 +1,442 @@
+"""Host-side execution plans for the conv stage of the hot path.
+
+A *plan* is a flat array of ``idh_op`` descriptors (include/idh_ops.h) plus the NHWC
+activation buffers they point into, built once per (module, input shape, device) and replayed
+with a single C-ABI call (``idh_run_ops``).  torch only owns the memory and the stream.
+
+What the plans encode (reference modules/networks.py + modules/layers.py):
+  BasicBlock   -> conv1(+LeakyReLU)  then ONE launch for conv2 + residual: the 1x1 / strided-3x3
+                  projection of the block input is a second K-source of that launch, the identity
+                  residual is added in the epilogue
+  torch.cat    -> producers write into channel slices of the consumer's input buffer
+  upsample     -> bilinear x2 kernel writing straight into that slice
+  heads        -> only the ``output_i`` results that survive in the reference's dict are
+                  computed (the reference evaluates and discards the others, networks.py:80)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import _lib
+
+# --- ctypes mirrors of include/idh_ops.h -------------------------------------------------
+OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD = 1, 2, 3, 4, 5, 6
+ACT_NONE, ACT_LRELU = 0, 1
+PAD_ZEROS, PAD_REPLICATE = 0, 1
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("w", C.c_void_p), ("cs", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Cin", C.c_int32), ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("_r", C.c_int32)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("src", ConvSrc * 2), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("out", C.c_void_p), ("ws", C.c_void_p), ("res_cs", C.c_int32), ("out_cs", C.c_int32), ("Ho", C.c_int32),
+                ("Wo", C.c_int32), ("Cout", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("split_k", C.c_int32),
+                ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("_pad", C.c_int32)]
+
+
+def _bind():
+    return _lib.lib()
+
+
+# --- NHWC views ---------------------------------------------------------------------------
+@dataclass
+class View:
+    """Channel slice [c0, c0+C) of a dense NHWC buffer (N,H,W,CS)."""
+
+    buf: torch.Tensor
+    c0: int
+    C: int
+
+    @property
+    def N(self):
+        return self.buf.shape[0]
+
+    @property
+    def H(self):
+        return self.buf.shape[1]
+
+    @property
+    def W(self):
+        return self.buf.shape[2]
+
+    @property
+    def cs(self):
+        return self.buf.shape[3]
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + 4 * self.c0
+
+    def slice(self, c0, C):
+        return View(self.buf, self.c0 + c0, C)
+
+    def dense(self) -> torch.Tensor:
+        return self.buf[..., self.c0 : self.c0 + self.C]
+
+
+def ceil16(v: int) -> int:
+    return (v + 15) & ~15
+
+
+def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
+    """[tap][ci/4][co][ci%4] copy of a Conv2d weight, cached on the module and refreshed when
+    the parameter is modified in place or moved."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    cached = getattr(conv, "_idh_packed", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    _lib.require_cuda_f32(w)
+    L = _bind()
+    co, ci, kh, kw = w.shape
+    if kh != kw or kh not in (1, 3):
+        raise _lib.IdhError(f"conv kernel {kh}x{kw} not covered by the gfx950 conv kernel (1x1 / 3x3 only)")
+    n = L.idh_packed_weight_floats(co, ci, kh)
+    dst = torch.empty(n, device=w.device, dtype=torch.float32)
+    _lib.check(L.idh_pack_conv_weight(w.detach().contiguous().data_ptr(), dst.data_ptr(), co, ci, kh, _lib.stream_ptr()), "idh_pack_conv_weight")
+    conv._idh_packed = (key, dst)
+    return dst
+
+
+TARGET_WAVES = 2048  # ~2 waves per SIMD over 256 CUs x 4 SIMDs
+MIN_WAVES = 1024
+
+
+def choose_tiles(M: int, cout: int, steps: int):
+    nsub = ceil16(cout) // 16
+    tn = 4 if nsub % 4 == 0 else (2 if nsub % 2 == 0 else 1)
+    tm, waves = 1, 0
+    for cand in (4, 2, 1):
+        waves = -(-M // (16 * cand)) * (nsub // tn)
+        tm = cand
+        if waves >= TARGET_WAVES:
+            break
+    split = 1
+    if waves < MIN_WAVES:
+        split = max(1, min(-(-MIN_WAVES // waves), steps // 4, 32))
+    return tm, tn, split
+
+
+class Plan:
+    """Ordered op list + owned buffers.  ``run()`` = one C-ABI call."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ops: List[Op] = []
+        self.keep: List[torch.Tensor] = []  # buffers / packed weights referenced by raw pointer
+        self._arr = None
+        self.flops = 0  # 2*MAC of the conv ops (algorithmic, no padding)
+
+    # buffers -------------------------------------------------------------------------
+    def buffer(self, N, H, W, Cch) -> View:
+        t = torch.empty(N, H, W, Cch, device=self.device, dtype=torch.float32)
+        self.keep.append(t)
+        return View(t, 0, Cch)
+
+    # ops -----------------------------------------------------------------------------
+    def conv(self, x: View, conv: nn.Conv2d, out: View, act=ACT_NONE, slope=0.2, res: Optional[View] = None,
+             x2: Optional[View] = None, conv2: Optional[nn.Conv2d] = None, pad_mode=PAD_ZEROS):
+        op = Op()
+        op.kind = OP_CONV
+        op.N = x.N
+        srcs = [(x, conv)] + ([(x2, conv2)] if x2 is not None else [])
+        steps = 0
+        for i, (v, cv) in enumerate(srcs):
+            ks, st = cv.kernel_size[0], cv.stride[0]
+            if v.C != cv.in_channels:
+                raise _lib.IdhError(f"conv expects {cv.in_channels} input channels, view has {v.C}")
+            w = packed_weight(cv)
+            self.keep.append(w)
+            s = op.src[i]
+            s.in_, s.w, s.cs, s.H, s.W, s.Cin = v.ptr, w.data_ptr(), v.cs, v.H, v.W, v.C
+            s.ks, s.stride, s.pad_mode = ks, st, pad_mode
+            steps += ks * ks * (ceil16(v.C) // 16)
+            self.flops += 2 * out.N * out.H * out.W * cv.out_channels * cv.in_channels * ks * ks
+        bias = conv.bias
+        if conv2 is not None and conv2.bias is not None:
+            bias = (conv.bias + conv2.bias).detach() if conv.bias is not None else conv2.bias
+        if bias is not None:
+            bias = bias.detach().contiguous()
+            self.keep.append(bias)
+            op.bias = bias.data_ptr()
+        if res is not None:
+            op.res, op.res_cs = res.ptr, res.cs
+        op.out, op.out_cs = out.ptr, out.cs
+        op.Ho, op.Wo, op.Cout = out.H, out.W, conv.out_channels
+        op.act, op.slope = act, slope
+        M = out.N * out.H * out.W
+        tm, tn, split = choose_tiles(M, conv.out_channels, steps)
+        op.tile_m, op.tile_n, op.split_k = tm, tn, split
+        if split > 1:
+            ws = torch.empty(split * M * ceil16(conv.out_channels), device=self.device, dtype=torch.float32)
+            self.keep.append(ws)
+            op.ws = ws.data_ptr()
+        self.ops.append(op)
+        self._arr = None
+        return out
+
+    def upsample2(self, x: View, out: View):
+        op = Op()
+        op.kind, op.N = OP_UPSAMPLE2, x.N
+        s = op.src[0]
+        s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
+        op.out, op.out_cs = out.ptr, out.cs
+        self.ops.append(op)
+        self._arr = None
+        return out
+
+    def import_nchw(self, shape_nchw, out: View) -> int:
+        """(N,C,H,W) dense -> NHWC slice.  The source pointer is patched per call with
+        ``set_in``; returns the op index."""
+        N, Cc, H, W = [int(v) for v in shape_nchw]
+        if (N, H, W, Cc) != (out.N, out.H, out.W, out.C):
+            raise _lib.IdhError(f"import of {tuple(shape_nchw)} into a view of {(out.N, out.C, out.H, out.W)}")
+        op = Op()
+        op.kind, op.N = OP_IMPORT, N
+        s = op.src[0]
+        s.H, s.W, s.Cin = H, W, Cc
+        op.out, op.out_cs = out.ptr, out.cs
+        self.ops.append(op)
+        self._arr = None
+        return len(self.ops) - 1
+
+    def export_nchw(self, x: View, out_nchw: Optional[torch.Tensor] = None) -> int:
+        op = Op()
+        op.kind, op.N = OP_EXPORT, x.N
+        s = op.src[0]
+        s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
+        if out_nchw is not None:
+            op.out = out_nchw.data_ptr()
+        self.ops.append(op)
+        self._arr = None
+        return len(self.ops) - 1
+
+    def head(self, x: View, conv: nn.Conv2d, out: torch.Tensor):
+        """1x1 conv to one channel (DepthDecoderPP heads, reference networks.py:158-161)."""
+        if conv.out_channels != 1 or conv.kernel_size != (1, 1):
+            raise _lib.IdhError("pointwise head kernel covers Conv2d(C,1,1) only")
+        op = Op()
+        op.kind, op.N = OP_HEAD, x.N
+        w = conv.weight.detach().reshape(-1).contiguous()
+        b = conv.bias.detach().contiguous()
+        self.keep += [w, b]
+        s = op.src[0]
+        s.in_, s.w, s.cs, s.H, s.W, s.Cin = x.ptr, w.data_ptr(), x.cs, x.H, x.W, x.C
+        op.bias, op.out = b.data_ptr(), out.data_ptr()
+        self.ops.append(op)
+        self._arr = None
+        return len(self.ops) - 1
+
+    # composite: BasicBlock (reference layers.py:78-95) ---------------------------------
+    def basic_block(self, x: View, blk, out: Optional[View] = None) -> View:
+        st = blk.conv1.stride[0]
+        Ho = (x.H + 2 - 3) // st + 1
+        Wo = (x.W + 2 - 3) // st + 1
+        planes = blk.conv1.out_channels
+        h = self.buffer(x.N, Ho, Wo, planes)
+        self.conv(x, blk.conv1, h, act=ACT_LRELU, slope=0.2)
+        if out is None:
+            out = self.buffer(x.N, Ho, Wo, planes)
+        if blk.downsample is None:
+            self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=x)
+        else:
+            self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, x2=x, conv2=blk.downsample[0])
+        return out
+
+    # execution -----------------------------------------------------------------------
+    def _array(self):
+        if self._arr is None:
+            self._arr = (Op * len(self.ops))(*self.ops)
+        return self._arr
+
+    def run(self):
+        L = _bind()
+        arr = self._array()
+        _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(self.ops), _lib.stream_ptr()), "idh_run_ops")
+
+    def set_in(self, idx: int, t: torch.Tensor):
+        self._array()[idx].src[0].in_ = t.data_ptr()
+
+    def set_out(self, idx: int, t: torch.Tensor):
+        self._array()[idx].out = t.data_ptr()
+
+
+def _plan_cache(module: nn.Module) -> Dict:
+    c = module.__dict__.get("_idh_plans")
+    if c is None:
+        c = {}
+        module.__dict__["_idh_plans"] = c
+    return c
+
+
+def _param_key(module: nn.Module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+def _check_in(*ts):
+    for t in ts:
+        _lib.require_cuda_f32(t)
+        if t.dim() != 4:
+            raise _lib.IdhError(f"expected NCHW tensors, got shape {tuple(t.shape)}")
+
+
+# --- BasicBlock as a stand-alone drop-in ----------------------------------------------------
+def block_forward_nchw(blk, x: torch.Tensor) -> torch.Tensor:
+    _check_in(x)
+    x = x.contiguous()
+    key = ("bb", tuple(x.shape), str(x.device), _param_key(blk))
+    cache = _plan_cache(blk)
+    ent = cache.get(key)
+    if ent is None:
+        cache.clear()
+        p = Plan(x.device)
+        N, Cc, H, W = x.shape
+        xin = p.buffer(N, H, W, Cc)
+        i_in = p.import_nchw(x.shape, xin)
+        y = p.basic_block(xin, blk)
+        i_out = p.export_nchw(y)
+        ent = (p, i_in, i_out, y)
+        cache[key] = ent
+    p, i_in, i_out, y = ent
+    out = torch.empty(y.N, y.C, y.H, y.W, device=x.device, dtype=torch.float32)
+    p.set_in(i_in, x)
+    p.set_out(i_out, out)
+    p.run()
+    return out
+
+
+# --- CVEncoder (reference networks.py:186-215) --------------------------------------------
+def build_cv_encoder(p: Plan, enc, cost: View, img_feat_shapes: Sequence[Sequence[int]]):
+    """Adds the encoder to plan ``p``.  Returns (outputs: List[View], import op indices for
+    img_feats)."""
+    outs, imports = [], []
+    x = cost
+    for i in range(enc.num_blocks):
+        ds = enc.convs[f"ds_conv_{i}"]
+        st = ds.conv1.stride[0]
+        Ho, Wo = (x.H + 2 - 3) // st + 1, (x.W + 2 - 3) // st + 1
+        cout = ds.conv1.out_channels
+        cimg = img_feat_shapes[i][1]
+        if tuple(img_feat_shapes[i][2:]) != (Ho, Wo):
+            raise _lib.IdhError(f"img_feats[{i}] spatial size {tuple(img_feat_shapes[i][2:])} != {(Ho, Wo)}")
+        cat = p.buffer(x.N, Ho, Wo, cout + cimg)
+        p.basic_block(x, ds, out=cat.slice(0, cout))
+        imports.append(p.import_nchw(img_feat_shapes[i], cat.slice(cout, cimg)))
+        seq = enc.convs[f"conv_{i}"]
+        y = p.basic_block(cat, seq[0])
+        y = p.basic_block(y, seq[1])
+        outs.append(y)
+        x = y
+    return outs, imports
+
+
+def cv_encoder_forward_nchw(enc, x: torch.Tensor, img_feats: List[torch.Tensor]) -> List[torch.Tensor]:
+    _check_in(x, *img_feats)
+    x = x.contiguous()
+    img_feats = [f.contiguous() for f in img_feats]
+    key = ("cve", tuple(x.shape), tuple(tuple(f.shape) for f in img_feats), str(x.device), _param_key(enc))
+    cache = _plan_cache(enc)
+    ent = cache.get(key)
+    if ent is None:
+        cache.clear()
+        p = Plan(x.device)
+        N, D, H, W = x.shape
+        xin = p.buffer(N, H, W, D)
+        i_x = p.import_nchw(x.shape, xin)
+        outs, i_img = build_cv_encoder(p, enc, xin, [f.shape for f in img_feats])
+        i_out = [p.export_nchw(o) for o in outs]
+        ent = (p, i_x, i_img, i_out, outs)
+        cache[key] = ent
+    p, i_x, i_img, i_out, outs = ent
+    res = [torch.empty(o.N, o.C, o.H, o.W, device=x.device, dtype=torch.float32) for o in outs]
+    p.set_in(i_x, x)
+    for i, f in zip(i_img, img_feats):
+        p.set_in(i, f)
+    for i, r in zip(i_out, res):
+        p.set_out(i, r)
+    p.run()
+    return res
+
+
+# --- UNet++ decoders (reference networks.py:20-84, 118-183) ------------------------------
+def build_decoder(p: Plan, dec, feats: List[View]):
+    """Adds the UNet++ grid to ``p``; returns {scale i: View of the surviving output_i result
+    (before the optional 1x1 depth head)}."""
+    prev = list(feats)
+    outputs: List[View] = []
+    final: Dict[int, View] = {}
+    for j in range(1, 5):
+        for i in range(4 - j, -1, -1):
+            right = dec.convs[f"right_conv_{i}{j - 1}"]
+            diag = dec.convs[f"diag_conv_{i + 1}{j - 1}"]
+            cout = right.conv1.out_channels
+            has_up = (i + j) != 4
+            xi = prev[i]
+            cat = p.buffer(xi.N, xi.H, xi.W, cout * (3 if has_up else 2))
+            p.basic_block(xi, right, out=cat.slice(0, cout))
+            lo = p.basic_block(prev[i + 1], diag)
+            if (lo.H * 2, lo.W * 2) != (xi.H, xi.W):
+                raise _lib.IdhError("decoder pyramid levels must differ by exactly x2")
+            p.upsample2(lo, cat.slice(cout, cout))
+            if has_up:
+                lo2 = p.basic_block(outputs[-1], dec.convs[f"up_conv_{i + 1}{j}"])
+                p.upsample2(lo2, cat.slice(2 * cout, cout))
+            seq = dec.convs[f"in_conv_{i}{j}"]
+            y = p.basic_block(cat, seq[0])
+            y = p.basic_block(y, seq.conv_0)
+            outputs.append(y)
+            if j == 4 - i:  # the only (i,j) whose output_i result survives in the dict
+                head = dec.convs[f"output_{i}"]
+                final[i] = p.basic_block(y, head[0]) if not isinstance(head[0], nn.Identity) else y
+        prev = outputs[::-1]
+    return final
+
+
+def decoder_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dict[str, torch.Tensor]:
+    _check_in(*input_features)
+    feats = [f.contiguous() for f in input_features]
+    key = ("dec", tuple(tuple(f.shape) for f in feats), str(feats[0].device), _param_key(dec))
+    cache = _plan_cache(dec)
+    ent = cache.get(key)
+    if ent is None:
+        cache.clear()
+        p = Plan(feats[0].device)
+        views, i_in = [], []
+        for f in feats:
+            v = p.buffer(f.shape[0], f.shape[2], f.shape[3], f.shape[1])
+            i_in.append(p.import_nchw(f.shape, v))
+            views.append(v)
+        final = build_decoder(p, dec, views)
+        i_out = {}
+        for i, v in final.items():
+            if dec.depth_head:
+                i_out[i] = p.head(v, dec.convs[f"output_{i}"][1], torch.empty(1, device=feats[0].device))
+            else:
+                i_out[i] = p.export_nchw(v)
+        ent = (p, i_in, i_out, final)
+        cache[key] = ent
+    p, i_in, i_out, final = ent
+    for i, f in zip(i_in, feats):
+        p.set_in(i, f)
+    res = {}
+    for i, v in final.items():
+        ch = 1 if dec.depth_head else v.C
+        t = torch.empty(v.N, ch, v.H, v.W, device=feats[0].device, dtype=torch.float32)
+        p.set_out(i_out[i], t)
+        res[dec.out_key.format(i)] = t
+    p.run()
+    return res
+
+
+def binary_mlp_forward(net, inputs, max_scale_only):
+    from .mlp import binary_mlp_forward as f
+
+    return f(net, inputs, max_scale_only)

@@ -1,0 +1,75 @@
+/*
+ * idh_ops.h — op descriptors for the conv / upsample / layout stage of the hot path.
+ *
+ * The reference runs CVEncoder / BDDecoderPP / DepthDecoderPP (modules/networks.py:20-215)
+ * as ~150 nn.Conv2d + F.interpolate + torch.cat calls.  Here a network pass is a flat array
+ * of idh_op descriptors, built once per (module, shape) by the host and submitted with ONE
+ * call, idh_run_ops(); every op is one gfx950 kernel launch on the given stream.
+ * All activations are NHWC fp32.  "cs" = channel stride = floats between consecutive pixels
+ * (>= channel count), which is how torch.cat along channels is eliminated: producers write
+ * straight into a channel slice of the consumer's input buffer.
+ */
+#ifndef IDH_OPS_H_
+#define IDH_OPS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    IDH_OP_CONV = 1,        /* implicit-GEMM conv on fp32 MFMA (layers.py:59-75 convs)       */
+    IDH_OP_UPSAMPLE2 = 2,   /* bilinear x2, align_corners=False (generic_utils.py:94-103)    */
+    IDH_OP_NCHW_TO_NHWC = 3,/* strided layout import: (N,C,H,W) -> NHWC slice                */
+    IDH_OP_NHWC_TO_NCHW = 4,/* strided layout export: NHWC slice -> (N,C,H,W)                */
+    IDH_OP_SPLITK_REDUCE = 5,/* sum split-K partials + bias + residual + activation          */
+    IDH_OP_POINTWISE_HEAD = 6 /* 1x1 conv to 1 channel (DepthDecoderPP heads, networks.py:158-161) */
+};
+
+#define IDH_PAD_ZEROS 0
+#define IDH_PAD_REPLICATE 1
+
+/* One conv source: input tensor + its packed weights.  A conv op may sum TWO sources into
+ * the same accumulator: BasicBlock's conv2(h) + downsample(x) (layers.py:86-92) becomes one
+ * launch whose second source is the 1x1 (or strided 3x3) projection of the block input. */
+typedef struct idh_conv_src {
+    const float *in; /* NHWC, N x H x W x (cs) */
+    const float *w;  /* packed by idh_pack_conv_weight: [ks*ks][Cin_pad/4][Cout_pad][4] */
+    int32_t cs, H, W, Cin;
+    int32_t ks, stride, pad_mode, _r;
+} idh_conv_src;
+
+typedef struct idh_op {
+    int32_t kind;
+    int32_t N;            /* batch */
+    idh_conv_src src[2];  /* src[1].in == NULL when unused */
+    const float *bias;    /* Cout floats (already summed over sources) or NULL */
+    const float *res;     /* residual NHWC (same Ho x Wo) or NULL */
+    float *out;           /* NHWC Ho x Wo x out_cs (or NCHW for the export op) */
+    float *ws;            /* split-K partials: split_k x M x Cout_pad floats */
+    int32_t res_cs, out_cs;
+    int32_t Ho, Wo, Cout;
+    int32_t act;          /* IDH_ACT_* */
+    float slope;
+    int32_t split_k;      /* 1 = no split */
+    int32_t tile_m, tile_n; /* wave tile in 16-wide MFMA sub-tiles (1,2,4); 0 = auto */
+    int32_t _pad;
+} idh_op;
+
+/* Repack OIHW conv weights (reference nn.Conv2d layout) for the MFMA B-fragment loads:
+ * dst[tap][ci/4][co][ci%4], zero padded to Cin_pad = ceil16(Cin), Cout_pad = ceil16(Cout).
+ * dst must hold idh_packed_weight_floats(Cout,Cin,ks) floats. */
+size_t idh_packed_weight_floats(int Cout, int Cin, int ks);
+int idh_pack_conv_weight(const float *w_oihw, float *dst, int Cout, int Cin, int ks, void *stream);
+
+/* sizeof(idh_op) as compiled into the library (bindings assert their mirror matches). */
+size_t idh_sizeof_op(void);
+
+/* Launch n ops in order on `stream`. `ops_host` is HOST memory (pointers inside are device). */
+int idh_run_ops(const idh_op *ops_host, int n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,7 +11,7 @@ from conftest import ROOT
 
 
 def _header_symbols():
-    txt = open(os.path.join(ROOT, "include", "idh.h")).read()
+    txt = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include"))) if f.endswith(".h"))
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(idh_[a-z0-9_]+)\s*\(", txt)))
 
@@ -54,3 +54,13 @@ def test_product_path_refuses_cpu_tensors():
     inp = syn.cost_volume_inputs(1, 2, 16, 8, 8, 0)
     with pytest.raises(_lib.IdhError):
         CostVolumeManager(8, 8, 4)(**inp)
+
+
+def test_op_descriptor_layout_matches_library():
+    import ctypes
+
+    from implicit_depth_amd import _lib, nhwc
+
+    assert ctypes.sizeof(nhwc.Op) == _lib.lib().idh_sizeof_op()
+    assert _lib.lib().idh_packed_weight_floats(40, 24, 3) == 9 * 32 * 48
+    assert _lib.lib().idh_run_ops(None, 0, None) == 0

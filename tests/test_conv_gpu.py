@@ -1,0 +1,120 @@
+"""HIP implicit-GEMM conv stack (BasicBlock / CVEncoder / UNet++ decoders) vs the reference
+goldens and the oracle.  fp32 MFMA is exact fp32, so the bar is the 1e-4 scale-relative
+tolerance of BASELINE.json with a lot of room."""
+import pytest
+import torch
+
+import implicit_depth_amd.synthetic as syn
+from conftest import TOL, load_golden, rel_err
+from oracle import networks as onet
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu_sd(m):
+    return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("tag", ["id", "proj", "down"])
+def test_basic_block_golden(tag):
+    from implicit_depth_amd.layers import BasicBlock
+
+    g = load_golden(f"g3_basicblock_{tag}")
+    cin, cout, stride = [int(v) for v in g["dims"]]
+    bb = BasicBlock(cin, cout, stride)
+    syn.fill_state_dict(bb, seed=10)
+    x = syn.randn((2, 24, 12, 20), 7, "bb_x")
+    y = bb.cuda()(x.cuda()).cpu()
+    assert rel_err(y, g["y"]) < TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 16, 9, 7, 1), (3, 64, 64, 33, 47, 1), (2, 112, 64, 24, 32, 1), (1, 64, 128, 31, 45, 2),
+                                   (2, 416, 256, 6, 8, 1), (1, 256, 384, 12, 16, 2), (4, 640, 384, 3, 4, 1), (1, 24, 64, 40, 52, 1)])
+def test_basic_block_vs_oracle(shape):
+    """odd sizes, channel counts of every CVEncoder/decoder layer family, split-K (tiny maps)."""
+    from implicit_depth_amd.layers import BasicBlock
+
+    N, cin, cout, H, W, stride = shape
+    bb = BasicBlock(cin, cout, stride)
+    syn.fill_state_dict(bb, seed=cin + cout)
+    x = syn.randn((N, cin, H, W), 3, "x")
+    ref = onet.basic_block(x.double(), {k: v.double() for k, v in _cpu_sd(bb).items()}, stride)
+    y = bb.cuda()(x.cuda()).cpu()
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < TOL
+    # second call replays the cached plan on fresh inputs
+    x2 = syn.randn((N, cin, H, W), 4, "x2")
+    ref2 = onet.basic_block(x2.double(), {k: v.double() for k, v in _cpu_sd(bb).items()}, stride)
+    assert rel_err(bb(x2.cuda()).cpu(), ref2) < TOL
+
+
+def test_weight_update_invalidates_packed_cache():
+    from implicit_depth_amd.layers import BasicBlock
+
+    bb = BasicBlock(16, 16).cuda()
+    syn.fill_state_dict(bb, seed=1)
+    x = syn.randn((1, 16, 8, 8), 1, "x").cuda()
+    y0 = bb(x).clone()
+    with torch.no_grad():
+        bb.conv2.weight.mul_(0.5)
+        bb.conv2.bias.zero_()
+    y1 = bb(x)
+    ref = onet.basic_block(x.cpu().double(), {k: v.double() for k, v in _cpu_sd(bb).items()})
+    assert rel_err(y1.cpu(), ref) < TOL and not torch.equal(y0, y1)
+
+
+def _nets():
+    from implicit_depth_amd import networks as net
+
+    Hm, Wm, Dcv = 24, 32, 16
+    pyr = syn.encoder_pyramid(1, Hm * 4, Wm * 4, seed=11)
+    cvol = syn.randn((1, Dcv, Hm, Wm), 11, "cv_in")
+    cve = net.CVEncoder(num_ch_cv=Dcv, num_ch_enc=[48, 64, 160, 256], num_ch_outs=[64, 128, 256, 384])
+    syn.fill_state_dict(cve, seed=12)
+    return net, pyr, cvol, cve
+
+
+def test_cvencoder_golden():
+    net, pyr, cvol, cve = _nets()
+    g = load_golden("g3_cvencoder")
+    outs = cve.cuda()(cvol.cuda(), [p.cuda() for p in pyr[1:]])
+    for i, o in enumerate(outs):
+        assert rel_err(o.cpu(), g[f"o{i}"]) < TOL
+
+
+@pytest.mark.parametrize("which", ["bd", "depth"])
+def test_decoders_golden(which):
+    net, pyr, cvol, cve = _nets()
+    gin = load_golden("g3_cvencoder")
+    dec_in = [pyr[0]] + [torch.as_tensor(gin[f"o{i}"]) for i in range(4)]
+    cls, nm, key = ((net.BDDecoderPP, "g3_bddecoder", "feature_s{}_b1hw") if which == "bd"
+                    else (net.DepthDecoderPP, "g3_depthdecoder", "log_depth_pred_s{}_b1hw"))
+    g = load_golden(nm)
+    dec = cls([24, 64, 128, 256, 384])
+    syn.fill_state_dict(dec, seed=13)
+    out = dec.cuda()([t.cuda() for t in dec_in])
+    assert sorted(out) == sorted(key.format(i) for i in range(4))
+    for i in range(4):
+        assert rel_err(out[key.format(i)].cpu(), g[f"s{i}"]) < TOL
+
+
+def test_cvencoder_decoder_batched_vs_oracle():
+    """B=2, D=64 (ds_conv_0 identity residual) at a non-golden size."""
+    from implicit_depth_amd import networks as net
+
+    B, Hm, Wm, D = 2, 16, 24, 64
+    pyr = syn.encoder_pyramid(B, Hm * 4, Wm * 4, seed=21)
+    cvol = syn.randn((B, D, Hm, Wm), 21, "cv")
+    cve = net.CVEncoder(D, [48, 64, 160, 256], [64, 128, 256, 384])
+    dec = net.BDDecoderPP([24, 64, 128, 256, 384])
+    syn.fill_state_dict(cve, seed=22)
+    syn.fill_state_dict(dec, seed=23)
+    ref_e = onet.cv_encoder(cvol, list(pyr[1:]), _cpu_sd(cve))
+    ref_d = onet.unetpp_decoder([pyr[0]] + ref_e, _cpu_sd(dec), depth_head=False)
+    cve.cuda(), dec.cuda()
+    outs = cve(cvol.cuda(), [p.cuda() for p in pyr[1:]])
+    for o, r in zip(outs, ref_e):
+        assert rel_err(o.cpu(), r) < TOL
+    out = dec([pyr[0].cuda()] + outs)
+    for i in range(4):
+        assert rel_err(out[f"feature_s{i}_b1hw"].cpu(), ref_d[f"feature_s{i}_b1hw"]) < TOL

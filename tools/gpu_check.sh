@@ -14,7 +14,8 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 echo "== bench ==" 
 timeout 600 python bench.py 2>&1 | tail -3 | tee $OUT/bench.json
 echo "== rocprofv3 kernel stats ==" 
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --no-cpu-baseline --steps 30 > $OLDPWD/$OUT/prof_bench.log 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --no-cpu-baseline --steps 30 > $OLDPWD/$OUT/prof_bench.log 2>&1 )
 find $OUT/prof -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -12 "$f" | tee $OUT/kernel_stats_head.csv
+ls $OUT/prof/* | head
