@@ -92,7 +92,7 @@ class CostVolumeManager(nn.Module):
         _lib.check(
             L.idh_cost_volume_dot_fwd(
                 _lib.ptr(cur_n), _lib.ptr(src_n), _lib.ptr(src_Ks.contiguous()), _lib.ptr(src_extrinsics.contiguous()),
-                _lib.ptr(cur_invK.contiguous()), dmin, dmax, B, K, C, H, W, D, _lib.ptr(cost), _lib.ptr(lowest),
+                _lib.ptr(cur_invK.contiguous()), dmin, dmax, B, K, C, H, W, D, _lib.ptr(cost), 0, _lib.ptr(lowest),
                 _lib.ptr(planes_d), _lib.stream_ptr()),
             "idh_cost_volume_dot_fwd",
         )

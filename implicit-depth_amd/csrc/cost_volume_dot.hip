@@ -16,8 +16,8 @@
 // 4 x dwordx4.  Work decomposition: a 256-thread workgroup owns 32 consecutive pixels and ALL
 // D planes: thread (px, g) sweeps planes [g*DP, (g+1)*DP) for its pixel, g = 0..7, so the
 // arg-max over planes finishes inside the workgroup (LDS reduce, first maximum wins) and the
-// cost volume is written exactly once.  The per-(b,k) 3x4 homographies are wave-uniform and
-// come through the scalar cache.
+// cost volume is written exactly once.  The per-(b,k) 3x4 homographies are built once per
+// workgroup into LDS and read back as same-address (broadcast) LDS reads.
 #include "idh_common.h"
 
 namespace {
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
                                                 const float *__restrict__ cur_invK,  // B,4,4
                                                 float dmin, float dmax,
                                                 int B, int K, int H, int W, int D, int tiles_per_img,
-                                                float *__restrict__ cost,        // B,D,N
+                                                int cost_cs,                     // 0: (B,D,N) planes; >0: NHWC, floats per pixel
+                                                float *__restrict__ cost,
                                                 float *__restrict__ lowest,      // B,N or null
                                                 float *__restrict__ planes_out) {  // D or null
     __shared__ float s_planes[kMaxPlanes];
@@ -156,7 +157,10 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
             const float bot = fmaf(wx1, t11, wx0 * t10);
             acc += fmaf(wy1, bot, wy0 * top);
         }
-        if (live) cost[((size_t)b * D + d) * N + p] = acc;
+        if (live) {
+            if (cost_cs > 0) cost[((size_t)b * N + p) * cost_cs + d] = acc;
+            else cost[((size_t)b * D + d) * N + p] = acc;
+        }
         if (acc > best) { best = acc; bidx = d; }
     }
     if (lowest == nullptr) return;
@@ -180,16 +184,18 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
 extern "C" int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
                                        const float *src_E_44, const float *cur_invK_44, float dmin,
                                        float dmax, int B, int K, int C, int H, int W, int D,
-                                       float *cost_bdhw, float *lowest_bhw, float *planes_d, void *stream) {
+                                       float *cost, int cost_nhwc_cs, float *lowest_bhw, float *planes_d,
+                                       void *stream) {
     if (B < 0 || K < 0 || H <= 0 || W <= 0 || D <= 0 || !(dmin > 0.f) || !(dmax > 0.f)) return IDH_EINVAL;
     if (C != kC || D > kMaxPlanes || K > IDH_MAX_SOURCE_VIEWS) return IDH_EUNSUPPORTED;
     if (B == 0) return IDH_OK;
-    if (!cur_nhwc || !cost_bdhw || !cur_invK_44 || (K > 0 && (!src_nhwc || !src_K_44 || !src_E_44)))
+    if (cost_nhwc_cs != 0 && cost_nhwc_cs < D) return IDH_EINVAL;
+    if (!cur_nhwc || !cost || !cur_invK_44 || (K > 0 && (!src_nhwc || !src_K_44 || !src_E_44)))
         return IDH_EINVAL;
     const int tiles = idh_cdiv((long long)H * W, kTilePx);
     hipLaunchKernelGGL(cv_dot_k, dim3((unsigned)(B * tiles)), dim3(256), 0, idh_stream(stream), cur_nhwc,
-                       src_nhwc, src_K_44, src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles, cost_bdhw,
-                       lowest_bhw, planes_d);
+                       src_nhwc, src_K_44, src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles, cost_nhwc_cs,
+                       cost, lowest_bhw, planes_d);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }

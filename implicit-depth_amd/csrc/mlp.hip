@@ -1,0 +1,218 @@
+// Per-pixel occlusion MLP over all query-depth planes in one launch (gfx950, fp32 MFMA).
+//
+// Replaces the reference's per-plane loop  bd_model.py:293-304 -> run_mlp_val :412-442 ->
+// BinaryMLPNetwork (modules/networks.py:98-115):
+//     for each rendered-depth plane p:  cat([depth_p, feature_s0(64), (prior_p)]) -> permute ->
+//         Linear(65|66,128) -> ELU -> Linear(128,128) -> ELU -> Linear(128,1) -> permute -> cat
+// i.e. P passes over a (B,192,256,66) tensor that is materialised P times.
+//
+// Here:  pre1 = W1[:,feat] . feat + b1 is plane independent and is computed ONCE per pixel;
+// per plane only the rank-1 terms  w_depth*depth_p (+ w_prior*prior_p)  are added before the ELU.
+// Everything is computed TRANSPOSED (channels x pixels) so that the C/D register layout of one
+// layer's MFMA result is exactly the B-operand layout of the next layer:
+//     out^T[n, m] = W[n, k] . act^T[k, m]       A operand = weights, B operand = activations
+// With v_mfma_f32_16x16x4_f32, lane (col = lane&15, q = lane>>4) holds rows 4q..4q+3 of each 16-row
+// sub-tile in its 4 accumulator registers, and as a B operand for k-block c it must supply
+// k = 16c + 4q + kk for MFMA kk = 0..3 (K order is free as long as A and B agree) — the same
+// registers.  So activations never leave the register file between layers: no LDS transpose.
+// Weights are pre-packed in "fragment order" so every A-fragment load is one coalesced 1 KiB
+// wave read (idh_pack_mlp_weight).
+#include "idh_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHidden = 128;           // mlp_size (networks.py:88)
+constexpr int kNS = kHidden / 16;      // 8 sub-tiles of 16 hidden units
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float lrelu(float x, float s) { return x >= 0.f ? x : x * s; }
+
+// One 128 -> 128 layer on register-resident activations (transposed form), TM pixel sub-tiles.
+//   hin[c][t]  : B operands, c = k-block (8), t = pixel sub-tile
+//   wfrag      : packed weights [c][i][lane][4]   (i = output sub-tile)
+//   acc[i][t]  : results in C/D layout (= next layer's B operands)
+template <int TM>
+__device__ __forceinline__ void dense128(const f32x4 (&hin)[kNS][TM], const float *__restrict__ wfrag, int lane,
+                                         f32x4 (&acc)[kNS][TM]) {
+#pragma unroll
+    for (int c = 0; c < kNS; ++c) {
+#pragma unroll
+        for (int i = 0; i < kNS; ++i) {
+            const f32x4 A = *reinterpret_cast<const f32x4 *>(wfrag + ((size_t)(c * kNS + i) * 64 + lane) * 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], hin[c][t][kk], acc[i][t], 0, 0, 0);
+        }
+        // keep the scheduler from hoisting all 64 weight-fragment loads (256 VGPRs) to the top
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+struct BinArgs {
+    const float *feat;    // NHWC rows, M x cs
+    const float *depth;   // B,P,HW
+    const float *prior;   // B,P,HW or null
+    const float *w1f;     // packed [Cf/16][8][64][4]
+    const float *w2;      // packed [8][8][64][4]
+    const float *vecs;    // 6 x 128: b1, w_depth, w_prior, b2, w3, (b3 at [5*128])
+    float *out;           // B,P,HW
+    int M, HW, P, cs, Cf;
+    int has_prior;        // W1 has a prior column
+    float prior_const;    // used when has_prior && prior == null
+};
+
+template <int TM>
+__global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_vec[6 * kHidden];
+    for (int i = threadIdx.x; i < 6 * kHidden; i += 256) s_vec[i] = a.vecs[i];
+    __syncthreads();
+    const float *s_b1 = s_vec, *s_wd = s_vec + kHidden, *s_wp = s_vec + 2 * kHidden, *s_b2 = s_vec + 3 * kHidden,
+                *s_w3 = s_vec + 4 * kHidden;
+    const float b3 = s_vec[5 * kHidden];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ln = lane & 15, q = lane >> 4;
+    const int tiles = (a.M + 16 * TM - 1) / (16 * TM);
+
+    for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+        const int m0 = tile * 16 * TM;
+        // ---- layer 1, plane-independent part: pre1^T = W1f . feat^T + b1 ------------------
+        f32x4 pre1[kNS][TM];
+#pragma unroll
+        for (int i = 0; i < kNS; ++i) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(s_b1 + 16 * i + 4 * q);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) pre1[i][t] = bv;
+        }
+        int mrow[TM];
+        bool mok[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int m = m0 + 16 * t + ln;
+            mok[t] = m < a.M;
+            mrow[t] = mok[t] ? m : a.M - 1;
+        }
+        const int cblocks = (a.Cf + 15) >> 4;
+#pragma unroll 1
+        for (int c = 0; c < cblocks; ++c) {
+            f32x4 Bf[TM];
+            const bool cok = (16 * c + 4 * q) < a.Cf;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                Bf[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (cok) Bf[t] = *reinterpret_cast<const f32x4 *>(a.feat + (size_t)mrow[t] * a.cs + 16 * c + 4 * q);
+            }
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+                const f32x4 A = *reinterpret_cast<const f32x4 *>(a.w1f + ((size_t)(c * kNS + i) * 64 + lane) * 4);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+                        pre1[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], Bf[t][kk], pre1[i][t], 0, 0, 0);
+            }
+        }
+        // per-lane pixel bookkeeping for the depth / prior / output planes (pixel = column ln)
+        size_t poff[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int b = mrow[t] / a.HW;
+            const int pix = mrow[t] - b * a.HW;
+            poff[t] = (size_t)b * a.P * a.HW + pix;
+        }
+        // ---- per query plane ----------------------------------------------------------------
+#pragma unroll 1
+        for (int p = 0; p < a.P; ++p) {
+            float dv[TM], pv[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                dv[t] = a.depth[poff[t] + (size_t)p * a.HW];
+                pv[t] = a.has_prior ? (a.prior ? a.prior[poff[t] + (size_t)p * a.HW] : a.prior_const) : 0.f;
+            }
+            f32x4 h1[kNS][TM], acc[kNS][TM];
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+                const f32x4 wd = *reinterpret_cast<const f32x4 *>(s_wd + 16 * i + 4 * q);
+                const f32x4 wp = *reinterpret_cast<const f32x4 *>(s_wp + 16 * i + 4 * q);
+                const f32x4 b2 = *reinterpret_cast<const f32x4 *>(s_b2 + 16 * i + 4 * q);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = fmaf(wd[r], dv[t], pre1[i][t][r]);
+                        v = fmaf(wp[r], pv[t], v);
+                        h1[i][t][r] = elu1(v);
+                    }
+                    acc[i][t] = b2;
+                }
+            }
+            dense128<TM>(h1, a.w2, lane, acc);
+            // ---- layer 3: logit = w3 . ELU(h2) + b3; reduce over the 4 lane quarters ----------
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const f32x4 w3 = *reinterpret_cast<const f32x4 *>(s_w3 + 16 * i + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = fmaf(w3[r], elu1(acc[i][t][r]), s);
+                }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (q == 0 && mok[t]) a.out[poff[t] + (size_t)p * a.HW] = s + b3;
+            }
+        }
+    }
+}
+
+// W (n_out=128, n_in) row-major, input columns [col0, col0+n_in_used) -> fragment order
+// dst[c][i][lane][4] = W[16i + (lane&15)][col0 + 16c + 4(lane>>4) + e], zero padded in k.
+__global__ __launch_bounds__(256) void pack_mlp_weight_k(const float *__restrict__ w, float *__restrict__ dst, int ld,
+                                                         int col0, int n_in, int cblocks) {
+    const int total = cblocks * kNS * 64 * 4;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int e = t & 3, lane = (t >> 2) & 63, i = (t >> 8) % kNS, c = (t >> 8) / kNS;
+        const int n = 16 * i + (lane & 15), k = 16 * c + 4 * (lane >> 4) + e;
+        dst[t] = (k < n_in) ? w[(size_t)n * ld + col0 + k] : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t idh_packed_mlp_weight_floats(int n_in) {
+    return n_in <= 0 ? 0 : (size_t)((n_in + 15) / 16) * kNS * 64 * 4;
+}
+
+// Repack columns [col0, col0+n_in) of a (128, ld) row-major Linear weight into MFMA A-fragment order.
+extern "C" int idh_pack_mlp_weight(const float *w, float *dst, int ld, int col0, int n_in, void *stream) {
+    if (!w || !dst || ld <= 0 || col0 < 0 || n_in <= 0 || col0 + n_in > ld) return IDH_EINVAL;
+    const int cblocks = (n_in + 15) / 16;
+    hipLaunchKernelGGL(pack_mlp_weight_k, dim3(idh_cdiv(cblocks * kNS * 256, 256)), dim3(256), 0, idh_stream(stream), w,
+                       dst, ld, col0, n_in, cblocks);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
+
+extern "C" int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *depth_bphw,
+                                  const float *prior_bphw, int has_prior, float prior_const, const float *w1f_packed,
+                                  const float *w2_packed, const float *vecs6x128, int B, int P, int HW,
+                                  float *out_bphw, void *stream) {
+    if (B < 0 || P < 0 || HW <= 0 || Cf <= 0 || (Cf & 3) || (feat_cs & 3) || feat_cs < Cf) return IDH_EINVAL;
+    if (B == 0 || P == 0) return IDH_OK;
+    if (!feat_nhwc || !depth_bphw || !w1f_packed || !w2_packed || !vecs6x128 || !out_bphw) return IDH_EINVAL;
+    const long long M = (long long)B * HW;
+    if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    BinArgs a{feat_nhwc, depth_bphw, prior_bphw, w1f_packed, w2_packed, vecs6x128, out_bphw,
+              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const};
+    constexpr int TM = 2;
+    const int tiles = (int)((M + 16 * TM - 1) / (16 * TM));
+    int grid = (tiles + 3) / 4;
+    if (grid > 256 * 8) grid = 256 * 8;
+    hipLaunchKernelGGL(binary_mlp_k<TM>, dim3(grid), dim3(256), 0, idh_stream(stream), a);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}

@@ -1,0 +1,92 @@
+"""Host side of the fused per-pixel occlusion MLP (csrc/mlp.hip).
+
+``occlusion_logits`` is the fused form of the reference's per-plane loop
+(experiment_modules/bd_model.py:293-304, :412-442); ``binary_mlp_forward`` keeps the exact
+``BinaryMLPNetwork.forward(list_of_BHWC, max_scale_only)`` interface
+(modules/networks.py:106-115) on top of the same kernel.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+def _prepared(seq: nn.Sequential, n_feat: int, use_prior: bool):
+    """Fragment-ordered copies of one scale's three Linear layers, cached on the module."""
+    l1, l2, l3 = seq[0], seq[2], seq[4]
+    key = tuple((p.data_ptr(), p._version) for p in seq.parameters())
+    c = seq.__dict__.get("_idh_mlp")
+    if c is not None and c[0] == key:
+        return c[1]
+    w1, w2 = l1.weight.detach().contiguous(), l2.weight.detach().contiguous()
+    _lib.require_cuda_f32(w1, w2)
+    if w1.shape[0] != 128 or tuple(w2.shape) != (128, 128) or l3.weight.shape != (1, 128):
+        raise _lib.IdhError("binary MLP kernel is specialised for mlp_size=128 (reference networks.py:88)")
+    if w1.shape[1] != n_feat + (2 if use_prior else 1):
+        raise _lib.IdhError(f"first Linear has {w1.shape[1]} inputs, expected depth + {n_feat} features" + (" + prior" if use_prior else ""))
+    L = _lib.lib()
+    dev = w1.device
+    w1p = torch.empty(L.idh_packed_mlp_weight_floats(n_feat), device=dev)
+    w2p = torch.empty(L.idh_packed_mlp_weight_floats(128), device=dev)
+    st = _lib.stream_ptr()
+    _lib.check(L.idh_pack_mlp_weight(w1.data_ptr(), w1p.data_ptr(), w1.shape[1], 1, n_feat, st), "idh_pack_mlp_weight")
+    _lib.check(L.idh_pack_mlp_weight(w2.data_ptr(), w2p.data_ptr(), 128, 0, 128, st), "idh_pack_mlp_weight")
+    vecs = torch.zeros(6, 128, device=dev)
+    vecs[0] = l1.bias.detach()
+    vecs[1] = w1[:, 0]
+    if use_prior:
+        vecs[2] = w1[:, n_feat + 1]
+    vecs[3] = l2.bias.detach()
+    vecs[4] = l3.weight.detach()[0]
+    vecs[5, 0] = l3.bias.detach()[0]
+    out = (w1p, w2p, vecs.contiguous())
+    seq.__dict__["_idh_mlp"] = (key, out)
+    return out
+
+
+def occlusion_logits(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, depth_bphw: torch.Tensor,
+                     prior_bphw: Optional[torch.Tensor] = None, scale: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """feat_nhwc: dense (B,H,W,CS) buffer, features are channels [feat_c0, feat_c0+n_feat).
+    Returns logits (B,P,H,W).  With a prior-enabled network and ``prior_bphw=None`` the prior
+    channel is the constant -1 (reference bd_model.py:433-434)."""
+    _lib.require_cuda_f32(feat_nhwc, depth_bphw, prior_bphw)
+    B, H, W, CS = feat_nhwc.shape
+    P = depth_bphw.shape[1]
+    if tuple(depth_bphw.shape) != (B, P, H, W):
+        raise _lib.IdhError(f"rendered depth {tuple(depth_bphw.shape)} does not match features {(B, H, W)}")
+    w1p, w2p, vecs = _prepared(net.mlps[f"s{scale}"], n_feat, net.use_prior)
+    depth = depth_bphw.contiguous()
+    prior = None
+    if prior_bphw is not None:
+        if not net.use_prior:
+            raise _lib.IdhError("prior given to a network built with use_prior=False")
+        prior = prior_bphw.expand(B, P, H, W).contiguous()
+    if out is None:
+        out = torch.empty(B, P, H, W, device=feat_nhwc.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(
+        L.idh_binary_mlp_fwd(feat_nhwc.data_ptr() + 4 * feat_c0, CS, n_feat, depth.data_ptr(), _lib.ptr(prior), int(net.use_prior), -1.0,
+                             w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(), B, P, H * W, out.data_ptr(), _lib.stream_ptr()),
+        "idh_binary_mlp_fwd")
+    return out
+
+
+def binary_mlp_forward(net, inputs: List[torch.Tensor], max_scale_only: bool = False) -> Dict[str, torch.Tensor]:
+    scales = [0] if max_scale_only else list(net.scales)
+    outs = {}
+    for s in scales:
+        x = inputs[s]
+        _lib.require_cuda_f32(x)
+        n_feat = x.shape[-1] - (2 if net.use_prior else 1)
+        lead = x.shape[:-1]
+        rows = x.reshape(1, -1, 1, x.shape[-1])  # (B=1, H=M, W=1, Cin)
+        feat = rows[..., 1 : 1 + n_feat].contiguous()
+        depth = rows[..., 0].reshape(1, 1, -1, 1)
+        prior = rows[..., 1 + n_feat].reshape(1, 1, -1, 1) if net.use_prior else None
+        y = occlusion_logits(net, feat, 0, n_feat, depth, prior, scale=s)
+        outs[f"pred_{s}"] = y.reshape(*lead, 1)
+    return outs

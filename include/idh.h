@@ -58,13 +58,33 @@ int idh_nhwc_to_nchw_f32(const float *src_nhwc, float *dst_nchw, int n_img, int 
  *   src_K_44   (B,K,4,4) source intrinsics at matching scale
  *   src_E_44   (B,K,4,4) src_cam_T_cur_cam
  *   cur_invK_44(B,4,4)
- *   cost_bdhw  (B,D,H,W) out; lowest_bhw (B,H,W) out or NULL; planes_d (D) out or NULL
+ *   cost       out: (B,D,H,W) when cost_nhwc_cs == 0 (the reference's layout), or NHWC
+ *              (B,H,W,cost_nhwc_cs >= D) so the CVEncoder's first conv reads it directly
+ *   lowest_bhw (B,H,W) out or NULL; planes_d (D) out or NULL
  * One launch, no workspace.
  */
 int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
                             const float *src_E_44, const float *cur_invK_44, float dmin, float dmax,
-                            int B, int K, int C, int H, int W, int D, float *cost_bdhw,
+                            int B, int K, int C, int H, int W, int D, float *cost, int cost_nhwc_cs,
                             float *lowest_bhw, float *planes_d, void *stream);
+
+/* ---- per-pixel occlusion MLP over all query planes ---------------------------------- */
+/* Replaces the per-plane loop bd_model.py:293-304 -> run_mlp_val (:412-442) ->
+ * BinaryMLPNetwork scale 0 (modules/networks.py:98-115): for every pixel m and plane p
+ *   x = [depth[b,p,pix], feat[m, 0:Cf], (prior[b,p,pix])]
+ *   out[b,p,pix] = W3 . ELU(W2 . ELU(W1 . x + b1) + b2) + b3          (hidden width 128)
+ * W1's feature columns and W2 are passed in MFMA fragment order (idh_pack_mlp_weight);
+ * vecs6x128 = rows {b1, W1[:,depth], W1[:,prior], b2, W3[0,:], [b3,0,...]}.
+ *   feat_nhwc  rows of Cf floats, feat_cs floats apart (B*HW rows)
+ *   depth_bphw (B,P,HW); prior_bphw (B,P,HW) or NULL (then prior_const is used when has_prior)
+ *   out_bphw   (B,P,HW) logits
+ */
+size_t idh_packed_mlp_weight_floats(int n_in);
+int idh_pack_mlp_weight(const float *w_row_major, float *dst, int ld, int col0, int n_in, void *stream);
+int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *depth_bphw,
+                       const float *prior_bphw, int has_prior, float prior_const,
+                       const float *w1f_packed, const float *w2_packed, const float *vecs6x128, int B,
+                       int P, int HW, float *out_bphw, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,8 +40,8 @@ def test_error_strings_and_host_only_entry_points():
     assert L.idh_error_string(0) == b"ok"
     assert b"workspace" in L.idh_error_string(-4)
     # argument validation happens before any launch: safe without a GPU
-    assert L.idh_cost_volume_dot_fwd(None, None, None, None, None, 0.25, 5.0, 1, 2, 16, 8, 8, 4, None, None, None, None) == -1
-    assert L.idh_cost_volume_dot_fwd(None, None, None, None, None, 0.25, 5.0, 1, 2, 8, 8, 8, 4, None, None, None, None) == -2
+    assert L.idh_cost_volume_dot_fwd(None, None, None, None, None, 0.25, 5.0, 1, 2, 16, 8, 8, 4, None, 0, None, None, None) == -1
+    assert L.idh_cost_volume_dot_fwd(None, None, None, None, None, 0.25, 5.0, 1, 2, 8, 8, 8, 4, None, 0, None, None, None) == -2
 
 
 def test_product_path_refuses_cpu_tensors():
