@@ -20,9 +20,10 @@
 //   * weights are pre-packed [tap][ci/4][co][ci%4] so the matching B fragment is one float4 per
 //     lane too (16 lanes x 16 B contiguous);
 //   * fp32 MFMA is slow per byte (64 flop/clk/SIMD), so operand traffic is ~1 float4 per
-//     256 MFMA-cycles per wave: it streams from L1/L2 without LDS staging, and the waves of a
-//     workgroup are independent — latency is hidden by wave-level parallelism (2-4 waves/SIMD);
-//   * zero padding = predicated loads; torch.cat = channel-strided in/out pointers; the
+//     256 MFMA-cycles per wave: it streams from L1/L2 without LDS staging; the K loop is
+//     software-pipelined (loads of step s+1 in flight under the MFMAs of step s, ping-pong
+//     register sets) and the waves of a workgroup are fully independent (no barriers);
+//   * zero padding = out-of-image lanes read a zero page (branch-free K loop); torch.cat = channel-strided in/out pointers; the
 //     residual projection of a BasicBlock is a second K-source of the same launch; bias +
 //     residual + LeakyReLU are applied on the accumulators before the single store;
 //   * layers with too few tiles to fill 256 CUs (12x16 / 24x32 maps) split K over `split_k`
@@ -54,16 +55,24 @@ struct ConvArgs {
     int steps_total;
     int act;
     float slope;
+    int dbg;  // diagnostics only: 1 = no operand loads in the K loop, 2 = no MFMAs
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     return (act == IDH_ACT_LRELU && v < 0.f) ? v * slope : v;
 }
 
+// Zero page: out-of-image taps (zero padding) read from here instead of being predicated,
+// so the K loop is branch-free.  Must cover the widest Cin_pad (host-checked).
+constexpr int kZeroFloats = 4096;
+__device__ float g_zero_page[kZeroFloats];
+
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // readfirstlane: tell the compiler the wave index is uniform, so the tile / split / step
+    // bookkeeping below lives in SGPRs and the K loop uses scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ln = lane & 15, h = lane >> 4;
 
     const unsigned blk = idh_xcd_remap(blockIdx.x, gridDim.x);
@@ -103,97 +112,336 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int step_base = 0;
-#pragma unroll 1
-    for (int si = 0; si < 2; ++si) {
-        const ConvSrc s = a.s[si];
-        if (s.in == nullptr) break;
-        const int ntaps = s.ks * s.ks;
+    // ---- step iterator: (source si, tap, channel block cb), all wave-uniform ----------------
+    const int steps0 = a.s[0].ks * a.s[0].ks * a.s[0].cblocks;
+    int si = (t0 >= steps0) ? 1 : 0;
+    ConvSrc s = a.s[si];
+    int local = t0 - (si ? steps0 : 0);
+    int tap = local / s.cblocks;
+    int cb = local - tap * s.cblocks;
+    const size_t w_cq_stride = (size_t)a.Cout_pad * 4;  // floats between consecutive ci/4 groups
+    const float *ap[TM];
+    const float *wp;
+    auto set_tap = [&]() {
         const int pad = s.ks >> 1;
-        const int src_steps = ntaps * s.cblocks;
-        // intersect [t0,t1) with this source's steps
-        const int lo_s = max(t0 - step_base, 0), hi_s = min(t1 - step_base, src_steps);
-        step_base += src_steps;
-        if (lo_s >= hi_s) continue;
-        const int tap_lo = lo_s / s.cblocks, tap_hi = (hi_s - 1) / s.cblocks;
-        const float *wl = s.w + ((size_t)h * a.Cout_pad + n_base + ln) * 4;
-        const size_t w_cq_stride = (size_t)a.Cout_pad * 4;  // floats between consecutive ci/4 groups
-#pragma unroll 1
-        for (int tap = tap_lo; tap <= tap_hi; ++tap) {
-            const int dy = tap / s.ks, dx = tap - dy * s.ks;
-            const int c_lo = (tap == tap_lo) ? lo_s - tap * s.cblocks : 0;
-            const int c_hi = (tap == tap_hi) ? hi_s - tap * s.cblocks : s.cblocks;
-            const float *ap[TM];
-            bool av[TM];
+        const int dy = tap / s.ks, dx = tap - dy * s.ks;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int iy = oy[i] * s.stride + dy - pad;
-                int ix = ox[i] * s.stride + dx - pad;
-                bool ok = mv[i];
-                if (s.pad_mode == IDH_PAD_REPLICATE) {
-                    iy = min(max(iy, 0), s.H - 1);
-                    ix = min(max(ix, 0), s.W - 1);
-                } else {
-                    ok = ok && iy >= 0 && iy < s.H && ix >= 0 && ix < s.W;
-                    iy = min(max(iy, 0), s.H - 1);
-                    ix = min(max(ix, 0), s.W - 1);
+        for (int i = 0; i < TM; ++i) {
+            int iy = oy[i] * s.stride + dy - pad;
+            int ix = ox[i] * s.stride + dx - pad;
+            // branch-free validity: unsigned compare folds the two-sided range test
+            const bool inb = ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            const bool ok = mv[i] & (inb | (s.pad_mode == IDH_PAD_REPLICATE));
+            iy = min(max(iy, 0), s.H - 1);
+            ix = min(max(ix, 0), s.W - 1);
+            const float *real = s.in + ((size_t)(nb[i] * s.H + iy) * s.W + ix) * s.cs + 4 * h;
+            ap[i] = ok ? real : (g_zero_page + 4 * h);
+        }
+        wp = s.w + ((size_t)tap * s.cblocks * 4 + h) * w_cq_stride + (size_t)(n_base + ln) * 4;
+    };
+    set_tap();
+    int remaining = t1 - t0;  // real steps not yet loaded
+    // Loads are UNCONDITIONAL (so the compiler can use counted s_waitcnt vmcnt(N) and keep the
+    // prefetch of step s+1 in flight under the MFMAs of step s).  Past the last real step the
+    // iterator parks on a "null step": activations come from the zero page, so the extra MFMAs of
+    // the ping-pong tail add exactly 0.
+    auto load = [&](f32x4(&A)[TM], f32x4(&Bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) A[i] = *reinterpret_cast<const f32x4 *>(ap[i] + 16 * cb);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Bf[j] = *reinterpret_cast<const f32x4 *>(wp + (size_t)cb * 4 * w_cq_stride + 64 * j);
+        --remaining;
+        if (remaining > 0) {  // advance to the next real step (uniform control flow, VALU only)
+            if (++cb == s.cblocks) {
+                cb = 0;
+                if (++tap == s.ks * s.ks) {
+                    tap = 0;
+                    si = 1;
+                    s = a.s[1];
                 }
-                av[i] = ok;
-                ap[i] = s.in + ((size_t)(nb[i] * s.H + iy) * s.W + ix) * s.cs + 4 * h;
+                set_tap();
             }
-            const float *wt = wl + (size_t)tap * s.cblocks * 4 * w_cq_stride;
-#pragma unroll 1
-            for (int cb = c_lo; cb < c_hi; ++cb) {
-                const bool cok = (16 * cb + 4 * h) < s.Cin;  // Cin % 4 == 0 (host-checked)
-                f32x4 A[TM], Bf[TN];
+        } else {
+            cb = 0;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    A[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (av[i] && cok) A[i] = *reinterpret_cast<const f32x4 *>(ap[i] + 16 * cb);
-                }
+            for (int i = 0; i < TM; ++i) ap[i] = g_zero_page + 4 * h;
+        }
+    };
+    auto mma = [&](const f32x4(&A)[TM], const f32x4(&Bf)[TN]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    Bf[j] = *reinterpret_cast<const f32x4 *>(wt + (size_t)cb * 4 * w_cq_stride + 64 * j);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- software-pipelined K loop: the loads of step s+1 are in flight under the MFMAs of s ----
+    f32x4 A0[TM], B0[TN], A1[TM], B1[TN];
+    const int nsteps = t1 - t0;
+    load(A0, B0);
+    if (a.dbg == 1) {
+#pragma unroll 1
+        for (int st = 0; st < nsteps; ++st) mma(A0, B0);
+    } else if (a.dbg == 2) {
+#pragma unroll 1
+        for (int st = 1; st < nsteps; ++st) {
+            load(A1, B1);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+            for (int i = 0; i < TM; ++i) A0[i] += A1[i];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][kk], Bf[j][kk], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TN; ++j) B0[j] += B1[j];
+        }
+        mma(A0, B0);
+    } else {
+#pragma unroll 1
+        for (int st = 0; st < nsteps; st += 2) {
+            load(A1, B1);
+            mma(A0, B0);
+            load(A0, B0);
+            mma(A1, B1);
         }
     }
 
-    // ---- epilogue: C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg ----------
-    if (a.S > 1) {
+    // ---- epilogue.  The MFMA was issued as D^T = W . X^T (weights as the A operand), so in the
+    // 16x16x4 C/D layout (col = lane&15, row = 4*(lane>>4) + reg) a lane holds 4 CONSECUTIVE
+    // output channels of ONE pixel — the pixel it loaded activations for — and the NHWC store is a
+    // single 16-byte vector per accumulator.
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        if (!mv[i]) continue;
+        const size_t m = (size_t)(m_base + 16 * i + ln);
+        if (a.S > 1) {
+            float *o = a.ws + ((size_t)sp * a.M + m) * a.Cout_pad + n_base + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + 16 * i + 4 * h + r;
-                if (m >= a.M) continue;
-                float *o = a.ws + ((size_t)sp * a.M + m) * a.Cout_pad + n_base + ln;
+            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4 *>(o + 16 * j) = acc[i][j];
+            continue;
+        }
+        float *o = a.out + m * a.out_cs;
+        const float *rp = a.res ? a.res + m * a.res_cs : nullptr;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) o[16 * j] = acc[i][j][r];
+        for (int j = 0; j < TN; ++j) {
+            const int co = n_base + 16 * j + 4 * h;
+            if (co >= a.Cout) continue;  // Cout % 4 == 0 (host-checked)
+            f32x4 v = acc[i][j];
+            if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
+            if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
+            if (a.act == IDH_ACT_LRELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * a.slope : v[r];
             }
-        return;
+            *reinterpret_cast<f32x4 *>(o + co) = v;
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-staged variant for the layers that carry ~95% of the flops: 3x3, stride 1, zero padding,
+// Cout % 64 == 0, optionally fused with a 1x1 projection of a second tensor.
+//
+// Why: the direct-fragment kernel above re-reads every input pixel 9x (once per tap) and every
+// weight once per wave through the vector L1, and that path sustains only ~30 B/clk/CU for these
+// 16-byte-per-lane gathers — the MFMA pipe idles ~50% (rocprof: profiles/r01).  Here a 256-thread
+// workgroup owns an 8x16-pixel x 64-channel output tile and, per 16-channel K chunk, stages
+//   A: the 10x18-pixel halo of the input        (11.25 KiB, read from HBM/L2 ONCE for 9 taps)
+//   B: the 9-tap x 16-ci x 64-co weight panel   (36 KiB, shared by the 4 waves)
+// in LDS; each wave then issues 9 x 32 MFMAs (2 tile rows x 64 channels) fed by conflict-free
+// ds_read_b128 fragment reads.  The next chunk's global loads are issued before the MFMA phase
+// and parked in registers (classic register prefetch), so HBM/L2 latency hides under ~9k cycles
+// of matrix work; 48 KiB of LDS per workgroup lets 3 workgroups share a CU and cover each
+// other's barrier / staging phases.
+//   A in LDS: [hy 10][q 4][hx 18] float4  (q = channel quad)  -> a tap shift is a pure offset and a
+//             fragment read touches 16 consecutive float4 per quarter-wave: no bank conflicts
+//   B in LDS: [tap 9][q 4][co 64] float4
+constexpr int kLT_H = 8, kLT_W = 16, kLT_N = 64;
+constexpr int kHaloW = kLT_W + 2, kHaloH = kLT_H + 2;
+constexpr int kASlots = kHaloH * 4 * kHaloW;  // 720 float4
+constexpr int kBSlots3 = 9 * 4 * kLT_N;       // 2304 float4
+
+struct LdsConvArgs {
+    ConvArgs c;
+    int tiles_x, tiles_y;  // spatial tiles per image
+};
+
+__global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
+    __shared__ f32x4 sA[kASlots];
+    __shared__ f32x4 sB[kBSlots3];
+    const ConvArgs &a = la.c;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, h = lane >> 4;
+
+    // block -> (split, image, tile_y, tile_x, channel tile); channel tile fastest so the blocks
+    // sharing an input tile are neighbours (same XCD after the remap -> L2 hits on the halo)
+    unsigned blk = idh_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = blk % a.NT; blk /= a.NT;
+    const int tx = blk % la.tiles_x; blk /= la.tiles_x;
+    const int ty = blk % la.tiles_y; blk /= la.tiles_y;
+    const int N_img = a.M / (a.Ho * a.Wo);
+    const int n = blk % N_img;
+    const int sp = blk / N_img;
+    const int y0 = ty * kLT_H, x0 = tx * kLT_W;
+    const int n0 = nt * kLT_N;
+
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n_base + 16 * j + ln;
-        if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // chunk list = [source-0 chunks][source-1 chunks]; this block's split owns [t0,t1)
+    const int nc0 = a.s[0].cblocks;
+    const int nc1 = a.s[1].in ? a.s[1].cblocks : 0;
+    const int t0 = (int)((long long)(nc0 + nc1) * sp / a.S);
+    const int t1 = (int)((long long)(nc0 + nc1) * (sp + 1) / a.S);
+
+    // ---- staging: global -> registers (prefetch) -> LDS -----------------------------------
+    // A slots are enumerated (hy, hx, q) with q fastest so that 4 consecutive lanes read the 64
+    // contiguous bytes of one pixel; the LDS image is [hy][q][hx].
+    f32x4 pa[3], pb[9];
+    auto issue3 = [&](int c) {  // 3x3 source 0, chunk c
+        const ConvSrc &s = a.s[0];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + 16 * i + 4 * h + r;
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (a.res) v += a.res[(size_t)m * a.res_cs + co];
-                a.out[(size_t)m * a.out_cs + co] = act_apply(v, a.act, a.slope);
+        for (int k = 0; k < 3; ++k) {
+            const int slot = tid + 256 * k;
+            const int q = slot & 3, pix = slot >> 2;
+            const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
+            const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+            const bool ok = (slot < kASlots) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
+            pa[k] = *reinterpret_cast<const f32x4 *>(p);
+        }
+        const float *wb = s.w + ((size_t)(4 * c) * a.Cout_pad + n0) * 4;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {  // slot = (tap k, q = tid>>6, co = tid&63)
+            const float *p = wb + ((size_t)(k * s.cblocks * 4 + (tid >> 6)) * a.Cout_pad + (tid & 63)) * 4;
+            pb[k] = *reinterpret_cast<const f32x4 *>(p);
+        }
+    };
+    auto commit3 = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int slot = tid + 256 * k;
+            const int q = slot & 3, pix = slot >> 2;
+            const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
+            if (slot < kASlots) sA[(hy * 4 + q) * kHaloW + hx] = pa[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sB[k * 256 + tid] = pb[k];
+    };
+    auto compute3 = [&]() {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            f32x4 A[2], Bf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) A[i] = sA[((2 * wave + i + dy) * 4 + h) * kHaloW + ln + dx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Bf[j] = sB[(tap * 4 + h) * kLT_N + 16 * j + ln];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
+        }
+    };
+    // 1x1 source 1: A = the 8x16 centre pixels (512 float4 -> 2 per thread), B = 4 x 64 float4
+    auto issue1 = [&](int c) {
+        const ConvSrc &s = a.s[1];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int slot = tid + 256 * k;
+            const int q = slot & 3, pix = slot >> 2;
+            const int py = pix >> 4, px = pix & 15;
+            const int iy = y0 + py, ix = x0 + px;
+            const bool ok = (iy < s.H) & (ix < s.W);
+            const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
+            pa[k] = *reinterpret_cast<const f32x4 *>(p);
+        }
+        pb[0] = *reinterpret_cast<const f32x4 *>(s.w + ((size_t)(4 * c + (tid >> 6)) * a.Cout_pad + n0 + (tid & 63)) * 4);
+    };
+    auto commit1 = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int slot = tid + 256 * k;
+            const int q = slot & 3, pix = slot >> 2;
+            const int py = pix >> 4, px = pix & 15;
+            sA[((py + 1) * 4 + q) * kHaloW + px + 1] = pa[k];
+        }
+        sB[tid] = pb[0];
+    };
+    auto compute1 = [&]() {
+        f32x4 A[2], Bf[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) A[i] = sA[((2 * wave + i + 1) * 4 + h) * kHaloW + ln + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bf[j] = sB[h * kLT_N + 16 * j + ln];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- source 0 chunks ---------------------------------------------------------------------
+    {
+        const int lo = min(t0, nc0), hi = min(t1, nc0);
+        if (lo < hi) issue3(lo);
+#pragma unroll 1
+        for (int c = lo; c < hi; ++c) {
+            __syncthreads();  // every wave is done reading the previous chunk's LDS image
+            commit3();
+            __syncthreads();
+            if (c + 1 < hi) issue3(c + 1);  // in flight under the 288 MFMAs below
+            compute3();
+        }
+    }
+    // ---- source 1 chunks (fused 1x1 projection) ------------------------------------------------
+    if (nc1 > 0) {
+        const int lo = max(t0 - nc0, 0), hi = max(t1 - nc0, 0);
+        if (lo < hi) issue1(lo);
+#pragma unroll 1
+        for (int c = lo; c < hi; ++c) {
+            __syncthreads();
+            commit1();
+            __syncthreads();
+            if (c + 1 < hi) issue1(c + 1);
+            compute1();
+        }
+    }
+
+    // ---- epilogue (same transposed C/D layout as above: 4 consecutive channels per lane) -------
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oy = y0 + 2 * wave + i, ox = x0 + ln;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t m = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+        if (a.S > 1) {
+            float *o = a.ws + ((size_t)sp * a.M + m) * a.Cout_pad + n0 + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(o + 16 * j) = acc[i][j];
+            continue;
+        }
+        float *o = a.out + m * a.out_cs;
+        const float *rp = a.res ? a.res + m * a.res_cs : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = n0 + 16 * j + 4 * h;
+            f32x4 v = acc[i][j];
+            if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
+            if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
+            if (a.act == IDH_ACT_LRELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * a.slope : v[r];
             }
+            *reinterpret_cast<f32x4 *>(o + co) = v;
+        }
     }
 }
 
@@ -338,9 +586,12 @@ int run_conv(const idh_op &op, hipStream_t st) {
         ConvSrc &d = a.s[i];
         d.in = s.in;
         if (!s.in) continue;
-        if (!s.w || s.Cin <= 0 || (s.Cin & 3) || s.cs < s.Cin || (s.cs & 3) || (s.ks != 1 && s.ks != 3) ||
+        // the K loop reads whole 16-channel blocks: the buffer must be readable (and finite) up to
+        // ceil16(Cin) channels per pixel; packed weights are zero there.
+        if (!s.w || s.Cin <= 0 || s.cs < ceil16(s.Cin) || (s.cs & 3) || (s.ks != 1 && s.ks != 3) ||
             (s.stride != 1 && s.stride != 2) || s.H <= 0 || s.W <= 0)
             return IDH_EINVAL;
+        if (ceil16(s.Cin) > kZeroFloats) return IDH_EUNSUPPORTED;
         const int pad = s.ks / 2;
         if ((s.H + 2 * pad - s.ks) / s.stride + 1 != op.Ho || (s.W + 2 * pad - s.ks) / s.stride + 1 != op.Wo)
             return IDH_EINVAL;
@@ -349,16 +600,35 @@ int run_conv(const idh_op &op, hipStream_t st) {
         steps += s.ks * s.ks * d.cblocks;
     }
     if (!a.s[0].in || !op.out || op.Cout <= 0 || op.N <= 0) return IDH_EINVAL;
+    // vector epilogue: 4 consecutive channels per lane -> 16-byte aligned rows
+    if ((op.Cout & 3) || (op.out_cs & 3) || ((uintptr_t)op.out & 15) || (op.bias && ((uintptr_t)op.bias & 15)) ||
+        (op.res && ((op.res_cs & 3) || ((uintptr_t)op.res & 15))))
+        return IDH_EINVAL;
     a.bias = op.bias; a.res = op.res; a.out = op.out; a.ws = op.ws;
     a.res_cs = op.res_cs; a.out_cs = op.out_cs; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
     a.Cout_pad = ceil16(op.Cout);
     const long long M = (long long)op.N * op.Ho * op.Wo;
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
-    a.M = (int)M; a.steps_total = steps; a.act = op.act; a.slope = op.slope;
+    a.M = (int)M; a.steps_total = steps; a.act = op.act; a.slope = op.slope; a.dbg = op._pad;
     a.S = op.split_k > 1 ? op.split_k : 1;
     if (a.S > steps) a.S = steps;
     if (a.S > 1 && !op.ws) return IDH_EWORKSPACE;
+    // LDS-staged kernel for the dominant shape family (tile_m == 8 requests it, tile_m == 0 = auto)
+    const bool lds_ok = a.s[0].ks == 3 && a.s[0].stride == 1 && a.s[0].pad_mode == IDH_PAD_ZEROS && (op.Cout % kLT_N) == 0 &&
+                        (!a.s[1].in || (a.s[1].ks == 1 && a.s[1].stride == 1)) && op.Wo >= kLT_W;
+    if (lds_ok && (op.tile_m == 8 || op.tile_m == 0)) {
+        LdsConvArgs la{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + kLT_H - 1) / kLT_H};
+        la.c.NT = op.Cout / kLT_N;
+        const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
+        if (la.c.S > chunks) la.c.S = chunks;
+        const long long blocks = (long long)la.c.S * op.N * la.tiles_x * la.tiles_y * la.c.NT;
+        if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
+        hipLaunchKernelGGL(conv3x3_lds_k, dim3((unsigned)blocks), dim3(256), 0, st, la);
+        IDH_CHECK_LAUNCH();
+        a.S = la.c.S;
+    } else {
     int tm = op.tile_m, tn = op.tile_n;
+    if (tm == 8) tm = 0;
     const int nsub = a.Cout_pad / 16;
     if (tn == 0) tn = (nsub % 4 == 0) ? 4 : (nsub % 2 == 0 ? 2 : 1);
     if (tm == 0) tm = 4;
@@ -371,6 +641,7 @@ int run_conv(const idh_op &op, hipStream_t st) {
     IDH_CASE(2, 1) IDH_CASE(1, 1)
 #undef IDH_CASE
     IDH_CHECK_LAUNCH();
+    }
     if (a.S > 1) {
         const long long tot = M * op.Cout;
         int grid = idh_cdiv(tot, 256);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
                 *s_w3 = s_vec + 4 * kHidden;
     const float b3 = s_vec[5 * kHidden];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ln = lane & 15, q = lane >> 4;
     const int tiles = (a.M + 16 * TM - 1) / (16 * TM);
 

@@ -110,6 +110,25 @@ TARGET_WAVES = 2048  # ~2 waves per SIMD over 256 CUs x 4 SIMDs
 MIN_WAVES = 1024
 
 
+def lds_eligible(srcs, cout: int, Wo: int, pad_mode: int) -> bool:
+    """Shape family of the LDS-staged kernel (csrc/conv.hip conv3x3_lds_k)."""
+    (v0, c0) = srcs[0]
+    if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64 or Wo < 16:
+        return False
+    if len(srcs) > 1:
+        (v1, c1) = srcs[1]
+        if c1.kernel_size[0] != 1 or c1.stride[0] != 1:
+            return False
+    return True
+
+
+def choose_lds_split(N: int, Ho: int, Wo: int, cout: int, chunks: int) -> int:
+    """Split K only when the grid cannot fill 256 CUs x 3 resident workgroups AND every split still
+    gets >= 6 chunks of 16 channels (measured on MI355X, tools/perf_conv_layers.py)."""
+    blocks = N * (-(-Ho // 8)) * (-(-Wo // 16)) * (cout // 64)
+    return max(1, min(-(-768 // blocks), chunks // 6, 16))
+
+
 def choose_tiles(M: int, cout: int, steps: int):
     nsub = ceil16(cout) // 16
     tn = 4 if nsub % 4 == 0 else (2 if nsub % 2 == 0 else 1)
@@ -137,7 +156,11 @@ class Plan:
 
     # buffers -------------------------------------------------------------------------
     def buffer(self, N, H, W, Cch) -> View:
-        t = torch.empty(N, H, W, Cch, device=self.device, dtype=torch.float32)
+        """Dense NHWC buffer.  The conv kernel reads whole 16-channel blocks, so channel counts
+        that are not a multiple of 16 get zero-filled padding channels (written by nobody)."""
+        cs = ceil16(Cch)
+        alloc = torch.zeros if cs != Cch else torch.empty
+        t = alloc(N, H, W, cs, device=self.device, dtype=torch.float32)
         self.keep.append(t)
         return View(t, 0, Cch)
 
@@ -153,6 +176,8 @@ class Plan:
             ks, st = cv.kernel_size[0], cv.stride[0]
             if v.C != cv.in_channels:
                 raise _lib.IdhError(f"conv expects {cv.in_channels} input channels, view has {v.C}")
+            if v.C % 16 and (v.c0 != 0 or v.cs != ceil16(v.C)):
+                raise _lib.IdhError("a conv input whose channel count is not a multiple of 16 must be a whole zero-padded buffer")
             w = packed_weight(cv)
             self.keep.append(w)
             s = op.src[i]
@@ -173,7 +198,11 @@ class Plan:
         op.Ho, op.Wo, op.Cout = out.H, out.W, conv.out_channels
         op.act, op.slope = act, slope
         M = out.N * out.H * out.W
-        tm, tn, split = choose_tiles(M, conv.out_channels, steps)
+        if lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
+            chunks = sum(ceil16(v.C) // 16 for v, _ in srcs)
+            tm, tn, split = 8, 0, choose_lds_split(out.N, out.H, out.W, conv.out_channels, chunks)
+        else:
+            tm, tn, split = choose_tiles(M, conv.out_channels, steps)
         op.tile_m, op.tile_n, op.split_k = tm, tn, split
         if split > 1:
             ws = torch.empty(split * M * ceil16(conv.out_channels), device=self.device, dtype=torch.float32)
