@@ -191,11 +191,9 @@ def main():
     elapsed = t.item()
 
     # the path's only collective: all-gather of per-frame metric vectors (RCCL over xGMI)
-    m = wl.metrics().float().contiguous()
-    if world > 1:
-        gathered = [torch.empty_like(m) for _ in range(world)]
-        dist.all_gather(gathered, m)
-        m = torch.cat(gathered, 0)
+    from implicit_depth_amd.dist import all_gather_metrics
+
+    m = all_gather_metrics(wl.metrics().float().contiguous(), counts=[wl.B] * world)
     frames_total = wl.B * world * args.steps
 
     if rank == 0:
