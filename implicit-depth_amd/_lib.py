@@ -36,6 +36,11 @@ _SIGS = {
     "idh_packed_mlp_weight_floats": (C.c_size_t, [C.c_int]),
     "idh_pack_mlp_weight": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idh_binary_mlp_fwd": (C.c_int, [f32p, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
+    "idh_feature_volume_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "idh_feature_volume_fwd": (
+        C.c_int,
+        [f32p] * 6 + [C.c_float, C.c_float] + [C.c_int] * 6 + [f32p] * 6 + [f32p, C.c_int, f32p, C.c_void_p, f32p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "idh_cost_volume_dot_fwd": (
         C.c_int,
         [f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_float] + [C.c_int] * 6 + [f32p, C.c_int, f32p, f32p, C.c_void_p],

@@ -121,6 +121,132 @@ class CostVolumeManager(nn.Module):
         return m.to(ref_module.linear_ramp_1d11.device)
 
 
+def feature_mlp_column_maps(K: int, C: int = 16):
+    """Column index maps that re-order the reference MLP's first Linear (input layout of
+    modules/cost_volume.py:681-695) into the K order csrc/feature_volume.hip builds its MFMA
+    operands in.  -1 = structurally zero column.  Returns (voxel_cols, pixel_cols, pose_cols)."""
+    base = C * (K + 1)
+    col_mask = lambda k: base + k
+    col_z = lambda k: base + K + k
+    col_plane = base + 2 * K
+    col_dot = lambda k: base + 2 * K + 1 + k
+    col_ang = lambda k: base + 3 * K + 1 + k
+    base_r = base + 4 * K + 1
+    col_ray = lambda k, e: base_r + 3 + 3 * k + e
+    base_p = base_r + 3 * (K + 1)
+    voxel = list(range(C * K))  # blocks 0..K-1: warped features, identity order
+    for cblk in range(4):
+        for q in range(4):
+            for kk in range(4):
+                j = 4 * cblk + kk
+                v = q if j < 7 else q + 4
+                jj = j % 7 if j < 14 else j
+                col = -1
+                if j < 14 and v < K:
+                    col = [col_mask(v), col_z(v), col_dot(v), col_ang(v), col_ray(v, 0), col_ray(v, 1), col_ray(v, 2)][jj]
+                elif j == 14 and q == 0:
+                    col = col_plane
+                voxel.append(col)
+    pixel = [C * K + i for i in range(C)]  # block 0: current-view features
+    for q in range(4):
+        for kk in range(4):
+            pixel.append(base_r + kk if (q == 0 and kk < 3) else -1)
+    pose = list(range(base_p, base_p + 3 * K))
+    return voxel, pixel, pose
+
+
+class FeatureVolumeManager(CostVolumeManager):
+    """MLP feature volume (reference modules/cost_volume.py:369-715): same constructor, ``mlp``
+    attribute (state_dict keys ``mlp.net.{0,2,4}.*``) and forward contract."""
+
+    def __init__(self, matching_height, matching_width, num_depth_bins=64, mlp_channels=None, matching_dim_size=16, num_source_views=7):
+        super().__init__(matching_height, matching_width, num_depth_bins)
+        from .networks import MLP
+
+        mlp_channels = list(mlp_channels) if mlp_channels is not None else [202, 128, 128, 1]
+        mlp_channels[0] = matching_dim_size * (1 + num_source_views) + 10 * num_source_views + 4  # reference :405-423
+        self.matching_dim_size = matching_dim_size
+        self.num_source_views = num_source_views
+        self.mlp = MLP(channel_list=mlp_channels, disable_final_activation=True)
+
+    # -- weights in kernel order, cached until a parameter changes ------------------------------
+    def _packed(self):
+        lins = [self.mlp.net[0], self.mlp.net[2], self.mlp.net[4]]
+        key = tuple((p.data_ptr(), p._version) for p in self.mlp.parameters())
+        c = self.__dict__.get("_idh_fv")
+        if c is not None and c[0] == key:
+            return c[1]
+        K, C = self.num_source_views, self.matching_dim_size
+        w1, w2, w3 = (l.weight.detach() for l in lins)
+        _lib.require_cuda_f32(w1, w2, w3)
+        if w1.shape[0] != 128 or tuple(w2.shape) != (128, 128) or tuple(w3.shape) != (1, 128) or C != 16:
+            raise _lib.IdhError("feature-volume kernel is specialised for C=16, MLP widths [*,128,128,1]")
+        vox, pix, pose = feature_mlp_column_maps(K, C)
+        dev = w1.device
+        w1e = torch.cat([w1, torch.zeros(128, 1, device=dev)], 1)
+        pick = lambda cols: w1e[:, torch.tensor([c if c >= 0 else w1.shape[1] for c in cols], device=dev)].contiguous()
+        L, st = _lib.lib(), _lib.stream_ptr()
+
+        def frag(mat):
+            dst = torch.empty(L.idh_packed_mlp_weight_floats(mat.shape[1]), device=dev)
+            _lib.check(L.idh_pack_mlp_weight(mat.data_ptr(), dst.data_ptr(), mat.shape[1], 0, mat.shape[1], st), "idh_pack_mlp_weight")
+            return dst
+
+        vecs = torch.zeros(3, 128, device=dev)
+        vecs[0], vecs[1], vecs[2, 0] = lins[1].bias.detach(), w3[0], lins[2].bias.detach()[0]
+        out = {"w1v": frag(pick(vox)), "w1p": frag(pick(pix)), "pose": pick(pose), "b1": lins[0].bias.detach().contiguous(),
+               "w2": frag(w2.contiguous()), "vecs": vecs.contiguous()}
+        self.__dict__["_idh_fv"] = (key, out)
+        return out
+
+    def _run(self, cur_n, src_n, src_extrinsics, src_poses, src_Ks, cur_invK, dmin, dmax, vol, vol_cs, want_mask):
+        B, K, H, W, C = src_n.shape
+        if K != self.num_source_views:
+            raise _lib.IdhError(f"FeatureVolumeManager was built for {self.num_source_views} source views, got {K} (the MLP input width is fixed)")
+        dev = cur_n.device
+        pk = self._packed()
+        L = _lib.lib()
+        D = self.num_depth_bins
+        lowest = torch.empty(B, H, W, device=dev)
+        planes = torch.empty(D, device=dev)
+        mask = torch.empty(B, H, W, device=dev, dtype=torch.uint8) if want_mask else None
+        wsb = L.idh_feature_volume_workspace_bytes(B)
+        ws = torch.empty(max(wsb // 4, 1), device=dev)
+        _lib.check(
+            L.idh_feature_volume_fwd(cur_n.data_ptr(), src_n.data_ptr(), src_Ks.contiguous().data_ptr(), src_extrinsics.contiguous().data_ptr(),
+                                     src_poses.contiguous().data_ptr(), cur_invK.contiguous().data_ptr(), dmin, dmax, B, K, C, H, W, D,
+                                     pk["w1v"].data_ptr(), pk["w1p"].data_ptr(), pk["pose"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(),
+                                     pk["vecs"].data_ptr(), vol.data_ptr() if torch.is_tensor(vol) else vol, vol_cs, lowest.data_ptr(),
+                                     _lib.ptr(mask), planes.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()),
+            "idh_feature_volume_fwd")
+        return lowest, planes, (mask.bool() if mask is not None else None)
+
+    def build_cost_volume(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
+                          depth_planes_bdhw=None, return_mask=False, cur_feats_nhwc=None, src_feats_nhwc=None):
+        if depth_planes_bdhw is not None:
+            raise _lib.IdhError("caller-supplied depth_planes_bdhw is not supported by the fused kernel")
+        B, K, C, H, W = self._check(cur_feats, src_feats)
+        _lib.require_cuda_f32(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
+        cur_n = cur_feats_nhwc if cur_feats_nhwc is not None else to_nhwc(cur_feats)
+        src_n = src_feats_nhwc if src_feats_nhwc is not None else to_nhwc(src_feats)
+        D = self.num_depth_bins
+        vol = torch.empty(B, D, H, W, device=cur_feats.device)
+        lowest, planes, mask = self._run(cur_n, src_n, src_extrinsics, src_poses, src_Ks, cur_invK, float(min_depth), float(max_depth), vol, 0, return_mask)
+        return vol, planes.view(1, D, 1, 1).expand(B, D, H, W), mask, lowest
+
+    def fused_into(self, cv_in, state, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK,
+                   dmin, dmax, return_mask):
+        """Pipeline entry: writes the volume NHWC into the CVEncoder's input buffer."""
+        B, K, C, H, W = matching_src_feats.shape
+        L, sp = _lib.lib(), _lib.stream_ptr()
+        mc, ms = matching_cur_feats.contiguous(), matching_src_feats.contiguous()
+        _lib.check(L.idh_nchw_to_nhwc_f32(mc.data_ptr(), state["cur_n"].data_ptr(), B, C, H * W, sp), "idh_nchw_to_nhwc_f32")
+        _lib.check(L.idh_nchw_to_nhwc_f32(ms.data_ptr(), state["src_n"].data_ptr(), B * K, C, H * W, sp), "idh_nchw_to_nhwc_f32")
+        lowest, planes, mask = self._run(state["cur_n"], state["src_n"], src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK, dmin, dmax,
+                                         cv_in.ptr, cv_in.cs, return_mask)
+        return lowest, mask
+
+
 class ZeroCostVolumeManager(CostVolumeManager):
     """Ablation volume of zeros (reference modules/cost_volume.py:1307-1384)."""
 

@@ -1,0 +1,396 @@
+// Fused MLP feature volume (gfx950): plane-sweep warp + per-voxel metadata + 3-layer MLP.
+//
+// Replaces FeatureVolumeManager.build_cost_volume + forward (reference
+// modules/cost_volume.py:437-706, 324-358; MLP modules/networks.py:218-233; geometry
+// utils/geometry_utils.py:55-89, 149-195).  The reference materialises, for each of D planes, a
+// (B,H,W,16(K+1)+10K+4) tensor (202 channels for K=7: 635 MB over 64 planes per frame) and runs
+// three nn.Linear over it.  Here the 202-vector of a voxel only ever exists in registers:
+//
+//   * 4 lanes cooperate on one voxel (pixel x plane): lane quarter q owns channels 4q..4q+3 of
+//     every feature vector, so one bilinear tap is a 64-byte segment read by 4 adjacent lanes,
+//     and — by construction — what a lane holds is exactly its B-operand fragment of
+//     v_mfma_f32_16x16x4_f32 (lane (col, q) supplies k = 16c + 4q + kk).  K order is free as long
+//     as the weights are packed to match, so W1's columns are re-ordered on the host into
+//         [ K blocks: warped features of view k ][ 4 blocks: per-voxel metadata ]
+//     where quarter q carries the metadata (mask, z, dot, ray angle, ray xyz) of views q and q+4
+//     (+ the plane depth), i.e. each lane builds rays only for "its" two views.
+//   * everything that does not depend on the plane is folded out of the per-voxel GEMM:
+//       - cur features and cur ray -> a per-pixel pre-activation computed once per task,
+//       - the 3K pose-distance inputs -> a per-batch-element bias (setup kernel).
+//   * layers are computed transposed (out^T = W . act^T, see csrc/mlp.hip) so activations stay in
+//     registers from the gather to the final dot product; W1 (per-voxel part) and W2 live in LDS in
+//     MFMA fragment order (152 KiB for K = 7) and are shared by the 8 waves of a persistent
+//     workgroup; per plane a wave issues (K+4+8)*32 MFMAs.
+// Roofline: fp32 MFMA (2*D*N*(16K+64+128)*128 + ... ~ 66.6 GFLOP per 96x128x64 frame).
+#include "idh_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kC = 16;
+constexpr int kHid = 128;
+constexpr int kNS = 8;            // 128 / 16
+constexpr int kMaxK = 7;          // LDS budget: (K+4)*8 KiB + 64 KiB + 1 KiB <= 160 KiB
+
+// per-b workspace layout (floats): [0,96) hom[k][12]   [96,128) tsrc[k][4]   [128,137) invK 3x3
+//                                  [144, 144+128) bias1_b
+constexpr int kWsHom = 0, kWsT = 96, kWsInvK = 128, kWsBias = 144;
+static_assert(kWsBias + kHid <= 272, "workspace layout");
+constexpr int kWsStrideReal = 272;
+
+__device__ __forceinline__ float lrelu01(float x) { return x >= 0.f ? x : x * 0.01f; }
+
+__device__ __forceinline__ float fv_depth_plane(int i, int D, float dmin, float dmax) {
+    float ramp = 0.f;
+    if (D > 1) {
+        const float step = 1.0f / (float)(D - 1);
+        ramp = (i < D / 2) ? step * (float)i : 1.0f - step * (float)(D - 1 - i);
+    }
+    return expf(logf(dmin) + logf(dmax / dmin) * ramp);
+}
+
+// ---- setup: homographies, source camera centres, pose-distance bias (one block per b) --------
+// w1_pose: (128, 3K) row-major = W1[:, pose-distance | R-measure | t-measure columns]
+__global__ void fv_setup_k(const float *__restrict__ src_K, const float *__restrict__ src_E,
+                           const float *__restrict__ src_poses, const float *__restrict__ cur_invK,
+                           const float *__restrict__ w1_pose, const float *__restrict__ b1, int K,
+                           float *__restrict__ ws) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    float *o = ws + (size_t)b * kWsStrideReal;
+    __shared__ float s_pd[3 * kMaxK];
+    if (t < K) {
+        const float *Km = src_K + (size_t)(b * K + t) * 16, *Em = src_E + (size_t)(b * K + t) * 16;
+        const float *iK = cur_invK + (size_t)b * 16, *Pm = src_poses + (size_t)(b * K + t) * 16;
+        float P[3][4];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+                for (int m = 0; m < 4; ++m) s = fmaf(Km[i * 4 + m], Em[m * 4 + j], s);
+                P[i][j] = s;
+            }
+        float *h = o + kWsHom + 12 * t;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                float s = 0.f;
+                for (int m = 0; m < 3; ++m) s = fmaf(P[i][m], iK[m * 4 + j], s);
+                h[i * 3 + j] = s;
+            }
+            h[9 + i] = P[i][3];
+        }
+        // source camera centre in the current frame (cost_volume.py:630-633)
+        o[kWsT + 4 * t + 0] = Pm[3]; o[kWsT + 4 * t + 1] = Pm[7]; o[kWsT + 4 * t + 2] = Pm[11]; o[kWsT + 4 * t + 3] = 0.f;
+        // DVMVS pose distance (geometry_utils.py:183-195)
+        const float tr = Pm[0] + Pm[5] + Pm[10];
+        const float rm = sqrtf(2.f * (1.f - fminf(3.f, tr) / 3.f));
+        const float tm = sqrtf(Pm[3] * Pm[3] + Pm[7] * Pm[7] + Pm[11] * Pm[11]);
+        s_pd[t] = sqrtf(tm * tm + rm * rm);
+        s_pd[K + t] = rm;
+        s_pd[2 * K + t] = tm;
+    }
+    if (t < 9) o[kWsInvK + t] = cur_invK[(size_t)b * 16 + (t / 3) * 4 + (t % 3)];
+    __syncthreads();
+    if (t < kHid) {
+        float s = b1[t];
+        for (int j = 0; j < 3 * K; ++j) s = fmaf(w1_pose[(size_t)t * 3 * K + j], s_pd[j], s);
+        o[kWsBias + t] = s;
+    }
+}
+
+struct FvArgs {
+    const float *cur;      // B,N,16
+    const float *src;      // B,K,N,16
+    const float *ws;       // per-b constants
+    const float *w1v;      // packed per-voxel part of W1: (K+4) blocks x 8 x 64 x float4
+    const float *w1p;      // packed per-pixel part of W1:   2 blocks x 8 x 64 x float4
+    const float *w2;       // packed W2: 8 x 8 x 64 x float4
+    const float *vecs;     // b2[128], w3[128], b3
+    float *vol;            // (B,D,N) if vol_cs == 0 else NHWC (B,N,vol_cs)
+    unsigned char *mask;   // (B,N) or null
+    int vol_cs;
+    int B, K, H, W, D;
+    int tiles_per_img;     // ceil(N/16)
+    int DP, G;             // planes per task, plane groups
+    float dmin, dmax;
+};
+
+__global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4 *sW1 = reinterpret_cast<f32x4 *>(smem_raw);            // (K+4)*8*64
+    f32x4 *sW2 = sW1 + (a.K + 4) * kNS * 64;                       // 8*8*64
+    float *sVec = reinterpret_cast<float *>(sW2 + kNS * kNS * 64); // 3*128 floats (b2, w3, b3)
+    {
+        const f32x4 *g1 = reinterpret_cast<const f32x4 *>(a.w1v);
+        const f32x4 *g2 = reinterpret_cast<const f32x4 *>(a.w2);
+        const int n1 = (a.K + 4) * kNS * 64, n2 = kNS * kNS * 64;
+        for (int i = threadIdx.x; i < n1; i += 512) sW1[i] = g1[i];
+        for (int i = threadIdx.x; i < n2; i += 512) sW2[i] = g2[i];
+        for (int i = threadIdx.x; i < 3 * kHid; i += 512) sVec[i] = a.vecs[i];
+    }
+    __syncthreads();
+    const float *s_b2 = sVec, *s_w3 = sVec + kHid;
+    const float b3 = sVec[2 * kHid];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ln = lane & 15, q = lane >> 4;
+    const int N = a.H * a.W;
+    const int K = a.K;
+    const float Wf = (float)a.W, Hf = (float)a.H;
+    const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
+
+    for (long long task = (long long)blockIdx.x * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
+        const int g = (int)(task % a.G);
+        const int tile = (int)((task / a.G) % a.tiles_per_img);
+        const int b = (int)(task / ((long long)a.G * a.tiles_per_img));
+        const int p_raw = tile * 16 + ln;
+        const bool live = p_raw < N;
+        const int p = live ? p_raw : N - 1;
+        const int py = p / a.W, px = p - py * a.W;
+        const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+        const float *pb = a.ws + (size_t)b * kWsStrideReal;
+
+        const f32x4 cur4 = *reinterpret_cast<const f32x4 *>(a.cur + ((size_t)b * N + p) * kC + 4 * q);
+        // back-projected ray of the pixel (geometry_utils.py:60) and its direction (cost_volume.py:618)
+        const float *iK = pb + kWsInvK;
+        const float rx = fmaf(iK[0], pxf, fmaf(iK[1], pyf, iK[2]));
+        const float ry = fmaf(iK[3], pxf, fmaf(iK[4], pyf, iK[5]));
+        const float rz = fmaf(iK[6], pxf, fmaf(iK[7], pyf, iK[8]));
+
+        // ---- per-pixel pre-activation: bias_b + W1[:,cur].cur + W1[:,cur_ray].ray -------------
+        f32x4 pre[kNS];
+#pragma unroll
+        for (int i = 0; i < kNS; ++i) pre[i] = *reinterpret_cast<const f32x4 *>(pb + kWsBias + 16 * i + 4 * q);
+        const int d0 = g * a.DP, d1 = min(a.D, d0 + a.DP);
+        if (d0 >= d1) continue;
+        // cur ray = normalize(depth * r): plane independent for depth > 0 (F.normalize eps 1e-12)
+        const float rn = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+        const float crx = rx / rn, cry = ry / rn, crz = rz / rn;
+        {
+            const f32x4 rayB = (q == 0) ? (f32x4){crx, cry, crz, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 *w1p = reinterpret_cast<const f32x4 *>(a.w1p);
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+                const f32x4 A0 = w1p[(0 * kNS + i) * 64 + lane];
+                const f32x4 A1 = w1p[(1 * kNS + i) * 64 + lane];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) pre[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[kk], cur4[kk], pre[i], 0, 0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) pre[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[kk], rayB[kk], pre[i], 0, 0, 0);
+            }
+        }
+
+#pragma unroll 1
+        for (int d = d0; d < d1; ++d) {
+            const float depth = fv_depth_plane(d, a.D, a.dmin, a.dmax);
+            const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
+            f32x4 acc1[kNS];
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
+            // metadata registers of this lane: [0..6] view q, [7..13] view q+4, [14] plane depth
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m7 = 0.f, m8 = 0.f, m9 = 0.f;
+            bool any_inb = false, any_front = false;
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const float *hm = pb + kWsHom + 12 * k;
+                const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+                const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+                const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+                const float cx = fmaf(depth, qx, hm[9]);
+                const float cy = fmaf(depth, qy, hm[10]);
+                const float cz = fmaf(depth, qz, hm[11]);
+                const float z = fmaxf(cz, 1e-5f);
+                float r = __builtin_amdgcn_rcpf(z);
+                r = r * fmaf(-z, r, 2.0f);
+                const float u = cx * r, v = cy * r;
+                any_inb |= (u > 2.f) & (u < Wf - 2.f) & (v > 2.f) & (v < Hf - 2.f);
+                const float maskv = z > 0.f ? 1.f : 0.f;
+                any_front |= z > 0.f;
+                const float sx = fminf(fmaxf(u - 0.5f, -1.0f), Wf);
+                const float sy = fminf(fmaxf(v - 0.5f, -1.0f), Hf);
+                const float x0f = floorf(sx), y0f = floorf(sy);
+                const float fx = sx - x0f, fy = sy - y0f;
+                const int x0 = (int)x0f, y0 = (int)y0f;
+                const float wx0 = (x0 >= 0 && x0 < a.W) ? 1.0f - fx : 0.f;
+                const float wx1 = (x0 + 1 < a.W) ? fx : 0.f;
+                const float wy0 = (y0 >= 0 && y0 < a.H) ? 1.0f - fy : 0.f;
+                const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
+                const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
+                const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
+                const float *sb = a.src + (size_t)(b * K + k) * N * kC + 4 * q;
+                const f32x4 t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kC);
+                const f32x4 t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kC);
+                const f32x4 t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kC);
+                const f32x4 t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kC);
+                const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+                f32x4 wv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wv[e] = fmaf(w11, t11[e], fmaf(w10, t10[e], fmaf(w01, t01[e], w00 * t00[e])));
+                float part = wv[0] * cur4[0];
+                part = fmaf(wv[1], cur4[1], part); part = fmaf(wv[2], cur4[2], part); part = fmaf(wv[3], cur4[3], part);
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+                const float dotv = part * maskv;
+                const bool s0 = (k == q), s1 = (k == q + 4);
+                m0 = s0 ? maskv : m0; m1 = s0 ? z : m1; m2 = s0 ? dotv : m2;
+                m7 = s1 ? maskv : m7; m8 = s1 ? z : m8; m9 = s1 ? dotv : m9;
+                // layer-1 block k: warped features of view k
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const f32x4 A = sW1[(k * kNS + i) * 64 + lane];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
+                }
+            }
+            // rays / ray angles of this lane's two views (cost_volume.py:630-659)
+            float m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m10 = 0.f, m11 = 0.f, m12 = 0.f, m13 = 0.f;
+            {
+                const int v0 = q, v1 = q + 4;
+                if (v0 < K) {
+                    const float *t = pb + kWsT + 4 * v0;
+                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
+                    const float in = 1.0f / fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
+                    m4 = ax * in; m5 = ay * in; m6 = az * in;
+                    const float n1 = fmaxf(sqrtf(crx * crx + cry * cry + crz * crz), 1e-5f);
+                    const float n2 = fmaxf(sqrtf(m4 * m4 + m5 * m5 + m6 * m6), 1e-5f);
+                    m3 = (crx * m4 + cry * m5 + crz * m6) / (n1 * n2);
+                }
+                if (v1 < K) {
+                    const float *t = pb + kWsT + 4 * v1;
+                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
+                    const float in = 1.0f / fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
+                    m11 = ax * in; m12 = ay * in; m13 = az * in;
+                    const float n1 = fmaxf(sqrtf(crx * crx + cry * cry + crz * crz), 1e-5f);
+                    const float n2 = fmaxf(sqrtf(m11 * m11 + m12 * m12 + m13 * m13), 1e-5f);
+                    m10 = (crx * m11 + cry * m12 + crz * m13) / (n1 * n2);
+                }
+            }
+            const f32x4 mb[4] = {(f32x4){m0, m1, m2, m3}, (f32x4){m4, m5, m6, m7}, (f32x4){m8, m9, m10, m11},
+                                 (f32x4){m12, m13, depth, 0.f}};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const f32x4 A = sW1[((K + c) * kNS + i) * 64 + lane];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], mb[c][kk], acc1[i], 0, 0, 0);
+                }
+            }
+            // ---- LeakyReLU(0.01) -> layer 2 (weights from LDS) -> LeakyReLU -> layer 3 ----------
+            f32x4 acc2[kNS];
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc1[i][r] = lrelu01(acc1[i][r]);
+                acc2[i] = *reinterpret_cast<const f32x4 *>(s_b2 + 16 * i + 4 * q);
+            }
+#pragma unroll
+            for (int c = 0; c < kNS; ++c) {
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const f32x4 A = sW2[(c * kNS + i) * 64 + lane];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], acc1[c][kk], acc2[i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+                const f32x4 w3 = *reinterpret_cast<const f32x4 *>(s_w3 + 16 * i + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fmaf(w3[r], lrelu01(acc2[i][r]), s);
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (q == 0 && live) {
+                if (a.vol_cs > 0) a.vol[((size_t)b * N + p) * a.vol_cs + d] = s + b3;
+                else a.vol[((size_t)b * a.D + d) * N + p] = s + b3;
+                // overall mask: the reference overwrites it every plane, the LAST plane survives
+                if (a.mask != nullptr && d == a.D - 1) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
+            }
+        }
+    }
+}
+
+// lowest[b,p] = plane_{argmax_d vol[b,d,p]} (first maximum wins), reference cost_volume.py:352-356
+__global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__ vol, int vol_cs, int B, int N, int D,
+                                                       float dmin, float dmax, float *__restrict__ lowest,
+                                                       float *__restrict__ planes_out) {
+    const long long total = (long long)B * N;
+    if (planes_out && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < D; i += 256) planes_out[i] = fv_depth_plane(i, D, dmin, dmax);
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
+        const long long b = t / N, p = t - b * N;
+        float best = -INFINITY;
+        int bi = 0;
+        for (int d = 0; d < D; ++d) {
+            const float v = vol_cs > 0 ? vol[t * vol_cs + d] : vol[(b * D + d) * N + p];
+            if (v > best) { best = v; bi = d; }
+        }
+        lowest[t] = fv_depth_plane(bi, D, dmin, dmax);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t idh_feature_volume_workspace_bytes(int B) { return B <= 0 ? 0 : (size_t)B * kWsStrideReal * sizeof(float); }
+
+extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                                      const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
+                                      float dmin, float dmax, int B, int K, int C, int H, int W, int D,
+                                      const float *w1_voxel_packed, const float *w1_pixel_packed,
+                                      const float *w1_pose_rowmajor, const float *b1, const float *w2_packed,
+                                      const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
+                                      unsigned char *mask_bhw, float *planes_d, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    if (B < 0 || K <= 0 || H <= 0 || W <= 0 || D <= 0 || !(dmin > 0.f) || !(dmax > 0.f)) return IDH_EINVAL;
+    if (C != kC || K > kMaxK || D > 4096) return IDH_EUNSUPPORTED;
+    if (B == 0) return IDH_OK;
+    if (!cur_nhwc || !src_nhwc || !src_K_44 || !src_E_44 || !src_poses_44 || !cur_invK_44 || !w1_voxel_packed ||
+        !w1_pixel_packed || !w1_pose_rowmajor || !b1 || !w2_packed || !vecs_b2_w3_b3 || !vol)
+        return IDH_EINVAL;
+    if (vol_nhwc_cs != 0 && vol_nhwc_cs < D) return IDH_EINVAL;
+    if (!workspace || workspace_bytes < idh_feature_volume_workspace_bytes(B)) return IDH_EWORKSPACE;
+    hipStream_t st = idh_stream(stream);
+    float *ws = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(fv_setup_k, dim3(B), dim3(128), 0, st, src_K_44, src_E_44, src_poses_44, cur_invK_44,
+                       w1_pose_rowmajor, b1, K, ws);
+    IDH_CHECK_LAUNCH();
+
+    FvArgs a{};
+    a.cur = cur_nhwc; a.src = src_nhwc; a.ws = ws; a.w1v = w1_voxel_packed; a.w1p = w1_pixel_packed; a.w2 = w2_packed;
+    a.vecs = vecs_b2_w3_b3; a.vol = vol; a.mask = mask_bhw; a.vol_cs = vol_nhwc_cs;
+    a.B = B; a.K = K; a.H = H; a.W = W; a.D = D; a.dmin = dmin; a.dmax = dmax;
+    const int N = H * W;
+    a.tiles_per_img = (N + 15) / 16;
+    // plane groups: aim at >= 8 tasks per wave slot (256 CUs x 8 waves) while keeping >= 4 planes
+    // per task so the per-pixel pre-activation is amortised
+    const long long pix_tasks = (long long)B * a.tiles_per_img;
+    int G = (int)((256ll * 8 * 4 + pix_tasks - 1) / pix_tasks);
+    if (G < 1) G = 1;
+    if (G > (D + 3) / 4) G = (D + 3) / 4;
+    a.DP = (D + G - 1) / G;
+    a.G = (D + a.DP - 1) / a.DP;
+    const long long ntasks = pix_tasks * a.G;
+    int grid = (int)((ntasks + 7) / 8);
+    if (grid > 256) grid = 256;  // persistent: one 512-thread workgroup per CU (LDS-resident weights)
+    const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4) + 3 * kHid * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return IDH_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fv_mlp_k, dim3(grid), dim3(512), lds, st, a);
+    IDH_CHECK_LAUNCH();
+    if (lowest_bhw) {
+        int g2 = idh_cdiv((long long)B * N, 256);
+        if (g2 > 4096) g2 = 4096;
+        hipLaunchKernelGGL(argmax_planes_k, dim3(g2), dim3(256), 0, st, vol, vol_nhwc_cs, B, N, D, dmin, dmax, lowest_bhw,
+                           planes_d);
+        IDH_CHECK_LAUNCH();
+    }
+    return IDH_OK;
+}

@@ -68,6 +68,34 @@ int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const 
                             int B, int K, int C, int H, int W, int D, float *cost, int cost_nhwc_cs,
                             float *lowest_bhw, float *planes_d, void *stream);
 
+/* ---- plane-sweep MLP feature volume ---------------------------------------------------- */
+/* Replaces FeatureVolumeManager.build_cost_volume + forward (reference
+ * modules/cost_volume.py:437-706, 324-358) for K <= 7 source views, C = 16, hidden width 128:
+ *   vol[b,d,y,x] = MLP([warped src feats (16K), cur feats (16), mask (K), depths (K), plane depth,
+ *                       dot products (K), ray angles (K), rays (3(K+1)), pose distances (3K)])
+ * with MLP = Linear -> LeakyReLU(.01) -> Linear -> LeakyReLU(.01) -> Linear (networks.py:218-233).
+ * The first Linear's weight W1 (128 x 16(K+1)+10K+4) is passed in three pieces, in the K order
+ * the kernel builds its operands in (implicit-depth_amd/cost_volume.py:pack_feature_mlp):
+ *   w1_voxel_packed  per-voxel columns [warped K*16 | 4 metadata blocks], MFMA fragment order
+ *   w1_pixel_packed  per-pixel columns [cur feats 16 | cur ray 3 + pad], MFMA fragment order
+ *   w1_pose_rowmajor (128, 3K) columns of the pose-distance / R / t measures (folded into a
+ *                    per-batch-element bias on the device)
+ *   vecs_b2_w3_b3    3 x 128 floats: b2, W3[0,:], [b3, 0...]
+ *   vol              (B,D,H,W) when vol_nhwc_cs == 0, else NHWC (B,H,W,vol_nhwc_cs >= D)
+ *   lowest_bhw       (B,H,W) or NULL; mask_bhw (B,H,W) uint8 "overall mask" of the LAST plane or
+ *                    NULL; planes_d (D) or NULL (written together with lowest_bhw)
+ *   workspace        >= idh_feature_volume_workspace_bytes(B)
+ */
+size_t idh_feature_volume_workspace_bytes(int B);
+int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                           const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
+                           float dmin, float dmax, int B, int K, int C, int H, int W, int D,
+                           const float *w1_voxel_packed, const float *w1_pixel_packed,
+                           const float *w1_pose_rowmajor, const float *b1, const float *w2_packed,
+                           const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
+                           unsigned char *mask_bhw, float *planes_d, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* ---- per-pixel occlusion MLP over all query planes ---------------------------------- */
 /* Replaces the per-plane loop bd_model.py:293-304 -> run_mlp_val (:412-442) ->
  * BinaryMLPNetwork scale 0 (modules/networks.py:98-115): for every pixel m and plane p
