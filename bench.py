@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="auto", help="auto | warp_match_dot | hot_path")
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
-    ap.add_argument("--views", type=int, default=8, help="source views K (BASELINE.json: 8; reference-native tuples: 7)")
+    ap.add_argument("--views", type=int, default=0, help="source views K; 0 = 7 for --volume mlp (reference-native 8-frame tuple = 1 cur + 7 src), 8 for --volume dot (BASELINE.json literal)")
+    ap.add_argument("--volume", default="mlp", choices=["mlp", "dot"], help="mlp = FeatureVolumeManager (every shipped BDModel config), dot = CostVolumeManager")
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
@@ -147,6 +148,8 @@ def make_workload(args, device, rank):
 # ------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.views == 0:
+        args.views = 7 if (args.volume == "mlp" and args.workload != "warp_match_dot") else 8
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -160,7 +160,14 @@ class HotPathWorkload:
         self.H, self.W, self.C = args.height // 4, args.width // 4, 16
         self.P = 8
         enc_ch = [24, 48, 64, 160, 256]
-        cv = CostVolumeManager(self.H, self.W, self.D)
+        self.volume = getattr(args, "volume", "dot")
+        if self.volume == "mlp":
+            from .cost_volume import FeatureVolumeManager
+
+            cv = FeatureVolumeManager(self.H, self.W, self.D, num_source_views=self.K)
+            syn.fill_state_dict(cv.mlp, seed=99, gain=1.4)
+        else:
+            cv = CostVolumeManager(self.H, self.W, self.D)
         cve = net.CVEncoder(self.D, enc_ch[1:], [64, 128, 256, 384])
         dec = net.BDDecoderPP(enc_ch[:1] + cve.num_ch_enc)
         mlp = net.BinaryMLPNetwork(dec.num_ch_dec, mlp_size=128, use_prior=False)
@@ -177,10 +184,11 @@ class HotPathWorkload:
         self.out = None
 
     def config(self):
-        return {"workload": f"{self.name}: matching feats -> fused warp+match (dot) -> CVEncoder -> BDDecoderPP (UNet++) -> occlusion MLP x{self.P} planes; "
+        vol = "fused MLP feature volume (FeatureVolumeManager, implicit_depth.yaml)" if self.volume == "mlp" else "fused warp+match (dot, CostVolumeManager)"
+        return {"workload": f"{self.name}: matching feats -> {vol} -> CVEncoder -> BDDecoderPP (UNet++) -> occlusion MLP x{self.P} planes; "
                             f"{self.Wi}x{self.Hi} image, matching map {self.W}x{self.H}, K={self.K} source views, D={self.D} planes, fp32; "
                             "image/matching backbones (third-party) replaced by resident synthetic feature maps",
-                "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D, "query_planes": self.P}
+                "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D, "query_planes": self.P, "volume": self.volume}
 
     def step(self, ev=None):
         d = self.d
@@ -227,7 +235,12 @@ class HotPathWorkload:
         n, t0 = 0, time.perf_counter()
         with torch.inference_mode():
             while True:
-                cvol, _, _ = ocv.cost_volume_dot(i["cur_feats"][:1], i["src_feats"][:1], i["src_extrinsics"][:1], i["src_Ks"][:1], i["cur_invK"][:1], 0.25, 5.0, self.D)
+                if self.volume == "mlp":
+                    w_fv = {k: v.detach().cpu() for k, v in self.model.cost_volume.mlp.state_dict().items()}
+                    cvol = ocv.feature_volume(i["cur_feats"][:1], i["src_feats"][:1], i["src_extrinsics"][:1], i["src_poses"][:1], i["src_Ks"][:1],
+                                              i["cur_invK"][:1], 0.25, 5.0, self.D, w_fv)[0]
+                else:
+                    cvol, _, _ = ocv.cost_volume_dot(i["cur_feats"][:1], i["src_feats"][:1], i["src_extrinsics"][:1], i["src_Ks"][:1], i["cur_invK"][:1], 0.25, 5.0, self.D)
                 pyr = [t[:1] for t in self.host_pyr]
                 enc = onet.cv_encoder(cvol, pyr[1:], w_cve)
                 dec = onet.unetpp_decoder([pyr[0]] + enc, w_dec, depth_head=False)
