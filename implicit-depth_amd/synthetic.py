@@ -144,3 +144,71 @@ def rendered_depth_planes(B: int, H: int, W: int, P: int = 8) -> torch.Tensor:
     """P fronto-parallel query planes 1.5..5.0 m (reference ``generic_mvs_dataset.py:242``)."""
     d = torch.linspace(1.5, 5.0, P).view(1, P, 1, 1)
     return d.expand(B, P, H, W).contiguous()
+
+
+class _FeatureInfo:
+    def __init__(self, ch):
+        self._ch = list(ch)
+
+    def channels(self):
+        return list(self._ch)
+
+
+class StubImageEncoder(torch.nn.Module):
+    """Random-init 5-level strided-conv pyramid with the output channels/strides of the
+    reference's timm ``tf_efficientnetv2_s`` feature extractor (bd_model.py:47-51).  NOT the
+    third-party network — a stand-in so that whole-model plumbing can run on both sides of a
+    comparison with identical inputs to the hot path."""
+
+    def __init__(self, channels=(24, 48, 64, 160, 256)):
+        super().__init__()
+        self._channels = list(channels)
+        self.stages = torch.nn.ModuleList()
+        cin = 3
+        for c in channels:
+            self.stages.append(torch.nn.Conv2d(cin, c, 3, 2, 1))
+            cin = c
+        self.feature_info = _FeatureInfo(self._channels)
+
+    def forward(self, x):
+        outs = []
+        for st in self.stages:
+            x = torch.tanh(st(x))
+            outs.append(x)
+        return outs
+
+
+class StubResnetStem(torch.nn.Module):
+    """Stand-in for antialiased_cnns.resnet18's conv1/bn1/relu/maxpool/layer1 (64 ch @ 1/4 res)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = torch.nn.Conv2d(3, 64, 7, 2, 3)
+        self.bn1 = torch.nn.Identity()
+        self.relu = torch.nn.ReLU()
+        self.maxpool = torch.nn.MaxPool2d(3, 2, 1)
+        self.layer1 = torch.nn.Conv2d(64, 64, 3, 1, 1)
+
+
+def frame_tuple(B: int, K: int, img_h: int, img_w: int, seed: int = 0, P: int = 8):
+    """cur_data / src_data dictionaries with the keys BDModel.forward reads
+    (bd_model.py:186-194, :266-299; produced by generic_mvs_dataset.py:742-809)."""
+    Hm, Wm = img_h // 4, img_w // 4
+    cvi = cost_volume_inputs(B, K, 16, Hm, Wm, seed)
+    cur_pose = torch.eye(4).expand(B, 4, 4).contiguous()  # world = current camera
+    src_world_T_cam = cvi["src_poses"]  # src -> world(=cur)
+    K1 = intrinsics(Wm, Hm).float()
+    K0 = intrinsics(img_w // 2, img_h // 2).float()
+    cur = {
+        "image_b3hw": randn((B, 3, img_h, img_w), seed, "cur_img"),
+        "K_s1_b44": K1.expand(B, 4, 4).contiguous(), "invK_s1_b44": torch.linalg.inv(K1).expand(B, 4, 4).contiguous(),
+        "K_s0_b44": K0.expand(B, 4, 4).contiguous(), "invK_s0_b44": torch.linalg.inv(K0).expand(B, 4, 4).contiguous(),
+        "cam_T_world_b44": cur_pose.clone(), "world_T_cam_b44": cur_pose.clone(),
+        "rendered_depth": rendered_depth_planes(B, img_h // 2, img_w // 2, P),
+    }
+    src = {
+        "image_b3hw": randn((B, K, 3, img_h, img_w), seed, "src_img"),
+        "K_s1_b44": K1.expand(B, K, 4, 4).contiguous(), "invK_s1_b44": torch.linalg.inv(K1).expand(B, K, 4, 4).contiguous(),
+        "cam_T_world_b44": torch.linalg.inv(src_world_T_cam), "world_T_cam_b44": src_world_T_cam.clone(),
+    }
+    return cur, src

@@ -217,6 +217,54 @@ def main():
     pts = bp(torch.full((1, 1, 6, 8), 1.7), invK)
     pr = Project3D()(pts, syn.intrinsics(8, 6).float()[None], torch.linalg.inv(poses[2])[None])
     save("g6_geometry", planes64=planes64, planes96=planes96, pose_dist=pd, backproject=pts, project=pr)
+    gen_bdmodel(syn)
+
+
+def gen_bdmodel(syn):
+    """G5: the reference's BDModel.forward end to end (BASELINE config 1 shape: 128x96 image,
+    K=2, D=16, simple_cost_volume) with stand-in backbones; stores the hot path's inputs
+    (matching features, encoder pyramid) and the model's outputs."""
+    print("G5 BDModel.forward (stub backbones)")
+    import timm, antialiased_cnns
+    from options import Options
+    timm.create_model = lambda *a, **k: syn.StubImageEncoder()
+    for nm in ("resnet18", "resnet34", "resnet50", "resnet101", "resnet152"):
+        setattr(antialiased_cnns, nm, lambda *a, **k: syn.StubResnetStem())
+    import contextlib, io
+    from experiment_modules.bd_model import BDModel
+    for name, fv, K, use_prior in (("g5_bdmodel_dot", "simple_cost_volume", 2, False), ("g5_bdmodel_mlp", "mlp_feature_volume", 7, False)):
+        o = Options()
+        o.image_width, o.image_height = 128, 96
+        o.matching_num_depth_bins = 16
+        o.feature_volume_type = fv
+        o.model_num_views = K + 1
+        o.binary_loss_positive_weight = 1.0
+        o.bd_edge_regularision = False
+        o.use_prior = use_prior
+        torch.nn.Module.save_hyperparameters = lambda self, *a, **k: None
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = BDModel(o)
+        model.eval()
+        syn.fill_state_dict(model, seed=30, gain=1.0)
+        cur, src = syn.frame_tuple(1, K, 96, 128, seed=31, P=3)
+        captured = {}
+        orig = model.compute_matching_feats
+        def spy(*a, **k):
+            r = orig(*a, **k)
+            captured["mc"], captured["ms"] = r
+            return r
+        model.compute_matching_feats = spy
+        enc_orig = model.encoder.forward
+        def enc_spy(x):
+            r = enc_orig(x)
+            captured["enc"] = r
+            return r
+        model.encoder.forward = enc_spy
+        out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+        extra = {"overall_mask": out["overall_mask_bhw"]} if out["overall_mask_bhw"] is not None else {}
+        save(name, K=np.array(K), pred_0=out["pred_0"], lowest_cost=out["lowest_cost_bhw"], matching_cur=captured["mc"],
+             matching_src=captured["ms"], **{f"enc{i}": e for i, e in enumerate(captured["enc"])}, **extra,
+             keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))))
 
 
 if __name__ == "__main__":

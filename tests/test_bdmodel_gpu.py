@@ -1,0 +1,53 @@
+"""End-to-end check against the REFERENCE's BDModel.forward (golden G5, stub backbones): the
+hot path is fed the matching / encoder features the reference model produced and must
+reproduce its ``pred_0``, ``lowest_cost_bhw`` and ``overall_mask_bhw`` — this pins the forward
+orchestration (relative poses bd_model.py:196-204, volume -> encoder -> decoder -> per-plane MLP)."""
+import pytest
+import torch
+from torch import nn
+
+import implicit_depth_amd.synthetic as syn
+from conftest import TOL, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _holder(K, volume):
+    from implicit_depth_amd import cost_volume as cv
+    from implicit_depth_amd import networks as net
+
+    h = nn.Module()
+    H, W, D = 24, 32, 16
+    h.cost_volume = cv.FeatureVolumeManager(H, W, D, num_source_views=K) if volume == "mlp" else cv.CostVolumeManager(H, W, D)
+    h.cost_volume_net = net.CVEncoder(D, [48, 64, 160, 256], [64, 128, 256, 384])
+    h.depth_decoder = net.BDDecoderPP([24] + h.cost_volume_net.num_ch_enc)
+    h.binary_mlp = net.BinaryMLPNetwork(h.depth_decoder.num_ch_dec, mlp_size=128, use_prior=False)
+    syn.fill_state_dict(h, seed=30)  # name-keyed: same tensors the reference BDModel received
+    return h
+
+
+@pytest.mark.parametrize("volume", ["dot", "mlp"])
+def test_hot_path_reproduces_reference_bdmodel_forward(volume):
+    from implicit_depth_amd.dropin import hot_path_of
+
+    g = load_golden(f"g5_bdmodel_{volume}")
+    K = int(g["K"])
+    h = _holder(K, volume)
+    hot_keys = sorted(k for k in h.state_dict() if not k.startswith("cost_volume.linear") or True)
+    assert sorted(h.state_dict()) == list(g["keys"])
+    h.cuda()
+    cur, src = syn.frame_tuple(1, K, 96, 128, seed=31, P=3)
+    cur = {k: v.cuda() for k, v in cur.items()}
+    src = {k: v.cuda() for k, v in src.items()}
+    src_cam_T_cur_cam = src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1)
+    cur_cam_T_src_cam = cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"]
+    hot = hot_path_of(h)
+    t = lambda name: torch.as_tensor(g[name]).cuda()
+    out = hot(t("matching_cur"), t("matching_src"), [t(f"enc{i}") for i in range(5)], src_cam_T_cur_cam, cur_cam_T_src_cam,
+              src["K_s1_b44"], cur["invK_s1_b44"], rendered_depth=cur["rendered_depth"], return_mask=True)
+    assert rel_err(out["pred_0"].cpu(), g["pred_0"]) < TOL
+    assert ((out["lowest_cost_bhw"].cpu() - torch.as_tensor(g["lowest_cost"])).abs() > 1e-5).float().mean().item() < 5e-3
+    if volume == "mlp":
+        assert (out["overall_mask_bhw"].cpu() != torch.as_tensor(g["overall_mask"])).float().mean().item() < 2e-3
+    else:
+        assert out["overall_mask_bhw"] is None
