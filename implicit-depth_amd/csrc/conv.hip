@@ -254,9 +254,10 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
 //   A in LDS: [hy 10][q 4][hx 18] float4  (q = channel quad)  -> a tap shift is a pure offset and a
 //             fragment read touches 16 consecutive float4 per quarter-wave: no bank conflicts
 //   B in LDS: [tap 9][q 4][co 64] float4
-constexpr int kLT_H = 8, kLT_W = 16, kLT_N = 64;
-constexpr int kHaloW = kLT_W + 2, kHaloH = kLT_H + 2;
-constexpr int kASlots = kHaloH * 4 * kHaloW;  // 720 float4
+// RW = tile rows per wave: RW = 2 -> 8x16 tile (best operand reuse), RW = 1 -> 4x16 tile (twice the
+// workgroups: used when an 8-row grid cannot fill 256 CUs x 3 resident workgroups).
+constexpr int kLT_W = 16, kLT_N = 64;
+constexpr int kHaloW = kLT_W + 2;
 constexpr int kBSlots3 = 9 * 4 * kLT_N;       // 2304 float4
 
 struct LdsConvArgs {
@@ -264,7 +265,12 @@ struct LdsConvArgs {
     int tiles_x, tiles_y;  // spatial tiles per image
 };
 
+template <int RW>
 __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
+    constexpr int kLT_H = 4 * RW, kHaloH = kLT_H + 2;
+    constexpr int kASlots = kHaloH * 4 * kHaloW;  // 720 (RW=2) / 432 (RW=1) float4
+    constexpr int kALoads = (kASlots + 255) / 256;
+    constexpr int kCLoads = (kLT_H * kLT_W * 4) / 256;  // centre pixels for the 1x1 source
     __shared__ f32x4 sA[kASlots];
     __shared__ f32x4 sB[kBSlots3];
     const ConvArgs &a = la.c;
@@ -285,9 +291,9 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
     const int y0 = ty * kLT_H, x0 = tx * kLT_W;
     const int n0 = nt * kLT_N;
 
-    f32x4 acc[2][4];
+    f32x4 acc[RW][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -300,11 +306,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
     // ---- staging: global -> registers (prefetch) -> LDS -----------------------------------
     // A slots are enumerated (hy, hx, q) with q fastest so that 4 consecutive lanes read the 64
     // contiguous bytes of one pixel; the LDS image is [hy][q][hx].
-    f32x4 pa[3], pb[9];
+    f32x4 pa[kALoads], pb[9];
     auto issue3 = [&](int c) {  // 3x3 source 0, chunk c
         const ConvSrc &s = a.s[0];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < kALoads; ++k) {
             const int slot = tid + 256 * k;
             const int q = slot & 3, pix = slot >> 2;
             const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
     };
     auto commit3 = [&]() {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < kALoads; ++k) {
             const int slot = tid + 256 * k;
             const int q = slot & 3, pix = slot >> 2;
             const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
@@ -335,25 +341,25 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
-            f32x4 A[2], Bf[4];
+            f32x4 A[RW], Bf[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) A[i] = sA[((2 * wave + i + dy) * 4 + h) * kHaloW + ln + dx];
+            for (int i = 0; i < RW; ++i) A[i] = sA[((RW * wave + i + dy) * 4 + h) * kHaloW + ln + dx];
 #pragma unroll
             for (int j = 0; j < 4; ++j) Bf[j] = sB[(tap * 4 + h) * kLT_N + 16 * j + ln];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < RW; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
         }
     };
-    // 1x1 source 1: A = the 8x16 centre pixels (512 float4 -> 2 per thread), B = 4 x 64 float4
+    // 1x1 source 1: A = the centre pixels of the tile (kCLoads float4 per thread), B = 4 x 64 float4
     auto issue1 = [&](int c) {
         const ConvSrc &s = a.s[1];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kCLoads; ++k) {
             const int slot = tid + 256 * k;
             const int q = slot & 3, pix = slot >> 2;
             const int py = pix >> 4, px = pix & 15;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
     };
     auto commit1 = [&]() {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kCLoads; ++k) {
             const int slot = tid + 256 * k;
             const int q = slot & 3, pix = slot >> 2;
             const int py = pix >> 4, px = pix & 15;
@@ -375,15 +381,15 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
         sB[tid] = pb[0];
     };
     auto compute1 = [&]() {
-        f32x4 A[2], Bf[4];
+        f32x4 A[RW], Bf[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) A[i] = sA[((2 * wave + i + 1) * 4 + h) * kHaloW + ln + 1];
+        for (int i = 0; i < RW; ++i) A[i] = sA[((RW * wave + i + 1) * 4 + h) * kHaloW + ln + 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) Bf[j] = sB[h * kLT_N + 16 * j + ln];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RW; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
@@ -418,8 +424,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
 
     // ---- epilogue (same transposed C/D layout as above: 4 consecutive channels per lane) -------
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int oy = y0 + 2 * wave + i, ox = x0 + ln;
+    for (int i = 0; i < RW; ++i) {
+        const int oy = y0 + RW * wave + i, ox = x0 + ln;
         if (oy >= a.Ho || ox >= a.Wo) continue;
         const size_t m = ((size_t)n * a.Ho + oy) * a.Wo + ox;
         if (a.S > 1) {
@@ -616,19 +622,21 @@ int run_conv(const idh_op &op, hipStream_t st) {
     // LDS-staged kernel for the dominant shape family (tile_m == 8 requests it, tile_m == 0 = auto)
     const bool lds_ok = a.s[0].ks == 3 && a.s[0].stride == 1 && a.s[0].pad_mode == IDH_PAD_ZEROS && (op.Cout % kLT_N) == 0 &&
                         (!a.s[1].in || (a.s[1].ks == 1 && a.s[1].stride == 1)) && op.Wo >= kLT_W;
-    if (lds_ok && (op.tile_m == 8 || op.tile_m == 0)) {
-        LdsConvArgs la{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + kLT_H - 1) / kLT_H};
+    if (lds_ok && (op.tile_m == 8 || op.tile_m == 0 || op.tile_m == 9)) {
+        const int rows = op.tile_m == 9 ? 4 : 8;
+        LdsConvArgs la{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + rows - 1) / rows};
         la.c.NT = op.Cout / kLT_N;
         const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
         if (la.c.S > chunks) la.c.S = chunks;
         const long long blocks = (long long)la.c.S * op.N * la.tiles_x * la.tiles_y * la.c.NT;
         if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
-        hipLaunchKernelGGL(conv3x3_lds_k, dim3((unsigned)blocks), dim3(256), 0, st, la);
+        if (rows == 8) hipLaunchKernelGGL(conv3x3_lds_k<2>, dim3((unsigned)blocks), dim3(256), 0, st, la);
+        else hipLaunchKernelGGL(conv3x3_lds_k<1>, dim3((unsigned)blocks), dim3(256), 0, st, la);
         IDH_CHECK_LAUNCH();
         a.S = la.c.S;
     } else {
     int tm = op.tile_m, tn = op.tile_n;
-    if (tm == 8) tm = 0;
+    if (tm == 8 || tm == 9) tm = 0;
     const int nsub = a.Cout_pad / 16;
     if (tn == 0) tn = (nsub % 4 == 0) ? 4 : (nsub % 2 == 0 ? 2 : 1);
     if (tm == 0) tm = 4;

@@ -122,11 +122,17 @@ def lds_eligible(srcs, cout: int, Wo: int, pad_mode: int) -> bool:
     return True
 
 
-def choose_lds_split(N: int, Ho: int, Wo: int, cout: int, chunks: int) -> int:
-    """Split K only when the grid cannot fill 256 CUs x 3 resident workgroups AND every split still
-    gets >= 6 chunks of 16 channels (measured on MI355X, tools/perf_conv_layers.py)."""
-    blocks = N * (-(-Ho // 8)) * (-(-Wo // 16)) * (cout // 64)
-    return max(1, min(-(-768 // blocks), chunks // 6, 16))
+def choose_lds_tile(N: int, Ho: int, Wo: int, cout: int, chunks: int):
+    """(tile code, split): 8-row tiles (code 8) when they already give one full round of
+    256 CUs x 3 resident workgroups, else 4-row tiles (code 9); split K only when the grid still
+    cannot fill the chip AND every split keeps >= 6 chunks of 16 channels (measured on MI355X,
+    tools/perf_conv_layers.py)."""
+    per_row_tiles = N * (-(-Wo // 16)) * (cout // 64)
+    code, rows = 8, 8
+    if per_row_tiles * (-(-Ho // 8)) < 768:
+        code, rows = 9, 4
+    blocks = per_row_tiles * (-(-Ho // rows))
+    return code, max(1, min(-(-768 // blocks), chunks // 6, 16))
 
 
 def choose_tiles(M: int, cout: int, steps: int):
@@ -200,7 +206,8 @@ class Plan:
         M = out.N * out.H * out.W
         if lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
             chunks = sum(ceil16(v.C) // 16 for v, _ in srcs)
-            tm, tn, split = 8, 0, choose_lds_split(out.N, out.H, out.W, conv.out_channels, chunks)
+            tm, split = choose_lds_tile(out.N, out.H, out.W, conv.out_channels, chunks)
+            tn = 0
         else:
             tm, tn, split = choose_tiles(M, conv.out_channels, steps)
         op.tile_m, op.tile_n, op.split_k = tm, tn, split

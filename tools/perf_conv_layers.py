@@ -29,18 +29,18 @@ for (cin, cout, H, W, ks, st) in LAYERS:
     x = torch.randn(B, H, W, cin, device="cuda")
     res = []
     nsub = cout // 16
-    for tm, tn in list(itertools.product((4, 2, 1), (4, 2))) + [(8, 0)]:
+    for tm, tn in list(itertools.product((4, 2, 1), (4, 2))) + [(8, 0), (9, 0)]:
         if tn and nsub % tn: continue
         for split in (1, 2, 4, 8):
-            if tm == 8:
-                waves = 4 * B * (-(-(H // st) // 8)) * (-(-(W // st) // 16)) * (cout // 64) * split
+            if tm >= 8:
+                waves = 4 * B * (-(-(H // st) // (8 if tm == 8 else 4))) * (-(-(W // st) // 16)) * (cout // 64) * split
                 if split > 1 and waves > 8192 * 2: continue
                 if split > cin // 16: continue
             else:
               pass
-            if tm == 8 and (cout % 64 or ks != 3 or st != 1): continue
+            if tm >= 8 and (cout % 64 or ks != 3 or st != 1): continue
             M = B * (H // st) * (W // st)
-            if tm != 8:
+            if tm < 8:
                 waves = -(-M // (16 * tm)) * (nsub // tn) * split
                 if split > 1 and waves > 8192: continue
                 if waves < 256: continue
