@@ -55,7 +55,6 @@ struct ConvArgs {
     int steps_total;
     int act;
     float slope;
-    int dbg;  // diagnostics only: 1 = no operand loads in the K loop, 2 = no MFMAs
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -181,27 +180,12 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
     f32x4 A0[TM], B0[TN], A1[TM], B1[TN];
     const int nsteps = t1 - t0;
     load(A0, B0);
-    if (a.dbg == 1) {
 #pragma unroll 1
-        for (int st = 0; st < nsteps; ++st) mma(A0, B0);
-    } else if (a.dbg == 2) {
-#pragma unroll 1
-        for (int st = 1; st < nsteps; ++st) {
-            load(A1, B1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) A0[i] += A1[i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) B0[j] += B1[j];
-        }
+    for (int st = 0; st < nsteps; st += 2) {
+        load(A1, B1);
         mma(A0, B0);
-    } else {
-#pragma unroll 1
-        for (int st = 0; st < nsteps; st += 2) {
-            load(A1, B1);
-            mma(A0, B0);
-            load(A0, B0);
-            mma(A1, B1);
-        }
+        load(A0, B0);
+        mma(A1, B1);
     }
 
     // ---- epilogue.  The MFMA was issued as D^T = W . X^T (weights as the A operand), so in the
@@ -266,7 +250,7 @@ struct LdsConvArgs {
 };
 
 template <int RW>
-__global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
+__device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned blk_in, unsigned nblk) {
     constexpr int kLT_H = 4 * RW, kHaloH = kLT_H + 2;
     constexpr int kASlots = kHaloH * 4 * kHaloW;  // 720 (RW=2) / 432 (RW=1) float4
     constexpr int kALoads = (kASlots + 255) / 256;
@@ -281,7 +265,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
 
     // block -> (split, image, tile_y, tile_x, channel tile); channel tile fastest so the blocks
     // sharing an input tile are neighbours (same XCD after the remap -> L2 hits on the halo)
-    unsigned blk = idh_xcd_remap(blockIdx.x, gridDim.x);
+    unsigned blk = idh_xcd_remap(blk_in, nblk);
     const int nt = blk % a.NT; blk /= a.NT;
     const int tx = blk % la.tiles_x; blk /= la.tiles_x;
     const int ty = blk % la.tiles_y; blk /= la.tiles_y;
@@ -451,6 +435,59 @@ __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
     }
 }
 
+template <int RW>
+__global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
+    conv3x3_lds_body<RW>(la, blockIdx.x, gridDim.x);
+}
+
+// Grouped launch: up to kMaxGroup INDEPENDENT convolutions (same dependency level of a plan, see
+// implicit-depth_amd/nhwc.py:Plan.schedule) share one grid, so the small low-resolution layers of
+// the UNet++ — each of which fills a fraction of the 256 CUs — run side by side.  Descriptors
+// travel by value in the kernel arguments (no device-side table to upload).
+constexpr int kMaxGroup = 12;
+struct LdsGroupArgs {
+    int n;
+    unsigned start[kMaxGroup + 1];
+    LdsConvArgs op[kMaxGroup];
+};
+
+template <int RW>
+__global__ __launch_bounds__(256) void conv3x3_lds_group_k(const LdsGroupArgs g) {
+    int idx = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (blockIdx.x >= g.start[i]) idx = i;
+    conv3x3_lds_body<RW>(g.op[idx], blockIdx.x - g.start[idx], g.start[idx + 1] - g.start[idx]);
+}
+
+struct ReduceDesc {
+    const float *ws, *bias, *res;
+    float *out;
+    int M, Cout, Cout_pad, S, res_cs, out_cs, act;
+    float slope;
+};
+struct ReduceGroupArgs {
+    int n;
+    unsigned start[kMaxGroup + 1];  // in units of 256-element blocks
+    ReduceDesc d[kMaxGroup];
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_group_k(const ReduceGroupArgs g) {
+    int idx = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (blockIdx.x >= g.start[i]) idx = i;
+    const ReduceDesc &d = g.d[idx];
+    const long long t = (long long)(blockIdx.x - g.start[idx]) * 256 + threadIdx.x;
+    const long long total = (long long)d.M * d.Cout;
+    if (t >= total) return;
+    const int co = (int)(t % d.Cout);
+    const long long m = t / d.Cout;
+    float v = 0.f;
+    for (int s = 0; s < d.S; ++s) v += d.ws[((size_t)s * d.M + m) * d.Cout_pad + co];
+    if (d.bias) v += d.bias[co];
+    if (d.res) v += d.res[m * d.res_cs + co];
+    d.out[m * d.out_cs + co] = act_apply(v, d.act, d.slope);
+}
+
 // split-K tail: out = act(sum_s ws[s] + bias + res)
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float *__restrict__ ws, const float *__restrict__ bias,
                                                        const float *__restrict__ res, float *__restrict__ out,
@@ -577,15 +614,19 @@ __global__ __launch_bounds__(256) void pointwise_head_k(const float *__restrict_
 
 inline int ceil16(int v) { return (v + 15) & ~15; }
 
-template <int TM, int TN>
-void launch_conv(const ConvArgs &a, hipStream_t st) {
-    const long long waves = (long long)a.MT * a.NT * a.S;
-    const unsigned grid = (unsigned)((waves + 3) / 4);
-    hipLaunchKernelGGL((conv_mfma_k<TM, TN>), dim3(grid), dim3(256), 0, st, a);
-}
+// A validated conv op, ready to launch: either the LDS-staged kernel (lds_rows = 8 / 4) or the
+// direct-fragment kernel (lds_rows = 0, tile tm x tn).
+struct PreparedConv {
+    ConvArgs a;
+    LdsConvArgs la;
+    int lds_rows, tm, tn;
+    unsigned blocks;
+    ReduceDesc red;  // valid when a.S > 1
+};
 
-int run_conv(const idh_op &op, hipStream_t st) {
-    ConvArgs a{};
+int prep_conv(const idh_op &op, PreparedConv &pc) {
+    ConvArgs &a = pc.a;
+    a = ConvArgs{};
     int steps = 0;
     for (int i = 0; i < 2; ++i) {
         const idh_conv_src &s = op.src[i];
@@ -615,50 +656,90 @@ int run_conv(const idh_op &op, hipStream_t st) {
     a.Cout_pad = ceil16(op.Cout);
     const long long M = (long long)op.N * op.Ho * op.Wo;
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
-    a.M = (int)M; a.steps_total = steps; a.act = op.act; a.slope = op.slope; a.dbg = op._pad;
+    a.M = (int)M; a.steps_total = steps; a.act = op.act; a.slope = op.slope;
     a.S = op.split_k > 1 ? op.split_k : 1;
     if (a.S > steps) a.S = steps;
-    if (a.S > 1 && !op.ws) return IDH_EWORKSPACE;
-    // LDS-staged kernel for the dominant shape family (tile_m == 8 requests it, tile_m == 0 = auto)
+    // LDS-staged kernel for the dominant shape family: tile_m 8 / 9 request the 8- / 4-row tile,
+    // 0 = auto (8-row)
     const bool lds_ok = a.s[0].ks == 3 && a.s[0].stride == 1 && a.s[0].pad_mode == IDH_PAD_ZEROS && (op.Cout % kLT_N) == 0 &&
                         (!a.s[1].in || (a.s[1].ks == 1 && a.s[1].stride == 1)) && op.Wo >= kLT_W;
+    pc.lds_rows = 0;
     if (lds_ok && (op.tile_m == 8 || op.tile_m == 0 || op.tile_m == 9)) {
         const int rows = op.tile_m == 9 ? 4 : 8;
-        LdsConvArgs la{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + rows - 1) / rows};
-        la.c.NT = op.Cout / kLT_N;
         const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
-        if (la.c.S > chunks) la.c.S = chunks;
-        const long long blocks = (long long)la.c.S * op.N * la.tiles_x * la.tiles_y * la.c.NT;
+        if (a.S > chunks) a.S = chunks;
+        a.NT = op.Cout / kLT_N;
+        pc.la = LdsConvArgs{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + rows - 1) / rows};
+        const long long blocks = (long long)a.S * op.N * pc.la.tiles_x * pc.la.tiles_y * a.NT;
         if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
-        if (rows == 8) hipLaunchKernelGGL(conv3x3_lds_k<2>, dim3((unsigned)blocks), dim3(256), 0, st, la);
-        else hipLaunchKernelGGL(conv3x3_lds_k<1>, dim3((unsigned)blocks), dim3(256), 0, st, la);
-        IDH_CHECK_LAUNCH();
-        a.S = la.c.S;
+        pc.blocks = (unsigned)blocks;
+        pc.lds_rows = rows;
     } else {
-    int tm = op.tile_m, tn = op.tile_n;
-    if (tm == 8 || tm == 9) tm = 0;
-    const int nsub = a.Cout_pad / 16;
-    if (tn == 0) tn = (nsub % 4 == 0) ? 4 : (nsub % 2 == 0 ? 2 : 1);
-    if (tm == 0) tm = 4;
-    if ((tm != 1 && tm != 2 && tm != 4) || (tn != 1 && tn != 2 && tn != 4) || nsub % tn) return IDH_EINVAL;
-    a.MT = (int)((M + 16 * tm - 1) / (16 * tm));
-    a.NT = nsub / tn;
-#define IDH_CASE(TM_, TN_) \
-    if (tm == TM_ && tn == TN_) launch_conv<TM_, TN_>(a, st);
-    IDH_CASE(4, 4) IDH_CASE(2, 4) IDH_CASE(1, 4) IDH_CASE(4, 2) IDH_CASE(2, 2) IDH_CASE(1, 2) IDH_CASE(4, 1)
-    IDH_CASE(2, 1) IDH_CASE(1, 1)
-#undef IDH_CASE
-    IDH_CHECK_LAUNCH();
+        int tm = op.tile_m, tn = op.tile_n;
+        if (tm == 8 || tm == 9) tm = 0;
+        const int nsub = a.Cout_pad / 16;
+        if (tn == 0) tn = (nsub % 4 == 0) ? 4 : (nsub % 2 == 0 ? 2 : 1);
+        if (tm == 0) tm = 4;
+        if ((tm != 1 && tm != 2 && tm != 4) || (tn != 1 && tn != 2 && tn != 4) || nsub % tn) return IDH_EINVAL;
+        a.MT = (int)((M + 16 * tm - 1) / (16 * tm));
+        a.NT = nsub / tn;
+        pc.tm = tm; pc.tn = tn;
+        const long long waves = (long long)a.MT * a.NT * a.S;
+        if ((waves + 3) / 4 >= (1ll << 31)) return IDH_EUNSUPPORTED;
+        pc.blocks = (unsigned)((waves + 3) / 4);
     }
     if (a.S > 1) {
-        const long long tot = M * op.Cout;
-        int grid = idh_cdiv(tot, 256);
-        if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(splitk_reduce_k, dim3(grid), dim3(256), 0, st, op.ws, op.bias, op.res, op.out, a.M, op.Cout,
-                           a.Cout_pad, a.S, op.res_cs, op.out_cs, op.act, op.slope);
-        IDH_CHECK_LAUNCH();
+        if (!op.ws) return IDH_EWORKSPACE;
+        pc.red = ReduceDesc{op.ws, op.bias, op.res, op.out, a.M, op.Cout, a.Cout_pad, a.S, op.res_cs, op.out_cs, op.act, op.slope};
     }
     return IDH_OK;
+}
+
+int launch_conv(const PreparedConv &pc, hipStream_t st) {
+    if (pc.lds_rows == 8) hipLaunchKernelGGL(conv3x3_lds_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4) hipLaunchKernelGGL(conv3x3_lds_k<1>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else {
+#define IDH_CASE(TM_, TN_) \
+    if (pc.tm == TM_ && pc.tn == TN_) hipLaunchKernelGGL((conv_mfma_k<TM_, TN_>), dim3(pc.blocks), dim3(256), 0, st, pc.a);
+        IDH_CASE(4, 4) IDH_CASE(2, 4) IDH_CASE(1, 4) IDH_CASE(4, 2) IDH_CASE(2, 2) IDH_CASE(1, 2) IDH_CASE(4, 1)
+        IDH_CASE(2, 1) IDH_CASE(1, 1)
+#undef IDH_CASE
+    }
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
+
+int launch_reduces(const PreparedConv *pcs, int n, hipStream_t st) {
+    ReduceGroupArgs g{};
+    unsigned cursor = 0;
+    for (int i = 0; i < n; ++i) {
+        if (pcs[i].a.S <= 1) continue;
+        g.start[g.n] = cursor;
+        g.d[g.n] = pcs[i].red;
+        cursor += (unsigned)idh_cdiv((long long)pcs[i].red.M * pcs[i].red.Cout, 256);
+        ++g.n;
+    }
+    if (g.n == 0) return IDH_OK;
+    g.start[g.n] = cursor;
+    hipLaunchKernelGGL(splitk_reduce_group_k, dim3(cursor), dim3(256), 0, st, g);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
+
+// Launch ops[i..j) — all convs of one dependency level that map to the 4-row LDS kernel — as one grid.
+int launch_group(const PreparedConv *pcs, int n, hipStream_t st) {
+    LdsGroupArgs g{};
+    unsigned cursor = 0;
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        g.start[i] = cursor;
+        g.op[i] = pcs[i].la;
+        cursor += pcs[i].blocks;
+    }
+    g.start[n] = cursor;
+    hipLaunchKernelGGL(conv3x3_lds_group_k<1>, dim3(cursor), dim3(256), 0, st, g);
+    IDH_CHECK_LAUNCH();
+    return launch_reduces(pcs, n, st);
 }
 
 }  // namespace
@@ -689,8 +770,29 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
         const idh_conv_src &s = op.src[0];
         switch (op.kind) {
             case IDH_OP_CONV: {
-                const int rc = run_conv(op, st);
+                // gather the run of consecutive convs that share a (non-zero) group id: the host
+                // scheduler guarantees they are mutually independent
+                PreparedConv pcs[kMaxGroup];
+                int cnt = 0;
+                int rc = prep_conv(op, pcs[0]);
                 if (rc != IDH_OK) return rc;
+                cnt = 1;
+                if (op.group != 0 && pcs[0].lds_rows == 4) {
+                    while (i + cnt < n && cnt < kMaxGroup && ops[i + cnt].kind == IDH_OP_CONV && ops[i + cnt].group == op.group) {
+                        rc = prep_conv(ops[i + cnt], pcs[cnt]);
+                        if (rc != IDH_OK) return rc;
+                        if (pcs[cnt].lds_rows != 4) break;
+                        ++cnt;
+                    }
+                }
+                if (cnt > 1) {
+                    rc = launch_group(pcs, cnt, st);
+                } else {
+                    rc = launch_conv(pcs[0], st);
+                    if (rc == IDH_OK) rc = launch_reduces(pcs, 1, st);
+                }
+                if (rc != IDH_OK) return rc;
+                i += cnt - 1;
                 break;
             }
             case IDH_OP_UPSAMPLE2: {

@@ -39,7 +39,7 @@ class Op(C.Structure):
     _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("src", ConvSrc * 2), ("bias", C.c_void_p), ("res", C.c_void_p),
                 ("out", C.c_void_p), ("ws", C.c_void_p), ("res_cs", C.c_int32), ("out_cs", C.c_int32), ("Ho", C.c_int32),
                 ("Wo", C.c_int32), ("Cout", C.c_int32), ("act", C.c_int32), ("slope", C.c_float), ("split_k", C.c_int32),
-                ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("_pad", C.c_int32)]
+                ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("group", C.c_int32)]
 
 
 def _bind():
@@ -84,6 +84,19 @@ class View:
 
 def ceil16(v: int) -> int:
     return (v + 15) & ~15
+
+
+def _region(v: "View", pad16: bool = False):
+    """(buffer id, first channel, one-past-last channel) touched through view ``v``."""
+    return (v.buf.data_ptr(), v.c0, v.c0 + (ceil16(v.C) if pad16 else v.C))
+
+
+def _overlap(ra, rb) -> bool:
+    for (ba, a0, a1) in ra:
+        for (bb, b0, b1) in rb:
+            if ba == bb and a0 < b1 and b0 < a1:
+                return True
+    return False
 
 
 def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
@@ -156,8 +169,10 @@ class Plan:
     def __init__(self, device):
         self.device = device
         self.ops: List[Op] = []
+        self.meta: List[dict] = []  # per op: regions read / written, for the level scheduler
         self.keep: List[torch.Tensor] = []  # buffers / packed weights referenced by raw pointer
         self._arr = None
+        self._pos: Optional[List[int]] = None  # op index at build time -> index after schedule()
         self.flops = 0  # 2*MAC of the conv ops (algorithmic, no padding)
 
     # buffers -------------------------------------------------------------------------
@@ -216,6 +231,8 @@ class Plan:
             self.keep.append(ws)
             op.ws = ws.data_ptr()
         self.ops.append(op)
+        reads = [_region(v, pad16=True) for v, _ in srcs] + ([_region(res)] if res is not None else [])
+        self.meta.append({"reads": reads, "writes": [_region(out)]})
         self._arr = None
         return out
 
@@ -226,6 +243,7 @@ class Plan:
         s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
         op.out, op.out_cs = out.ptr, out.cs
         self.ops.append(op)
+        self.meta.append({"reads": [_region(x)], "writes": [_region(out)]})
         self._arr = None
         return out
 
@@ -241,6 +259,7 @@ class Plan:
         s.H, s.W, s.Cin = H, W, Cc
         op.out, op.out_cs = out.ptr, out.cs
         self.ops.append(op)
+        self.meta.append({"reads": [], "writes": [_region(out)]})
         self._arr = None
         return len(self.ops) - 1
 
@@ -252,6 +271,7 @@ class Plan:
         if out_nchw is not None:
             op.out = out_nchw.data_ptr()
         self.ops.append(op)
+        self.meta.append({"reads": [_region(x)], "writes": []})
         self._arr = None
         return len(self.ops) - 1
 
@@ -268,6 +288,7 @@ class Plan:
         s.in_, s.w, s.cs, s.H, s.W, s.Cin = x.ptr, w.data_ptr(), x.cs, x.H, x.W, x.C
         op.bias, op.out = b.data_ptr(), out.data_ptr()
         self.ops.append(op)
+        self.meta.append({"reads": [_region(x)], "writes": []})
         self._arr = None
         return len(self.ops) - 1
 
@@ -287,11 +308,42 @@ class Plan:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, x2=x, conv2=blk.downsample[0])
         return out
 
+    # scheduling ----------------------------------------------------------------------
+    def schedule(self):
+        """Re-order the ops by dependency level (longest path from the inputs) and mark the
+        4-row-tile LDS convs of one level as a launch group: they are mutually independent, so
+        ``idh_run_ops`` runs them as ONE grid.  This is how the many small low-resolution convs
+        of the UNet++ grid (each filling only a fraction of 256 CUs) get to run side by side
+        — the reference executes them strictly one after another."""
+        n = len(self.ops)
+        level = [0] * n
+        for j in range(n):
+            mj = self.meta[j]
+            for i in range(j):
+                mi = self.meta[i]
+                if _overlap(mi["writes"], mj["reads"]) or _overlap(mi["writes"], mj["writes"]) or _overlap(mi["reads"], mj["writes"]):
+                    level[j] = max(level[j], level[i] + 1)
+        groupable = lambda k: self.ops[k].kind == OP_CONV and self.ops[k].tile_m == 9
+        order = sorted(range(n), key=lambda k: (level[k], 0 if groupable(k) else 1, k))
+        for k in range(n):
+            self.ops[k].group = level[k] + 1 if groupable(k) else 0
+        self.ops = [self.ops[k] for k in order]
+        self.meta = [self.meta[k] for k in order]
+        self.levels = [level[k] for k in order]
+        pos = [0] * n
+        for new, old in enumerate(order):
+            pos[old] = new
+        self._pos = pos if self._pos is None else [pos[p] for p in self._pos]
+        self._arr = None
+
     # execution -----------------------------------------------------------------------
     def _array(self):
         if self._arr is None:
             self._arr = (Op * len(self.ops))(*self.ops)
         return self._arr
+
+    def _idx(self, idx: int) -> int:
+        return idx if self._pos is None else self._pos[idx]
 
     def run(self):
         L = _bind()
@@ -299,10 +351,11 @@ class Plan:
         _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(self.ops), _lib.stream_ptr()), "idh_run_ops")
 
     def set_in(self, idx: int, t: torch.Tensor):
-        self._array()[idx].src[0].in_ = t.data_ptr()
+        """idx = op index returned at build time (stable across schedule())."""
+        self._array()[self._idx(idx)].src[0].in_ = t.data_ptr()
 
     def set_out(self, idx: int, t: torch.Tensor):
-        self._array()[idx].out = t.data_ptr()
+        self._array()[self._idx(idx)].out = t.data_ptr()
 
 
 def _plan_cache(module: nn.Module) -> Dict:
@@ -339,6 +392,7 @@ def block_forward_nchw(blk, x: torch.Tensor) -> torch.Tensor:
         i_in = p.import_nchw(x.shape, xin)
         y = p.basic_block(xin, blk)
         i_out = p.export_nchw(y)
+        p.schedule()
         ent = (p, i_in, i_out, y)
         cache[key] = ent
     p, i_in, i_out, y = ent
@@ -389,6 +443,7 @@ def cv_encoder_forward_nchw(enc, x: torch.Tensor, img_feats: List[torch.Tensor])
         i_x = p.import_nchw(x.shape, xin)
         outs, i_img = build_cv_encoder(p, enc, xin, [f.shape for f in img_feats])
         i_out = [p.export_nchw(o) for o in outs]
+        p.schedule()
         ent = (p, i_x, i_img, i_out, outs)
         cache[key] = ent
     p, i_x, i_img, i_out, outs = ent
@@ -457,6 +512,7 @@ def decoder_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dict[str, t
                 i_out[i] = p.head(v, dec.convs[f"output_{i}"][1], torch.empty(1, device=feats[0].device))
             else:
                 i_out[i] = p.export_nchw(v)
+        p.schedule()
         ent = (p, i_in, i_out, final)
         cache[key] = ent
     p, i_in, i_out, final = ent

@@ -63,6 +63,7 @@ class HotPath(nn.Module):
         if getattr(self.depth_decoder, "depth_head", False):
             for i, v in final.items():
                 ent["heads"][i] = p.head(v, self.depth_decoder.convs[f"output_{i}"][1], torch.empty(1, device=device))
+        p.schedule()
         self._plans[key] = ent
         return ent
 

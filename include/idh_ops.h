@@ -53,8 +53,10 @@ typedef struct idh_op {
     int32_t act;          /* IDH_ACT_* */
     float slope;
     int32_t split_k;      /* 1 = no split */
-    int32_t tile_m, tile_n; /* wave tile in 16-wide MFMA sub-tiles (1,2,4); 0 = auto */
-    int32_t _pad;
+    int32_t tile_m, tile_n; /* direct kernel: wave tile in 16-wide MFMA sub-tiles (1,2,4), 0 = auto;
+                               tile_m = 8 / 9 selects the LDS-staged kernel with 8- / 4-row tiles */
+    int32_t group;        /* != 0: consecutive conv ops with the same id are mutually independent and
+                               may be launched as ONE grid (see Plan.schedule in nhwc.py) */
 } idh_op;
 
 /* Repack OIHW conv weights (reference nn.Conv2d layout) for the MFMA B-fragment loads:

@@ -50,7 +50,6 @@ for (cin, cout, H, W, ks, st) in LAYERS:
             p.conv(xin, conv, out, act=1)
             op = p.ops[0]
             op.tile_m, op.tile_n, op.split_k = tm, tn, split
-            op._pad = int(os.environ.get('DBG', 0))
             if split > 1:
                 ws = torch.empty(split * M * cout, device="cuda"); p.keep.append(ws); op.ws = ws.data_ptr()
             p._arr = None
