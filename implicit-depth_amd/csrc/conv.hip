@@ -612,6 +612,65 @@ __global__ __launch_bounds__(256) void pointwise_head_k(const float *__restrict_
     }
 }
 
+// ---- InstanceNorm2d (no affine, eps 1e-5) on NHWC, optional LeakyReLU -------------------------
+// reference modules/networks.py:279-283 (matching-encoder head).  Deterministic two-stage
+// reduction: per-(image, pixel-chunk) channel sums -> per-thread combine in the apply kernel.
+constexpr int kInChunk = 1024;  // pixels per partial
+
+__global__ __launch_bounds__(256) void instnorm_stats_k(const float *__restrict__ in, int cs, int C, int HW, int nchunks,
+                                                        float *__restrict__ part) {  // part[n][chunk][2][C]
+    extern __shared__ float red[];  // 256 * 8 floats
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int cq = C >> 2;                 // channel quads
+    const int q = threadIdx.x % cq;
+    const int prow = threadIdx.x / cq, pstep = 256 / cq;  // host guarantees cq divides 256
+    const int p0 = chunk * kInChunk, p1 = min(HW, p0 + kInChunk);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + prow; p < p1; p += pstep) {
+        const float4 v = *reinterpret_cast<const float4 *>(in + ((size_t)n * HW + p) * cs + 4 * q);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        ss[0] = fmaf(v.x, v.x, ss[0]); ss[1] = fmaf(v.y, v.y, ss[1]); ss[2] = fmaf(v.z, v.z, ss[2]); ss[3] = fmaf(v.w, v.w, ss[3]);
+    }
+    float *mine = red + threadIdx.x * 8;
+    for (int e = 0; e < 4; ++e) { mine[e] = s[e]; mine[4 + e] = ss[e]; }
+    __syncthreads();
+    if (threadIdx.x < cq) {  // fixed-order combine over the pstep rows: deterministic
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < pstep; ++r)
+            for (int e = 0; e < 8; ++e) a[e] += red[(r * cq + threadIdx.x) * 8 + e];
+        float *o = part + ((size_t)(n * nchunks + chunk) * 2) * C + 4 * threadIdx.x;
+        for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[C + e] = a[4 + e]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void instnorm_apply_k(const float *__restrict__ in, int cs, float *__restrict__ out, int out_cs,
+                                                        int C, int HW, int nchunks, const float *__restrict__ part, int act,
+                                                        float slope) {
+    const int n = blockIdx.y;
+    const int cq = C >> 2;
+    const long long total = (long long)HW * cq;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
+        const int q = (int)(t % cq);
+        const long long p = t / cq;
+        float mean[4], rstd[4];
+        for (int e = 0; e < 4; ++e) {
+            float s = 0.f, ss = 0.f;
+            for (int c = 0; c < nchunks; ++c) {
+                const float *o = part + ((size_t)(n * nchunks + c) * 2) * C + 4 * q + e;
+                s += o[0];
+                ss += o[C];
+            }
+            mean[e] = s / (float)HW;
+            const float var = fmaxf(ss / (float)HW - mean[e] * mean[e], 0.f);  // biased, as nn.InstanceNorm2d
+            rstd[e] = 1.0f / sqrtf(var + 1e-5f);
+        }
+        const float4 v = *reinterpret_cast<const float4 *>(in + ((size_t)n * HW + p) * cs + 4 * q);
+        float r[4] = {(v.x - mean[0]) * rstd[0], (v.y - mean[1]) * rstd[1], (v.z - mean[2]) * rstd[2], (v.w - mean[3]) * rstd[3]};
+        for (int e = 0; e < 4; ++e) r[e] = act_apply(r[e], act, slope);
+        *reinterpret_cast<float4 *>(out + ((size_t)n * HW + p) * out_cs + 4 * q) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 inline int ceil16(int v) { return (v + 15) & ~15; }
 
 // A validated conv op, ready to launch: either the LDS-staged kernel (lds_rows = 8 / 4) or the
@@ -828,6 +887,22 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 if (grid > 8192) grid = 8192;
                 hipLaunchKernelGGL(pointwise_head_k, dim3(grid), dim3(256), 0, st, s.in, s.w, op.bias, op.out, M, s.Cin,
                                    s.cs);
+                IDH_CHECK_LAUNCH();
+                break;
+            }
+            case IDH_OP_INSTNORM: {
+                const int C = s.Cin, HW = s.H * s.W;
+                if (!s.in || !op.out || !op.ws || C <= 0 || (C & 3) || 256 % (C >> 2) || (s.cs & 3) || (op.out_cs & 3) ||
+                    op.N <= 0 || op.N > 65535)
+                    return IDH_EINVAL;
+                const int nchunks = idh_cdiv(HW, kInChunk);
+                hipLaunchKernelGGL(instnorm_stats_k, dim3(nchunks, op.N), dim3(256), 256 * 8 * sizeof(float), st, s.in, s.cs, C, HW,
+                                   nchunks, op.ws);
+                IDH_CHECK_LAUNCH();
+                int gx = idh_cdiv((long long)HW * (C >> 2), 256);
+                if (gx > 2048) gx = 2048;
+                hipLaunchKernelGGL(instnorm_apply_k, dim3(gx, op.N), dim3(256), 0, st, s.in, s.cs, op.out, op.out_cs, C, HW, nchunks,
+                                   op.ws, op.act, op.slope);
                 IDH_CHECK_LAUNCH();
                 break;
             }

@@ -130,3 +130,40 @@ class BinaryMLPNetwork(nn.Module):
         from .nhwc import binary_mlp_forward
 
         return binary_mlp_forward(self, inputs, max_scale_only)
+
+
+class ResnetMatchingEncoder(nn.Module):
+    """Matching encoder (reference modules/networks.py:236-287).
+
+    ``net[0:5]`` — conv1/bn1/relu/maxpool/layer1 of antialiased_cnns.resnet18 — is third-party
+    code that is not part of the reference tree: the caller passes those five
+    modules in (or any stand-in with 64 output channels at 1/4 resolution) and they run as
+    ordinary torch modules.  The head ``net[5:10]`` (1x1 conv 64->128, InstanceNorm, LeakyReLU(0.2),
+    3x3 replicate-padded conv 128->C, InstanceNorm) runs on the gfx950 kernels and can hand its
+    output over channels-last, which is the layout the cost-volume kernels consume.
+    State-dict keys are the reference's (``net.5.weight`` … ``net.8.bias``)."""
+
+    def __init__(self, backbone_modules, num_ch_out: int = 16, backbone_channels: int = 64):
+        super().__init__()
+        backbone_modules = list(backbone_modules)
+        if len(backbone_modules) != 5:
+            raise ValueError("expected the 5 backbone modules conv1, bn1, relu, maxpool, layer1")
+        self.num_ch_out = num_ch_out
+        self.net = nn.Sequential(
+            *backbone_modules,
+            nn.Conv2d(backbone_channels, 128, (1, 1)),
+            nn.InstanceNorm2d(128),
+            nn.LeakyReLU(0.2, True),
+            nn.Conv2d(128, num_ch_out, (3, 3), padding=1, padding_mode="replicate"),
+            nn.InstanceNorm2d(num_ch_out),
+        )
+
+    def backbone(self, x):
+        for i in range(5):
+            x = self.net[i](x)
+        return x
+
+    def forward(self, input_image, channels_last: bool = False):
+        from .nhwc import matching_head_forward
+
+        return matching_head_forward(self, self.backbone(input_image), channels_last)

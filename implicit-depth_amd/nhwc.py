@@ -25,7 +25,7 @@ from torch import nn
 from . import _lib
 
 # --- ctypes mirrors of include/idh_ops.h -------------------------------------------------
-OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD = 1, 2, 3, 4, 5, 6
+OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD, OP_INSTNORM = 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_LRELU = 0, 1
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 
@@ -242,6 +242,23 @@ class Plan:
         s = op.src[0]
         s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
         op.out, op.out_cs = out.ptr, out.cs
+        self.ops.append(op)
+        self.meta.append({"reads": [_region(x)], "writes": [_region(out)]})
+        self._arr = None
+        return out
+
+    def instance_norm(self, x: View, out: View, act=ACT_NONE, slope=0.2):
+        """nn.InstanceNorm2d(C) (no affine, eps 1e-5) optionally followed by LeakyReLU."""
+        if x.C % 4 or 256 % (x.C // 4):
+            raise _lib.IdhError(f"instance-norm kernel needs C/4 to divide 256 (C={x.C})")
+        op = Op()
+        op.kind, op.N = OP_INSTNORM, x.N
+        s = op.src[0]
+        s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
+        op.out, op.out_cs, op.act, op.slope = out.ptr, out.cs, act, slope
+        ws = torch.empty(x.N * (-(-(x.H * x.W) // 1024)) * 2 * x.C, device=self.device, dtype=torch.float32)
+        self.keep.append(ws)
+        op.ws = ws.data_ptr()
         self.ops.append(op)
         self.meta.append({"reads": [_region(x)], "writes": [_region(out)]})
         self._arr = None
@@ -532,3 +549,45 @@ def binary_mlp_forward(net, inputs, max_scale_only):
     from .mlp import binary_mlp_forward as f
 
     return f(net, inputs, max_scale_only)
+
+
+# --- matching-encoder head (reference networks.py:279-283) ---------------------------------
+def build_matching_head(p: Plan, enc, x: View) -> View:
+    c1, c2 = enc.net[5], enc.net[8]
+    h = p.buffer(x.N, x.H, x.W, c1.out_channels)
+    p.conv(x, c1, h)
+    hn = p.buffer(x.N, x.H, x.W, c1.out_channels)
+    p.instance_norm(h, hn, act=ACT_LRELU, slope=0.2)
+    y = p.buffer(x.N, x.H, x.W, c2.out_channels)
+    p.conv(hn, c2, y, pad_mode=PAD_REPLICATE)
+    out = p.buffer(x.N, x.H, x.W, c2.out_channels)
+    p.instance_norm(y, out)
+    return out
+
+
+def matching_head_forward(enc, feat_nchw: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
+    _check_in(feat_nchw)
+    x = feat_nchw.contiguous()
+    key = ("mh", tuple(x.shape), str(x.device), channels_last, _param_key(enc.net[5]) + _param_key(enc.net[8]))
+    cache = _plan_cache(enc)
+    ent = cache.get(key)
+    if ent is None:
+        cache.clear()
+        p = Plan(x.device)
+        N, Cc, H, W = x.shape
+        xin = p.buffer(N, H, W, Cc)
+        i_in = p.import_nchw(x.shape, xin)
+        y = build_matching_head(p, enc, xin)
+        i_out = None if channels_last else p.export_nchw(y)
+        p.schedule()
+        ent = (p, i_in, i_out, y)
+        cache[key] = ent
+    p, i_in, i_out, y = ent
+    p.set_in(i_in, x)
+    if channels_last:
+        p.run()
+        return y.dense().clone()
+    out = torch.empty(y.N, y.C, y.H, y.W, device=x.device, dtype=torch.float32)
+    p.set_out(i_out, out)
+    p.run()
+    return out

@@ -218,6 +218,7 @@ def main():
     pr = Project3D()(pts, syn.intrinsics(8, 6).float()[None], torch.linalg.inv(poses[2])[None])
     save("g6_geometry", planes64=planes64, planes96=planes96, pose_dist=pd, backproject=pts, project=pr)
     gen_bdmodel(syn)
+    gen_matching_head(syn)
 
 
 def gen_bdmodel(syn):
@@ -265,6 +266,17 @@ def gen_bdmodel(syn):
         save(name, K=np.array(K), pred_0=out["pred_0"], lowest_cost=out["lowest_cost_bhw"], matching_cur=captured["mc"],
              matching_src=captured["ms"], **{f"enc{i}": e for i, e in enumerate(captured["enc"])}, **extra,
              keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))))
+
+
+def gen_matching_head(syn):
+    """G7: head of the reference ResnetMatchingEncoder (networks.py:279-283) on a given 64-channel map."""
+    print("G7 matching-encoder head")
+    from modules.networks import ResnetMatchingEncoder
+    enc = ResnetMatchingEncoder(18, 16)
+    syn.fill_state_dict(enc, seed=40, gain=1.0)
+    x = syn.randn((3, 64, 24, 32), 41, "mh_x")
+    y = enc.net[5:](x)
+    save("g7_matching_head", y=y, keys=np.array(sorted(k for k in enc.state_dict() if k.split(".")[1] in ("5", "8"))))
 
 
 if __name__ == "__main__":

@@ -118,3 +118,26 @@ def test_cvencoder_decoder_batched_vs_oracle():
     out = dec([pyr[0].cuda()] + outs)
     for i in range(4):
         assert rel_err(out[f"feature_s{i}_b1hw"].cpu(), ref_d[f"feature_s{i}_b1hw"]) < TOL
+
+
+def test_matching_head_golden_and_layouts():
+    """1x1 conv + InstanceNorm + LeakyReLU + replicate-padded 3x3 conv + InstanceNorm
+    (reference networks.py:279-283); NCHW and channels-last hand-over."""
+    from implicit_depth_amd import networks as net
+
+    g = load_golden("g7_matching_head")
+    stem = syn.StubResnetStem()
+    enc = net.ResnetMatchingEncoder([stem.conv1, stem.bn1, stem.relu, stem.maxpool, stem.layer1], 16)
+    syn.fill_state_dict(enc, seed=40)
+    enc.cuda()
+    x = syn.randn((3, 64, 24, 32), 41, "mh_x").cuda()
+    from implicit_depth_amd.nhwc import matching_head_forward
+
+    y = matching_head_forward(enc, x)
+    assert rel_err(y.cpu(), g["y"]) < TOL
+    y_cl = matching_head_forward(enc, x, channels_last=True)
+    assert torch.equal(y_cl.permute(0, 3, 1, 2).contiguous(), y)
+    # whole module incl. the (stand-in) backbone run by torch
+    img = syn.randn((2, 3, 48, 64), 42, "img").cuda()
+    ref = onet.matching_head(enc.backbone(img).cpu().double(), {k: v.cpu().double() for k, v in enc.state_dict().items()})
+    assert rel_err(enc(img).cpu(), ref) < TOL

@@ -184,3 +184,18 @@ def test_geometry_unit_vectors():
     X, u, v, z = ocv.project_plane(rays, torch.tensor(1.7), P)
     assert rel_err(X, g["backproject"][:, :3]) < 1e-6
     assert rel_err(torch.stack([u[0, 0], v[0, 0], z[0, 0]]), g["project"][0]) < 1e-5
+
+
+def test_matching_head_matches_reference():
+    from implicit_depth_amd import networks as net
+
+    g = load_golden("g7_matching_head")
+    enc = net.ResnetMatchingEncoder([torch.nn.Identity()] * 5, 16)
+    # same parameter names as the reference => same seeded tensors
+    stem = syn.StubResnetStem()
+    enc = net.ResnetMatchingEncoder([stem.conv1, stem.bn1, stem.relu, stem.maxpool, stem.layer1], 16)
+    syn.fill_state_dict(enc, seed=40)
+    w = dict(enc.state_dict())
+    assert sorted(k for k in w if k.split(".")[1] in ("5", "8")) == list(g["keys"])
+    x = syn.randn((3, 64, 24, 32), 41, "mh_x")
+    assert rel_err(onet.matching_head(x, w), g["y"]) < 2e-5
