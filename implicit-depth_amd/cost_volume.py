@@ -89,10 +89,13 @@ class CostVolumeManager(nn.Module):
         L = _lib.lib()
         planes_d = torch.empty(D, device=dev, dtype=torch.float32)
         dmin, dmax = float(min_depth), float(max_depth)
+        # keep the contiguous copies alive until the launch is enqueued (a temporary's block may be
+        # recycled by the next .contiguous() before the kernel runs)
+        Ks_c, E_c, iK_c = src_Ks.contiguous(), src_extrinsics.contiguous(), cur_invK.contiguous()
         _lib.check(
             L.idh_cost_volume_dot_fwd(
-                _lib.ptr(cur_n), _lib.ptr(src_n), _lib.ptr(src_Ks.contiguous()), _lib.ptr(src_extrinsics.contiguous()),
-                _lib.ptr(cur_invK.contiguous()), dmin, dmax, B, K, C, H, W, D, _lib.ptr(cost), 0, _lib.ptr(lowest),
+                _lib.ptr(cur_n), _lib.ptr(src_n), _lib.ptr(Ks_c), _lib.ptr(E_c),
+                _lib.ptr(iK_c), dmin, dmax, B, K, C, H, W, D, _lib.ptr(cost), 0, _lib.ptr(lowest),
                 _lib.ptr(planes_d), _lib.stream_ptr()),
             "idh_cost_volume_dot_fwd",
         )
@@ -212,9 +215,10 @@ class FeatureVolumeManager(CostVolumeManager):
         mask = torch.empty(B, H, W, device=dev, dtype=torch.uint8) if want_mask else None
         wsb = L.idh_feature_volume_workspace_bytes(B)
         ws = torch.empty(max(wsb // 4, 1), device=dev)
+        Ks_c, E_c, P_c, iK_c = src_Ks.contiguous(), src_extrinsics.contiguous(), src_poses.contiguous(), cur_invK.contiguous()
         _lib.check(
-            L.idh_feature_volume_fwd(cur_n.data_ptr(), src_n.data_ptr(), src_Ks.contiguous().data_ptr(), src_extrinsics.contiguous().data_ptr(),
-                                     src_poses.contiguous().data_ptr(), cur_invK.contiguous().data_ptr(), dmin, dmax, B, K, C, H, W, D,
+            L.idh_feature_volume_fwd(cur_n.data_ptr(), src_n.data_ptr(), Ks_c.data_ptr(), E_c.data_ptr(),
+                                     P_c.data_ptr(), iK_c.data_ptr(), dmin, dmax, B, K, C, H, W, D,
                                      pk["w1v"].data_ptr(), pk["w1p"].data_ptr(), pk["pose"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(),
                                      pk["vecs"].data_ptr(), vol.data_ptr() if torch.is_tensor(vol) else vol, vol_cs, lowest.data_ptr(),
                                      _lib.ptr(mask), planes.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()),

@@ -181,7 +181,81 @@ __global__ __launch_bounds__(256) void pack_mlp_weight_k(const float *__restrict
     }
 }
 
+// ---- temporal prior: warp the previous frame's occlusion prediction into the current view ----
+// reference experiment_modules/bd_model.py:395-410 (BackprojectDepth -> Project3D ->
+// grid_sample(mode="nearest", zeros, align_corners=False) -> invalid := -1)
+__global__ __launch_bounds__(256) void sample_prior_k(const float *__restrict__ depth, const float *__restrict__ prior,
+                                                      int Q, const float *__restrict__ cur_world_T_cam,
+                                                      const float *__restrict__ prior_cam_T_world,
+                                                      const float *__restrict__ Kmat, const float *__restrict__ invK, int P,
+                                                      int H, int W, float *__restrict__ out) {
+    __shared__ float sP[12], sI[9];
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        const float *A = prior_cam_T_world + (size_t)b * 16, *Bm = cur_world_T_cam + (size_t)b * 16, *Kb = Kmat + (size_t)b * 16;
+        float T[4][4], Pm[3][4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+                for (int m = 0; m < 4; ++m) s = fmaf(A[i * 4 + m], Bm[m * 4 + j], s);
+                T[i][j] = s;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+                for (int m = 0; m < 4; ++m) s = fmaf(Kb[i * 4 + m], T[m][j], s);
+                Pm[i][j] = s;
+            }
+        for (int i = 0; i < 12; ++i) sP[i] = Pm[i / 4][i % 4];
+        for (int i = 0; i < 9; ++i) sI[i] = invK[(size_t)b * 16 + (i / 3) * 4 + (i % 3)];
+    }
+    __syncthreads();
+    const int N = H * W;
+    const float Wf = (float)W, Hf = (float)H;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < P * N; t += gridDim.x * 256) {
+        const int p = t / N, pix = t - p * N;
+        const int y = pix / W, x = pix - y * W;
+        const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
+        const float d = depth[((size_t)b * P + p) * N + pix];
+        const float X0 = d * fmaf(sI[0], pxf, fmaf(sI[1], pyf, sI[2]));
+        const float X1 = d * fmaf(sI[3], pxf, fmaf(sI[4], pyf, sI[5]));
+        const float X2 = d * fmaf(sI[6], pxf, fmaf(sI[7], pyf, sI[8]));
+        const float cx = fmaf(sP[0], X0, fmaf(sP[1], X1, fmaf(sP[2], X2, sP[3])));
+        const float cy = fmaf(sP[4], X0, fmaf(sP[5], X1, fmaf(sP[6], X2, sP[7])));
+        const float cz = fmaf(sP[8], X0, fmaf(sP[9], X1, fmaf(sP[10], X2, sP[11])));
+        const float z = fmaxf(cz, 1e-5f);
+        const float u = cx / z, v = cy / z;
+        // normalise exactly as the reference does, then grid_sample's un-normalisation + nearbyint
+        const float gx = (u / Wf - 0.5f) * 2.f, gy = (v / Hf - 0.5f) * 2.f;
+        const float sx = ((gx + 1.f) * Wf - 1.f) * 0.5f, sy = ((gy + 1.f) * Hf - 1.f) * 0.5f;
+        const float xr = rintf(sx), yr = rintf(sy);  // round-half-even, like std::nearbyint
+        float val = 0.f;
+        if (xr >= 0.f && xr <= Wf - 1.f && yr >= 0.f && yr <= Hf - 1.f) {
+            const int q = p < Q ? p : Q - 1;
+            val = prior[((size_t)b * Q + q) * N + (int)yr * W + (int)xr];
+        }
+        // (cam z > 0) is always true after the clamp — same quirk as the cost-volume mask
+        out[((size_t)b * P + p) * N + pix] = (d > 0.f && z > 0.f) ? val : -1.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int idh_sample_prior_fwd(const float *rendered_depth_bphw, const float *prior_pred_bqhw, int Q,
+                                    const float *cur_world_T_cam_44, const float *prior_cam_T_world_44, const float *K_44,
+                                    const float *invK_44, int B, int P, int H, int W, float *out_bphw, void *stream) {
+    if (B < 0 || P <= 0 || Q <= 0 || H <= 0 || W <= 0) return IDH_EINVAL;
+    if (B == 0) return IDH_OK;
+    if (!rendered_depth_bphw || !prior_pred_bqhw || !cur_world_T_cam_44 || !prior_cam_T_world_44 || !K_44 || !invK_44 || !out_bphw ||
+        B > 65535)
+        return IDH_EINVAL;
+    int gx = idh_cdiv((long long)P * H * W, 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(sample_prior_k, dim3(gx, B), dim3(256), 0, idh_stream(stream), rendered_depth_bphw, prior_pred_bqhw, Q,
+                       cur_world_T_cam_44, prior_cam_T_world_44, K_44, invK_44, P, H, W, out_bphw);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
 
 extern "C" size_t idh_packed_mlp_weight_floats(int n_in) {
     return n_in <= 0 ? 0 : (size_t)((n_in + 15) / 16) * kNS * 64 * 4;

@@ -75,6 +75,25 @@ def occlusion_logits(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, de
     return out
 
 
+def sample_prior(rendered_depth: torch.Tensor, prior_prediction: torch.Tensor, cur_world_T_cam: torch.Tensor,
+                 prior_cam_T_world: torch.Tensor, K: torch.Tensor, invK: torch.Tensor) -> torch.Tensor:
+    """BDModel.sample_prior (reference bd_model.py:395-410) on the GPU kernel; returns the prior
+    channel (B,P,H,W) with -1 where invalid."""
+    _lib.require_cuda_f32(rendered_depth, prior_prediction, cur_world_T_cam, prior_cam_T_world, K, invK)
+    B, P, H, W = rendered_depth.shape
+    if prior_prediction.shape[0] != B or tuple(prior_prediction.shape[2:]) != (H, W):
+        raise _lib.IdhError(f"prior prediction {tuple(prior_prediction.shape)} does not match rendered depth {tuple(rendered_depth.shape)}")
+    out = torch.empty(B, P, H, W, device=rendered_depth.device, dtype=torch.float32)
+    # hold the contiguous copies in locals until the launch is enqueued
+    rd, pp, cw, pc, Kc, iKc = (t.contiguous() for t in (rendered_depth, prior_prediction, cur_world_T_cam, prior_cam_T_world, K, invK))
+    _lib.check(
+        _lib.lib().idh_sample_prior_fwd(rd.data_ptr(), pp.data_ptr(), prior_prediction.shape[1],
+                                        cw.data_ptr(), pc.data_ptr(), Kc.data_ptr(),
+                                        iKc.data_ptr(), B, P, H, W, out.data_ptr(), _lib.stream_ptr()),
+        "idh_sample_prior_fwd")
+    return out
+
+
 def binary_mlp_forward(net, inputs: List[torch.Tensor], max_scale_only: bool = False) -> Dict[str, torch.Tensor]:
     scales = [0] if max_scale_only else list(net.scales)
     outs = {}

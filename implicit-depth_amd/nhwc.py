@@ -114,7 +114,8 @@ def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
         raise _lib.IdhError(f"conv kernel {kh}x{kw} not covered by the gfx950 conv kernel (1x1 / 3x3 only)")
     n = L.idh_packed_weight_floats(co, ci, kh)
     dst = torch.empty(n, device=w.device, dtype=torch.float32)
-    _lib.check(L.idh_pack_conv_weight(w.detach().contiguous().data_ptr(), dst.data_ptr(), co, ci, kh, _lib.stream_ptr()), "idh_pack_conv_weight")
+    wc = w.detach().contiguous()
+    _lib.check(L.idh_pack_conv_weight(wc.data_ptr(), dst.data_ptr(), co, ci, kh, _lib.stream_ptr()), "idh_pack_conv_weight")
     conv._idh_packed = (key, dst)
     return dst
 

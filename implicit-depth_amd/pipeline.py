@@ -95,8 +95,9 @@ class HotPath(nn.Module):
             mc, ms = matching_cur_feats.contiguous(), matching_src_feats.contiguous()
             _lib.check(L.idh_nchw_to_nhwc_f32(mc.data_ptr(), st["cur_n"].data_ptr(), B, C, H * W, sp), "idh_nchw_to_nhwc_f32")
             _lib.check(L.idh_nchw_to_nhwc_f32(ms.data_ptr(), st["src_n"].data_ptr(), B * K, C, H * W, sp), "idh_nchw_to_nhwc_f32")
-            _lib.check(L.idh_cost_volume_dot_fwd(st["cur_n"].data_ptr(), st["src_n"].data_ptr(), src_K.contiguous().data_ptr(),
-                                                 src_cam_T_cur_cam.contiguous().data_ptr(), cur_invK.contiguous().data_ptr(),
+            Ks_c, E_c, iK_c = src_K.contiguous(), src_cam_T_cur_cam.contiguous(), cur_invK.contiguous()  # alive until enqueued
+            _lib.check(L.idh_cost_volume_dot_fwd(st["cur_n"].data_ptr(), st["src_n"].data_ptr(), Ks_c.data_ptr(),
+                                                 E_c.data_ptr(), iK_c.data_ptr(),
                                                  self.min_depth, self.max_depth, B, K, C, H, W, D, ent["cv_in"].ptr, ent["cv_in"].cs,
                                                  lowest.data_ptr(), st["planes"].data_ptr(), sp), "idh_cost_volume_dot_fwd")
         else:

@@ -114,6 +114,18 @@ int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float 
                        const float *w1f_packed, const float *w2_packed, const float *vecs6x128, int B,
                        int P, int HW, float *out_bphw, void *stream);
 
+/* ---- temporal prior ------------------------------------------------------------------ */
+/* Replaces BDModel.sample_prior (reference experiment_modules/bd_model.py:395-410): back-project
+ * the rendered depth, project into the previous frame's camera, nearest-neighbour sample the
+ * previous prediction (zeros outside), -1 where the rendered depth is not positive.
+ *   rendered_depth_bphw (B,P,H,W); prior_pred_bqhw (B,Q,H,W) (plane p samples channel min(p,Q-1))
+ *   cur_world_T_cam_44, prior_cam_T_world_44, K_44, invK_44: (B,4,4) at the prediction resolution
+ */
+int idh_sample_prior_fwd(const float *rendered_depth_bphw, const float *prior_pred_bqhw, int Q,
+                         const float *cur_world_T_cam_44, const float *prior_cam_T_world_44,
+                         const float *K_44, const float *invK_44, int B, int P, int H, int W,
+                         float *out_bphw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

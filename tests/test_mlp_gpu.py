@@ -79,3 +79,24 @@ def test_all_scales_interface():
         h = onet.elu(h @ seq[2].weight.cpu().double().t() + seq[2].bias.cpu().double())
         ref = h @ seq[4].weight.cpu().double().t() + seq[4].bias.cpu().double()
         assert rel_err(out[f"pred_{s}"].cpu(), ref) < TOL
+
+
+def test_sample_prior_golden_and_oracle():
+    from implicit_depth_amd.mlp import sample_prior
+
+    g = load_golden("g4_sample_prior")
+    Hq, Wq = [int(v) for v in g["dims"]]
+    rd = syn.rendered_depth_planes(1, Hq, Wq, 3)
+    rd[:, 1, :5, :7] = 0.0
+    prior = torch.sigmoid(syn.randn((1, 1, Hq, Wq), 14, "prior"))
+    Ks0 = syn.intrinsics(Wq, Hq).float()[None]
+    cur_pose, prev_pose = syn.source_pose(0).float()[None], syn.source_pose(1).float()[None]
+    args = (cur_pose, torch.linalg.inv(prev_pose), Ks0, torch.linalg.inv(Ks0))
+    sp = sample_prior(rd[:, 1:2].cuda(), prior.cuda(), *[a.cuda() for a in args]).cpu()
+    assert ((sp - torch.as_tensor(g["sampled"])).abs() > 1e-6).float().mean().item() < 2e-3
+    # all planes at once == plane by plane through the oracle
+    allp = sample_prior(rd.cuda(), prior.cuda(), *[a.cuda() for a in args]).cpu()
+    for p in range(3):
+        ref = onet.sample_prior(rd[:, p : p + 1], prior, *args)
+        assert ((allp[:, p : p + 1] - ref).abs() > 1e-6).float().mean().item() < 2e-3
+    assert (allp[:, 1, :5, :7] == -1).all()
