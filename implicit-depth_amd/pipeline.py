@@ -71,7 +71,12 @@ class HotPath(nn.Module):
     def forward(self, matching_cur_feats: torch.Tensor, matching_src_feats: torch.Tensor, cur_feats: List[torch.Tensor],
                 src_cam_T_cur_cam: torch.Tensor, cur_cam_T_src_cam: torch.Tensor, src_K: torch.Tensor, cur_invK: torch.Tensor,
                 rendered_depth: Optional[torch.Tensor] = None, prior: Optional[torch.Tensor] = None,
-                return_mask: bool = False, return_features: bool = False) -> Dict[str, torch.Tensor]:
+                return_mask: bool = False, return_features: bool = False,
+                prior_inputs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """``prior``: an already-warped prior channel (B,P,H/2,W/2), or ``prior_inputs`` = the
+        reference's temporal inputs {"prior_prediction", "prior_cam_T_world", "world_T_cam_b44",
+        "K_s0_b44", "invK_s0_b44"} (bd_model.py:420-431) to warp it here; with neither, a
+        prior-enabled MLP sees the constant -1 (bd_model.py:433-434)."""
         _lib.require_cuda_f32(matching_cur_feats, matching_src_feats, src_cam_T_cur_cam, src_K, cur_invK, rendered_depth, prior, *cur_feats)
         B, K, C, H, W = matching_src_feats.shape
         dev = matching_cur_feats.device
@@ -121,6 +126,12 @@ class HotPath(nn.Module):
 
         # 3. occlusion MLP over every query plane (BDModel only)
         if self.binary_mlp is not None and rendered_depth is not None:
+            if prior is None and prior_inputs is not None and prior_inputs.get("prior_prediction") is not None:
+                from .mlp import sample_prior
+
+                prior = sample_prior(rendered_depth, prior_inputs["prior_prediction"], prior_inputs["world_T_cam_b44"],
+                                     prior_inputs["prior_cam_T_world"], prior_inputs["K_s0_b44"], prior_inputs["invK_s0_b44"])
+                out["prior_mask"] = prior
             f0 = final[0]
             out["pred_0"] = occlusion_logits(self.binary_mlp, f0.buf, f0.c0, f0.C, rendered_depth, prior)
         if return_features:

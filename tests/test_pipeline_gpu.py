@@ -90,3 +90,50 @@ def test_prior_channel_path():
     out = model(d["cur_feats"], d["src_feats"], [t.cuda() for t in pyr], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
                 rendered_depth=rd.cuda(), prior=prior.cuda())
     assert rel_err(out["pred_0"].cpu(), logits) < TOL
+
+
+def test_temporal_sequence_with_prior_d96():
+    """BASELINE config 5 in miniature: 8-frame tuple (K=7), MLP feature volume with 96 planes,
+    prior-enabled occlusion MLP, prediction of frame t warped into frame t+1 (inference.py:139-157)."""
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd.cost_volume import FeatureVolumeManager
+    from implicit_depth_amd.pipeline import HotPath
+
+    B, K, H, W, D = 1, 7, 16, 24, 96
+    cv = FeatureVolumeManager(H, W, D, num_source_views=K)
+    cve = net.CVEncoder(D, [48, 64, 160, 256], [64, 128, 256, 384])
+    dec = net.BDDecoderPP([24, 64, 128, 256, 384])
+    mlp = net.BinaryMLPNetwork(dec.num_ch_dec, use_prior=True)
+    syn.fill_state_dict(cv.mlp, 70, gain=1.4)
+    for i, m in enumerate((cve, dec, mlp)):
+        syn.fill_state_dict(m, 71 + i)
+    model = HotPath(cv, cve, dec, mlp)
+    sd = lambda m: {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    w_fv, w_cve, w_dec, w_mlp = sd(cv.mlp), sd(cve), sd(dec), sd(mlp)
+    model.cuda()
+    Ks0 = syn.intrinsics(W * 2, H * 2).float()[None]
+    prev_pred_ref, prev_pred = None, None
+    prev_pose = None
+    for t in range(2):
+        inp = syn.cost_volume_inputs(B, K, 16, H, W, seed=80 + t)
+        pyr = syn.encoder_pyramid(B, H * 4, W * 4, seed=80 + t)
+        rd = syn.rendered_depth_planes(B, H * 2, W * 2, 1) * (1.0 + 0.1 * t)
+        cur_world_T_cam = syn.source_pose(t).float()[None]
+        d = {k: v.double() for k, v in inp.items()}
+        vol = ocv.feature_volume(d["cur_feats"], d["src_feats"], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"], 0.25, 5.0, D, w_fv)[0]
+        enc = onet.cv_encoder(vol, [p.double() for p in pyr[1:]], w_cve)
+        feats = onet.unetpp_decoder([pyr[0].double()] + enc, w_dec, depth_head=False)
+        if prev_pred_ref is None:
+            prior_ref = -torch.ones(B, 1, H * 2, W * 2, dtype=torch.float64)
+        else:
+            prior_ref = onet.sample_prior(rd.double(), prev_pred_ref, cur_world_T_cam.double(), torch.linalg.inv(prev_pose).double(), Ks0.double(), torch.linalg.inv(Ks0).double())
+        logits_ref = onet.occlusion_logits(feats["feature_s0_b1hw"], rd.double(), w_mlp, prior_ref)
+        g = {k: v.cuda() for k, v in inp.items()}
+        pin = None
+        if prev_pred is not None:
+            pin = {"prior_prediction": prev_pred, "prior_cam_T_world": torch.linalg.inv(prev_pose).cuda(), "world_T_cam_b44": cur_world_T_cam.cuda(),
+                   "K_s0_b44": Ks0.cuda(), "invK_s0_b44": torch.linalg.inv(Ks0).cuda()}
+        out = model(g["cur_feats"], g["src_feats"], [p.cuda() for p in pyr], g["src_extrinsics"], g["src_poses"], g["src_Ks"], g["cur_invK"],
+                    rendered_depth=rd.cuda(), prior_inputs=pin)
+        assert rel_err(out["pred_0"].cpu(), logits_ref) < 2 * TOL
+        prev_pred_ref, prev_pred, prev_pose = torch.sigmoid(logits_ref), torch.sigmoid(out["pred_0"]), cur_world_T_cam
