@@ -41,6 +41,8 @@ _SIGS = {
         C.c_int,
         [f32p] * 6 + [C.c_float, C.c_float] + [C.c_int] * 6 + [f32p] * 6 + [f32p, C.c_int, f32p, C.c_void_p, f32p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "idh_binary_mlp_search_fwd": (C.c_int, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int,
+                                            C.c_float, C.c_float, C.c_float, f32p, f32p, C.c_void_p]),
     "idh_sample_prior_fwd": (C.c_int, [f32p, f32p, C.c_int, f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
     "idh_cost_volume_dot_fwd": (
         C.c_int,

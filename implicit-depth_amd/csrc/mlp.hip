@@ -63,6 +63,11 @@ struct BinArgs {
     int M, HW, P, cs, Cf;
     int has_prior;        // W1 has a prior column
     float prior_const;    // used when has_prior && prior == null
+    // per-pixel binary depth search (bd_model.py:273-292): when search_iters > 0 the P planes are
+    // replaced by search_iters dependent evaluations at the pixel's current search depth
+    int search_iters;
+    float search_lo, search_hi, thr_logit;
+    float *search_out;    // B,1,HW final search depths
 };
 
 template <int TM>
@@ -125,13 +130,19 @@ __global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
             poff[t] = (size_t)b * a.P * a.HW + pix;
         }
         // ---- per query plane ----------------------------------------------------------------
+        const bool search = a.search_iters > 0;
+        const int n_eval = search ? a.search_iters : a.P;
+        float lo[TM], hi[TM], sd[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) { lo[t] = a.search_lo; hi[t] = a.search_hi; sd[t] = (a.search_hi - a.search_lo) * 0.5f; }
 #pragma unroll 1
-        for (int p = 0; p < a.P; ++p) {
+        for (int p = 0; p < n_eval; ++p) {
             float dv[TM], pv[TM];
+            const int pp = search ? 0 : p;  // the search reads plane 0 of the prior (P = 1 there)
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
-                dv[t] = a.depth[poff[t] + (size_t)p * a.HW];
-                pv[t] = a.has_prior ? (a.prior ? a.prior[poff[t] + (size_t)p * a.HW] : a.prior_const) : 0.f;
+                dv[t] = search ? sd[t] : a.depth[poff[t] + (size_t)p * a.HW];
+                pv[t] = a.has_prior ? (a.prior ? a.prior[poff[t] + (size_t)pp * a.HW] : a.prior_const) : 0.f;
             }
             f32x4 h1[kNS][TM], acc[kNS][TM];
 #pragma unroll
@@ -163,8 +174,21 @@ __global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
                 }
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
-                if (q == 0 && mok[t]) a.out[poff[t] + (size_t)p * a.HW] = s + b3;
+                const float logit = s + b3;
+                if (!search) {
+                    if (q == 0 && mok[t]) a.out[poff[t] + (size_t)p * a.HW] = logit;
+                } else {
+                    // sigmoid(logit) < threshold  <=>  logit < logit(threshold): "visible" -> move the far bound
+                    if (logit < a.thr_logit) hi[t] = sd[t]; else lo[t] = sd[t];
+                    if (p == n_eval - 1 && q == 0 && mok[t]) a.out[poff[t]] = logit;  // pred_0 of the last evaluation
+                    sd[t] = (hi[t] + lo[t]) * 0.5f;
+                }
             }
+        }
+        if (search) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+                if (q == 0 && mok[t]) a.search_out[poff[t]] = sd[t];
         }
     }
 }
@@ -271,6 +295,8 @@ extern "C" int idh_pack_mlp_weight(const float *w, float *dst, int ld, int col0,
     return IDH_OK;
 }
 
+static int binary_mlp_launch(BinArgs a, int B, void *stream);
+
 extern "C" int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *depth_bphw,
                                   const float *prior_bphw, int has_prior, float prior_const, const float *w1f_packed,
                                   const float *w2_packed, const float *vecs6x128, int B, int P, int HW,
@@ -281,11 +307,39 @@ extern "C" int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, c
     const long long M = (long long)B * HW;
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
     BinArgs a{feat_nhwc, depth_bphw, prior_bphw, w1f_packed, w2_packed, vecs6x128, out_bphw,
-              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const};
+              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr};
+    return binary_mlp_launch(a, B, stream);
+}
+
+// Per-pixel binary search for the depth at which the occlusion MLP flips (reference
+// experiment_modules/bd_model.py:273-292, `infer_depth=True`): `iters` dependent MLP evaluations
+// fused into one launch; bounds [lo, hi], first query (hi - lo)/2 as in the reference (0.5, 8.0, 3.75),
+// "visible" when sigmoid(logit) < threshold.
+extern "C" int idh_binary_mlp_search_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *prior_b1hw,
+                                         int has_prior, float prior_const, const float *w1f_packed,
+                                         const float *w2_packed, const float *vecs6x128, int B, int HW, int iters,
+                                         float lo, float hi, float threshold, float *search_depths_b1hw,
+                                         float *last_logits_b1hw, void *stream) {
+    if (B < 0 || HW <= 0 || iters <= 0 || Cf <= 0 || (Cf & 3) || (feat_cs & 3) || feat_cs < Cf || !(threshold > 0.f) ||
+        !(threshold < 1.f) || !(hi > lo))
+        return IDH_EINVAL;
+    if (B == 0) return IDH_OK;
+    if (!feat_nhwc || !w1f_packed || !w2_packed || !vecs6x128 || !search_depths_b1hw || !last_logits_b1hw) return IDH_EINVAL;
+    const long long M = (long long)B * HW;
+    if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    BinArgs a{feat_nhwc, nullptr, prior_b1hw, w1f_packed, w2_packed, vecs6x128, last_logits_b1hw,
+              (int)M, HW, 1, feat_cs, Cf, has_prior, prior_const, iters, lo, hi, logf(threshold / (1.f - threshold)),
+              search_depths_b1hw};
+    return binary_mlp_launch(a, B, stream);
+}
+
+static int binary_mlp_launch(BinArgs a, int B, void *stream) {
+    const long long M = a.M;
     constexpr int TM = 2;
     const int tiles = (int)((M + 16 * TM - 1) / (16 * TM));
     int grid = (tiles + 3) / 4;
     if (grid > 256 * 8) grid = 256 * 8;
+    (void)B;
     hipLaunchKernelGGL(binary_mlp_k<TM>, dim3(grid), dim3(256), 0, idh_stream(stream), a);
     IDH_CHECK_LAUNCH();
     return IDH_OK;

@@ -75,6 +75,24 @@ def occlusion_logits(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, de
     return out
 
 
+def infer_depth(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, prior_b1hw: Optional[torch.Tensor] = None,
+                iters: int = 12, lo: float = 0.5, hi: float = 8.0, threshold: float = 0.5):
+    """Fused form of the reference's ``infer_depth`` loop (bd_model.py:273-292): returns
+    (search_depths (B,1,H,W), logits of the last evaluation (B,1,H,W))."""
+    _lib.require_cuda_f32(feat_nhwc, prior_b1hw)
+    B, H, W, CS = feat_nhwc.shape
+    w1p, w2p, vecs = _prepared(net.mlps["s0"], n_feat, net.use_prior)
+    prior = prior_b1hw.contiguous() if prior_b1hw is not None else None
+    sd = torch.empty(B, 1, H, W, device=feat_nhwc.device)
+    logits = torch.empty(B, 1, H, W, device=feat_nhwc.device)
+    _lib.check(
+        _lib.lib().idh_binary_mlp_search_fwd(feat_nhwc.data_ptr() + 4 * feat_c0, CS, n_feat, _lib.ptr(prior), int(net.use_prior), -1.0,
+                                             w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(), B, H * W, iters, lo, hi, threshold,
+                                             sd.data_ptr(), logits.data_ptr(), _lib.stream_ptr()),
+        "idh_binary_mlp_search_fwd")
+    return sd, logits
+
+
 def sample_prior(rendered_depth: torch.Tensor, prior_prediction: torch.Tensor, cur_world_T_cam: torch.Tensor,
                  prior_cam_T_world: torch.Tensor, K: torch.Tensor, invK: torch.Tensor) -> torch.Tensor:
     """BDModel.sample_prior (reference bd_model.py:395-410) on the GPU kernel; returns the prior

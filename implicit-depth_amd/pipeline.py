@@ -72,7 +72,7 @@ class HotPath(nn.Module):
                 src_cam_T_cur_cam: torch.Tensor, cur_cam_T_src_cam: torch.Tensor, src_K: torch.Tensor, cur_invK: torch.Tensor,
                 rendered_depth: Optional[torch.Tensor] = None, prior: Optional[torch.Tensor] = None,
                 return_mask: bool = False, return_features: bool = False,
-                prior_inputs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                prior_inputs: Optional[Dict[str, torch.Tensor]] = None, infer_depth: bool = False) -> Dict[str, torch.Tensor]:
         """``prior``: an already-warped prior channel (B,P,H/2,W/2), or ``prior_inputs`` = the
         reference's temporal inputs {"prior_prediction", "prior_cam_T_world", "world_T_cam_b44",
         "K_s0_b44", "invK_s0_b44"} (bd_model.py:420-431) to warp it here; with neither, a
@@ -133,7 +133,12 @@ class HotPath(nn.Module):
                                      prior_inputs["prior_cam_T_world"], prior_inputs["K_s0_b44"], prior_inputs["invK_s0_b44"])
                 out["prior_mask"] = prior
             f0 = final[0]
-            out["pred_0"] = occlusion_logits(self.binary_mlp, f0.buf, f0.c0, f0.C, rendered_depth, prior)
+            if infer_depth:  # bd_model.py:273-292: 12-step per-pixel binary search, one launch
+                from .mlp import infer_depth as _search
+
+                out["search_depths"], out["pred_0"] = _search(self.binary_mlp, f0.buf, f0.c0, f0.C, prior[:, :1] if prior is not None else None)
+            else:
+                out["pred_0"] = occlusion_logits(self.binary_mlp, f0.buf, f0.c0, f0.C, rendered_depth, prior)
         if return_features:
             for i, v in final.items():
                 out[f"feature_s{i}_b1hw"] = _export(v)
