@@ -213,9 +213,17 @@ def main():
             roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                     "traffic": None, "kernel": wl.dominant_kernel, "kernel_ms": conv_ms / n_launch, "launches_per_step": n_launch,
                     "kernel_ms_per_step": conv_ms, "algorithmic_flops_per_launch": flops / n_launch, "step_ms_hip_events": kernel_ms}
-        traffic = getattr(wl, "pmc_traffic_bytes", None)
-        if traffic is not None:
-            roof["traffic"] = traffic
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the
+        # process, so the figure comes from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/pmc_traffic.json, tools/pmc_bench.sh) when the configuration matches, else null.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = f"{wl.name}/{getattr(wl, 'volume', 'dot')}/b{wl.B}" if wl.name == "hot_path" else f"{wl.name}/b{wl.B}"
+            if key in pmc and (wl.name != "warp_match_dot" or (wl.K, wl.D) == (8, 64)):
+                roof["traffic"] = pmc[key]["traffic_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/pmc_traffic.json"
+        except Exception:
+            pass
         out = {
             "metric": "frames/sec (BDModel.forward, 512x384, 64 planes, 8 views)",
             "value": frames_total / elapsed,
