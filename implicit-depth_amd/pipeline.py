@@ -165,7 +165,6 @@ class HotPathWorkload:
     maps of the right shape (they are outside the hot path)."""
 
     name = "hot_path"
-    dominant_kernel = "conv_mfma_k"
     bound = "mfma"
 
     def __init__(self, args, device, rank):
@@ -217,24 +216,39 @@ class HotPathWorkload:
         if ev is not None:
             ev[1].record()
 
-    # roofline of the dominant kernel: all conv_mfma_k launches of one step ------------------
-    def conv_only_ms(self, iters=10):
-        ent = next(iter(self.model._plans.values()))
-        p = ent["plan"]
-        convs = [op for op in p.ops if op.kind == nhwc.OP_CONV]
-        arr = (nhwc.Op * len(convs))(*convs)
+    # roofline of the dominant kernel -------------------------------------------------------
+    dominant_kernel = "conv3x3_lds_k<2>"
+
+    def _replay_ms(self, ops, iters=10):
         import ctypes as C
 
+        arr = (nhwc.Op * len(ops))(*ops)
         L = _lib.lib()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(2):
-            _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(convs), _lib.stream_ptr()), "idh_run_ops")
+            _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(ops), _lib.stream_ptr()), "idh_run_ops")
         e0.record()
         for _ in range(iters):
-            _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(convs), _lib.stream_ptr()), "idh_run_ops")
+            _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(ops), _lib.stream_ptr()), "idh_run_ops")
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters, len(convs), p.flops
+        return e0.elapsed_time(e1) / iters
+
+    @staticmethod
+    def _conv_flops(op):
+        return sum(2 * op.N * op.Ho * op.Wo * op.Cout * s.Cin * s.ks * s.ks for s in op.src if s.in_)
+
+    def conv_only_ms(self, iters=10):
+        """HIP-event timing of (a) the launches of the dominant kernel — the 8-row LDS-staged
+        3x3 conv, one launch per op with tile code 8 — and (b) every conv op of the step, each
+        set replayed alone on the launch stream.  Returns two (ms_per_step, launches, flops)."""
+        ent = next(iter(self.model._plans.values()))
+        p = ent["plan"]
+        convs = [op for op in p.ops if op.kind == nhwc.OP_CONV]
+        dom = [op for op in convs if op.tile_m == 8]
+        dom_res = (self._replay_ms(dom, iters), len(dom), sum(self._conv_flops(o) for o in dom))
+        all_res = (self._replay_ms(convs, iters), len(convs), sum(self._conv_flops(o) for o in convs))
+        return dom_res, all_res
 
     def metrics(self):
         o = self.out
