@@ -190,8 +190,14 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             // metadata registers of this lane: [0..6] view q, [7..13] view q+4, [14] plane depth
             float m0 = 0.f, m1 = 0.f, m2 = 0.f, m7 = 0.f, m8 = 0.f, m9 = 0.f;
             bool any_inb = false, any_front = false;
-#pragma unroll 1
-            for (int k = 0; k < K; ++k) {
+            // Software-pipelined view loop: the projection + 4 tap loads of view k+1 are issued
+            // before the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work.
+            struct Tap {
+                f32x4 t00, t01, t10, t11;
+                float w00, w01, w10, w11, z, u, v;
+            };
+            auto issue = [&](int k) {
+                Tap t;
                 const float *hm = pb + kWsHom + 12 * k;
                 const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
                 const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
@@ -199,15 +205,13 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 const float cx = fmaf(depth, qx, hm[9]);
                 const float cy = fmaf(depth, qy, hm[10]);
                 const float cz = fmaf(depth, qz, hm[11]);
-                const float z = fmaxf(cz, 1e-5f);
-                float r = __builtin_amdgcn_rcpf(z);
-                r = r * fmaf(-z, r, 2.0f);
-                const float u = cx * r, v = cy * r;
-                any_inb |= (u > 2.f) & (u < Wf - 2.f) & (v > 2.f) & (v < Hf - 2.f);
-                const float maskv = z > 0.f ? 1.f : 0.f;
-                any_front |= z > 0.f;
-                const float sx = fminf(fmaxf(u - 0.5f, -1.0f), Wf);
-                const float sy = fminf(fmaxf(v - 0.5f, -1.0f), Hf);
+                t.z = fmaxf(cz, 1e-5f);
+                float r = __builtin_amdgcn_rcpf(t.z);
+                r = r * fmaf(-t.z, r, 2.0f);
+                t.u = cx * r;
+                t.v = cy * r;
+                const float sx = fminf(fmaxf(t.u - 0.5f, -1.0f), Wf);
+                const float sy = fminf(fmaxf(t.v - 0.5f, -1.0f), Hf);
                 const float x0f = floorf(sx), y0f = floorf(sy);
                 const float fx = sx - x0f, fy = sy - y0f;
                 const int x0 = (int)x0f, y0 = (int)y0f;
@@ -218,14 +222,25 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
                 const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
                 const float *sb = a.src + (size_t)(b * K + k) * N * kC + 4 * q;
-                const f32x4 t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kC);
-                const f32x4 t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kC);
-                const f32x4 t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kC);
-                const f32x4 t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kC);
-                const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+                t.t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kC);
+                t.t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kC);
+                t.t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kC);
+                t.t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kC);
+                t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
+                return t;
+            };
+            Tap cur = issue(0);
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const Tap nxt = issue(min(k + 1, K - 1));  // unconditional: counted vmcnt waits
+                any_inb |= (cur.u > 2.f) & (cur.u < Wf - 2.f) & (cur.v > 2.f) & (cur.v < Hf - 2.f);
+                const float z = cur.z;
+                const float maskv = z > 0.f ? 1.f : 0.f;
+                any_front |= z > 0.f;
                 f32x4 wv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) wv[e] = fmaf(w11, t11[e], fmaf(w10, t10[e], fmaf(w01, t01[e], w00 * t00[e])));
+                for (int e = 0; e < 4; ++e)
+                    wv[e] = fmaf(cur.w11, cur.t11[e], fmaf(cur.w10, cur.t10[e], fmaf(cur.w01, cur.t01[e], cur.w00 * cur.t00[e])));
                 float part = wv[0] * cur4[0];
                 part = fmaf(wv[1], cur4[1], part); part = fmaf(wv[2], cur4[2], part); part = fmaf(wv[3], cur4[3], part);
                 part += __shfl_xor(part, 16, 64);
@@ -241,6 +256,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
                 }
+                cur = nxt;
             }
             // rays / ray angles of this lane's two views (cost_volume.py:630-659)
             float m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m10 = 0.f, m11 = 0.f, m12 = 0.f, m13 = 0.f;
