@@ -34,13 +34,13 @@ __device__ __forceinline__ float lrelu(float x, float s) { return x >= 0.f ? x :
 //   wfrag      : packed weights [c][i][lane][4]   (i = output sub-tile)
 //   acc[i][t]  : results in C/D layout (= next layer's B operands)
 template <int TM>
-__device__ __forceinline__ void dense128(const f32x4 (&hin)[kNS][TM], const float *__restrict__ wfrag, int lane,
+__device__ __forceinline__ void dense128(const f32x4 (&hin)[kNS][TM], const f32x4 *wfrag, int lane,
                                          f32x4 (&acc)[kNS][TM]) {
 #pragma unroll
     for (int c = 0; c < kNS; ++c) {
 #pragma unroll
         for (int i = 0; i < kNS; ++i) {
-            const f32x4 A = *reinterpret_cast<const f32x4 *>(wfrag + ((size_t)(c * kNS + i) * 64 + lane) * 4);
+            const f32x4 A = wfrag[(c * kNS + i) * 64 + lane];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -70,10 +70,27 @@ struct BinArgs {
     float *search_out;    // B,1,HW final search depths
 };
 
+// Persistent 512-thread workgroups (one per CU): W2 (64 KiB) and, when it fits, the feature part
+// of W1 (8 KiB per 16 input channels) are staged once into LDS in MFMA fragment order and shared
+// by the 8 waves; each wave then streams 16-pixel tiles.
+constexpr int kBinThreads = 512, kBinWaves = kBinThreads / 64;
+constexpr int kW1LdsMaxBlocks = 4;  // Cf <= 64 -> W1f in LDS (32 KiB); wider scales read it via L1/L2
+
 template <int TM>
-__global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_vec[6 * kHidden];
-    for (int i = threadIdx.x; i < 6 * kHidden; i += 256) s_vec[i] = a.vecs[i];
+__global__ __launch_bounds__(kBinThreads) void binary_mlp_k(const BinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4 *sW2 = reinterpret_cast<f32x4 *>(smem_raw);
+    const int cblocks = (a.Cf + 15) >> 4;
+    const bool w1_lds = cblocks <= kW1LdsMaxBlocks;
+    f32x4 *sW1 = sW2 + kNS * kNS * 64;
+    float *s_vec = reinterpret_cast<float *>(sW1 + (w1_lds ? cblocks * kNS * 64 : 0));
+    {
+        const f32x4 *g2 = reinterpret_cast<const f32x4 *>(a.w2), *g1 = reinterpret_cast<const f32x4 *>(a.w1f);
+        for (int i = threadIdx.x; i < kNS * kNS * 64; i += kBinThreads) sW2[i] = g2[i];
+        if (w1_lds)
+            for (int i = threadIdx.x; i < cblocks * kNS * 64; i += kBinThreads) sW1[i] = g1[i];
+        for (int i = threadIdx.x; i < 6 * kHidden; i += kBinThreads) s_vec[i] = a.vecs[i];
+    }
     __syncthreads();
     const float *s_b1 = s_vec, *s_wd = s_vec + kHidden, *s_wp = s_vec + 2 * kHidden, *s_b2 = s_vec + 3 * kHidden,
                 *s_w3 = s_vec + 4 * kHidden;
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
     const int ln = lane & 15, q = lane >> 4;
     const int tiles = (a.M + 16 * TM - 1) / (16 * TM);
 
-    for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    for (int tile = blockIdx.x * kBinWaves + wave; tile < tiles; tile += gridDim.x * kBinWaves) {
         const int m0 = tile * 16 * TM;
         // ---- layer 1, plane-independent part: pre1^T = W1f . feat^T + b1 ------------------
         f32x4 pre1[kNS][TM];
@@ -101,7 +118,6 @@ __global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
             mok[t] = m < a.M;
             mrow[t] = mok[t] ? m : a.M - 1;
         }
-        const int cblocks = (a.Cf + 15) >> 4;
 #pragma unroll 1
         for (int c = 0; c < cblocks; ++c) {
             f32x4 Bf[TM];
@@ -113,7 +129,8 @@ __global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < kNS; ++i) {
-                const f32x4 A = *reinterpret_cast<const f32x4 *>(a.w1f + ((size_t)(c * kNS + i) * 64 + lane) * 4);
+                const f32x4 A = w1_lds ? sW1[(c * kNS + i) * 64 + lane]
+                                       : *reinterpret_cast<const f32x4 *>(a.w1f + ((size_t)(c * kNS + i) * 64 + lane) * 4);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(256) void binary_mlp_k(const BinArgs a) {
                     acc[i][t] = b2;
                 }
             }
-            dense128<TM>(h1, a.w2, lane, acc);
+            dense128<TM>(h1, sW2, lane, acc);
             // ---- layer 3: logit = w3 . ELU(h2) + b3; reduce over the 4 lane quarters ----------
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
@@ -335,12 +352,22 @@ extern "C" int idh_binary_mlp_search_fwd(const float *feat_nhwc, int feat_cs, in
 
 static int binary_mlp_launch(BinArgs a, int B, void *stream) {
     const long long M = a.M;
-    constexpr int TM = 2;
+    constexpr int TM = 1;
     const int tiles = (int)((M + 16 * TM - 1) / (16 * TM));
-    int grid = (tiles + 3) / 4;
-    if (grid > 256 * 8) grid = 256 * 8;
+    int grid = (tiles + kBinWaves - 1) / kBinWaves;
+    if (grid > 256) grid = 256;  // persistent: one workgroup per CU (LDS-resident weights)
     (void)B;
-    hipLaunchKernelGGL(binary_mlp_k<TM>, dim3(grid), dim3(256), 0, idh_stream(stream), a);
+    const int cblocks = (a.Cf + 15) >> 4;
+    const size_t lds = ((size_t)kNS * kNS * 64 + (cblocks <= kW1LdsMaxBlocks ? (size_t)cblocks * kNS * 64 : 0)) * sizeof(f32x4) +
+                       6 * kHidden * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(binary_mlp_k<TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return IDH_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(binary_mlp_k<TM>, dim3(grid), dim3(kBinThreads), lds, idh_stream(stream), a);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }
