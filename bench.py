@@ -161,14 +161,15 @@ def main():
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun: exercise RCCL even at N=1
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     wl = make_workload(args, device, rank)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     with torch.inference_mode():
@@ -189,7 +190,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
 
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
 
@@ -248,7 +249,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,37 @@
+"""Per-launch-unit timing of the hot-path plan in scheduled order (groups timed as one unit)."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import implicit_depth_amd.synthetic as syn
+from implicit_depth_amd import nhwc, _lib
+from implicit_depth_amd.pipeline import HotPathWorkload
+import argparse
+a = argparse.Namespace(batch=int(sys.argv[1]) if len(sys.argv) > 1 else 4, views=7, planes=64, height=384, width=512, volume="mlp")
+wl = HotPathWorkload(a, torch.device("cuda"), 0)
+for _ in range(2): wl.step()
+torch.cuda.synchronize()
+p = next(iter(wl.model._plans.values()))["plan"]
+L = _lib.lib()
+units, i = [], 0
+while i < len(p.ops):
+    op = p.ops[i]; j = i + 1
+    if op.kind == 1 and op.group != 0 and op.tile_m == 9:
+        while j < len(p.ops) and j - i < 12 and p.ops[j].kind == 1 and p.ops[j].group == op.group and p.ops[j].tile_m == 9: j += 1
+    units.append((i, j)); i = j
+def flops(op): return sum(2 * op.N * op.Ho * op.Wo * op.Cout * s.Cin * s.ks * s.ks for s in op.src if s.in_) if op.kind == 1 else 0
+rows = []
+for (i, j) in units:
+    arr = (nhwc.Op * (j - i))(*p.ops[i:j])
+    for _ in range(2): L.idh_run_ops(C.cast(arr, C.c_void_p), j - i, _lib.stream_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): L.idh_run_ops(C.cast(arr, C.c_void_p), j - i, _lib.stream_ptr())
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    fl = sum(flops(o) for o in p.ops[i:j])
+    desc = " | ".join((f"{o.src[0].Cin}" + (f"+{o.src[1].Cin}" if o.src[1].in_ else "") + f">{o.Cout}@{o.Ho}x{o.Wo} t{o.tile_m}s{o.split_k}") if o.kind == 1 else f"k{o.kind}:{o.src[0].Cin}@{o.src[0].H}x{o.src[0].W}" for o in p.ops[i:j])
+    rows.append((ms, fl, p.levels[i], j - i, desc))
+tot = sum(r[0] for r in rows)
+print(f"B={a.batch} units={len(rows)} ops={len(p.ops)} total {tot:.3f} ms  conv TF={sum(r[1] for r in rows)/tot/1e9:.1f}")
+for ms, fl, lv, n, desc in sorted(rows, key=lambda r: -r[0])[:45]:
+    print(f"{ms*1e3:7.1f} us {100*ms/tot:4.1f}% L{lv:<3d} n={n:<2d} {fl/ms/1e9 if ms else 0:6.1f} TF  {desc[:150]}")
