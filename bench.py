@@ -116,6 +116,7 @@ class WarpMatchDot:
         i = self.host_inputs
         one = {k: (v[:1] if v.shape[0] == self.B and v.ndim > 1 and k not in ("min_depth", "max_depth") else v) for k, v in i.items()}
         n, t0 = 0, time.perf_counter()
+        ocv.FAST_GATHER = True  # time the restatement with torch's own grid_sample primitive
         with torch.inference_mode():
             while True:
                 ocv.cost_volume_dot(one["cur_feats"], one["src_feats"], one["src_extrinsics"], one["src_Ks"], one["cur_invK"], 0.25, 5.0, self.D)

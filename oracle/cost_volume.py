@@ -60,6 +60,12 @@ def project_plane(
     return X, cam[:, :, 0] / z, cam[:, :, 1] / z, z
 
 
+# When True the gather below is delegated to torch's grid_sample primitive (the op the reference
+# itself calls) instead of the hand-rolled taps.  Same result (tests/test_oracle_golden.py); it
+# exists so that the CPU *baseline* timed by bench.py is not handicapped by a slow restatement.
+FAST_GATHER = False
+
+
 def bilinear_zeros(src_bkchw: torch.Tensor, u: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """Sample src at pixel-unit coords (u,v) exactly as grid_sample(bilinear, zeros,
     align_corners=False) does after the reference's normalisation: array coords
@@ -71,6 +77,13 @@ def bilinear_zeros(src_bkchw: torch.Tensor, u: torch.Tensor, v: torch.Tensor) ->
     dt = src_bkchw.dtype
     gx = 2 * u * torch.tensor(1.0 / W, dtype=dt) - 1
     gy = 2 * v * torch.tensor(1.0 / H, dtype=dt) - 1
+    if FAST_GATHER:
+        import torch.nn.functional as F
+
+        N = u.shape[-1]
+        grid = torch.stack([gx, gy], -1).reshape(B * K, 1, N, 2)
+        out = F.grid_sample(src_bkchw.reshape(B * K, C, H, W), grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+        return out.reshape(B, K, C, N)
     sx = ((gx + 1) * W - 1) / 2
     sy = ((gy + 1) * H - 1) / 2
     x0f, y0f = torch.floor(sx), torch.floor(sy)

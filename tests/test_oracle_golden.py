@@ -199,3 +199,16 @@ def test_matching_head_matches_reference():
     assert sorted(k for k in w if k.split(".")[1] in ("5", "8")) == list(g["keys"])
     x = syn.randn((3, 64, 24, 32), 41, "mh_x")
     assert rel_err(onet.matching_head(x, w), g["y"]) < 2e-5
+
+
+def test_fast_gather_equals_hand_rolled_taps():
+    """The grid_sample shortcut used for the timed CPU baseline is the same function."""
+    inp = syn.cost_volume_inputs(2, 3, 16, 12, 20, 9, behind_view=2)
+    args = (inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_Ks"], inp["cur_invK"], 0.25, 5.0, 6)
+    slow = ocv.cost_volume_dot(*args)[0]
+    ocv.FAST_GATHER = True
+    try:
+        fast = ocv.cost_volume_dot(*args)[0]
+    finally:
+        ocv.FAST_GATHER = False
+    assert rel_err(fast, slow) < 1e-6
