@@ -246,6 +246,9 @@ class HotPathWorkload:
         p = ent["plan"]
         convs = [op for op in p.ops if op.kind == nhwc.OP_CONV]
         dom = [op for op in convs if op.tile_m == 8]
+        if not dom:  # small batches: every layer runs on the 4-row tile variant
+            dom = [op for op in convs if op.tile_m == 9]
+            self.dominant_kernel = "conv3x3_lds_k<1> + conv3x3_lds_group_k<1>"
         dom_res = (self._replay_ms(dom, iters), len(dom), sum(self._conv_flops(o) for o in dom))
         all_res = (self._replay_ms(convs, iters), len(convs), sum(self._conv_flops(o) for o in convs))
         return dom_res, all_res
