@@ -140,9 +140,10 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
     const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
 
     for (long long task = (long long)blockIdx.x * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
-        const int g = (int)(task % a.G);
-        const int tile = (int)((task / a.G) % a.tiles_per_img);
-        const int b = (int)(task / ((long long)a.G * a.tiles_per_img));
+        // wave-uniform task coordinates: pin to SGPRs so the per-b constants come through the scalar cache
+        const int g = __builtin_amdgcn_readfirstlane((int)(task % a.G));
+        const int tile = __builtin_amdgcn_readfirstlane((int)((task / a.G) % a.tiles_per_img));
+        const int b = __builtin_amdgcn_readfirstlane((int)(task / ((long long)a.G * a.tiles_per_img)));
         const int p_raw = tile * 16 + ln;
         const bool live = p_raw < N;
         const int p = live ? p_raw : N - 1;
@@ -380,14 +381,25 @@ extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nh
     a.B = B; a.K = K; a.H = H; a.W = W; a.D = D; a.dmin = dmin; a.dmax = dmax;
     const int N = H * W;
     a.tiles_per_img = (N + 15) / 16;
-    // plane groups: aim at >= 8 tasks per wave slot (256 CUs x 8 waves) while keeping >= 4 planes
-    // per task so the per-pixel pre-activation is amortised
+    // plane groups: tasks are uniform in cost and run on 256 CUs x 8 persistent waves, so pick the
+    // number of groups G (>= 4 planes per task, so the per-pixel pre-activation stays amortised) that
+    // wastes the least of the last round: minimise ceil(tasks/slots)*slots/tasks, smallest G on ties.
     const long long pix_tasks = (long long)B * a.tiles_per_img;
-    int G = (int)((256ll * 8 * 4 + pix_tasks - 1) / pix_tasks);
-    if (G < 1) G = 1;
-    if (G > (D + 3) / 4) G = (D + 3) / 4;
-    a.DP = (D + G - 1) / G;
-    a.G = (D + a.DP - 1) / a.DP;
+    const long long slots = 256ll * 8;
+    int bestG = 1;
+    double bestWaste = 1e30;
+    for (int G = 1; G <= (D + 3) / 4; ++G) {
+        const int DP = (D + G - 1) / G;
+        const int Gr = (D + DP - 1) / DP;
+        if (Gr != G) continue;
+        // planes are not always divisible: cost of a task ~ DP (+1 for the pre-activation)
+        const long long tasks = pix_tasks * G;
+        const double rounds = (double)((tasks + slots - 1) / slots);
+        const double waste = rounds * slots * (DP + 1) / ((double)pix_tasks * (D + G));
+        if (waste < bestWaste - 1e-9) { bestWaste = waste; bestG = G; }
+    }
+    a.G = bestG;
+    a.DP = (D + bestG - 1) / bestG;
     const long long ntasks = pix_tasks * a.G;
     int grid = (int)((ntasks + 7) / 8);
     if (grid > 256) grid = 256;  // persistent: one 512-thread workgroup per CU (LDS-resident weights)
