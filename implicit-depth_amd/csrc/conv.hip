@@ -58,7 +58,9 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
-    return (act == IDH_ACT_LRELU && v < 0.f) ? v * slope : v;
+    if (act == IDH_ACT_LRELU) return v < 0.f ? v * slope : v;
+    if (act == IDH_ACT_ELU) return v > 0.f ? v : expm1f(v);  // nn.ELU(alpha=1), networks_fast.py:17
+    return v;
 }
 
 // Zero page: out-of-image taps (zero padding) read from here instead of being predicated,
@@ -211,9 +213,9 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
             f32x4 v = acc[i][j];
             if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
             if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
-            if (a.act == IDH_ACT_LRELU) {
+            if (a.act != IDH_ACT_NONE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * a.slope : v[r];
+                for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, a.slope);
             }
             *reinterpret_cast<f32x4 *>(o + co) = v;
         }
@@ -426,9 +428,9 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             f32x4 v = acc[i][j];
             if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
             if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
-            if (a.act == IDH_ACT_LRELU) {
+            if (a.act != IDH_ACT_NONE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] < 0.f ? v[r] * a.slope : v[r];
+                for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, a.slope);
             }
             *reinterpret_cast<f32x4 *>(o + co) = v;
         }
@@ -556,6 +558,36 @@ __global__ __launch_bounds__(256) void upsample2_k(const float *__restrict__ in,
         o.z = hy0 * (wx0 * p00.z + wx1 * p01.z) + hy1 * (wx0 * p10.z + wx1 * p11.z);
         o.w = hy0 * (wx0 * p00.w + wx1 * p01.w) + hy1 * (wx0 * p10.w + wx1 * p11.w);
         *reinterpret_cast<float4 *>(out + (((size_t)n * Ho + y) * Wo + x) * out_cs + 4 * q) = o;
+    }
+}
+
+// nearest x2 (F.interpolate(scale_factor=2, mode="nearest"), networks_fast.py:43): out[y,x] = in[y>>1, x>>1]
+__global__ __launch_bounds__(256) void upsample2_nearest_k(const float *__restrict__ in, float *__restrict__ out, int N, int H,
+                                                           int W, int C, int in_cs, int out_cs) {
+    const int cq = C >> 2;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)N * Ho * Wo * cq;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
+        const int q = (int)(t % cq);
+        long long p = t / cq;
+        const int x = (int)(p % Wo);
+        p /= Wo;
+        const int y = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const float4 v = *reinterpret_cast<const float4 *>(in + (((size_t)n * H + (y >> 1)) * W + (x >> 1)) * in_cs + 4 * q);
+        *reinterpret_cast<float4 *>(out + (((size_t)n * Ho + y) * Wo + x) * out_cs + 4 * q) = v;
+    }
+}
+
+// channel-strided NHWC copy (places an existing feature map into a slice of a concat buffer)
+__global__ __launch_bounds__(256) void copy_nhwc_k(const float *__restrict__ in, float *__restrict__ out, long long npix, int C,
+                                                   int in_cs, int out_cs) {
+    const int cq = C >> 2;
+    const long long total = npix * cq;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
+        const int q = (int)(t % cq);
+        const long long p = t / cq;
+        *reinterpret_cast<float4 *>(out + p * out_cs + 4 * q) = *reinterpret_cast<const float4 *>(in + p * in_cs + 4 * q);
     }
 }
 
@@ -854,13 +886,18 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 i += cnt - 1;
                 break;
             }
-            case IDH_OP_UPSAMPLE2: {
+            case IDH_OP_UPSAMPLE2:
+            case IDH_OP_UPSAMPLE2_NEAREST: {
                 if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0) return IDH_EINVAL;
                 const long long tot = (long long)op.N * 4 * s.H * s.W * (s.Cin >> 2);
                 int grid = idh_cdiv(tot, 256);
                 if (grid > 8192) grid = 8192;
-                hipLaunchKernelGGL(upsample2_k, dim3(grid), dim3(256), 0, st, s.in, op.out, op.N, s.H, s.W, s.Cin, s.cs,
-                                   op.out_cs);
+                if (op.kind == IDH_OP_UPSAMPLE2)
+                    hipLaunchKernelGGL(upsample2_k, dim3(grid), dim3(256), 0, st, s.in, op.out, op.N, s.H, s.W, s.Cin, s.cs,
+                                       op.out_cs);
+                else
+                    hipLaunchKernelGGL(upsample2_nearest_k, dim3(grid), dim3(256), 0, st, s.in, op.out, op.N, s.H, s.W, s.Cin,
+                                       s.cs, op.out_cs);
                 IDH_CHECK_LAUNCH();
                 break;
             }
@@ -887,6 +924,15 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 if (grid > 8192) grid = 8192;
                 hipLaunchKernelGGL(pointwise_head_k, dim3(grid), dim3(256), 0, st, s.in, s.w, op.bias, op.out, M, s.Cin,
                                    s.cs);
+                IDH_CHECK_LAUNCH();
+                break;
+            }
+            case IDH_OP_COPY: {
+                if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0) return IDH_EINVAL;
+                const long long npix = (long long)op.N * s.H * s.W;
+                int grid = idh_cdiv(npix * (s.Cin >> 2), 256);
+                if (grid > 8192) grid = 8192;
+                hipLaunchKernelGGL(copy_nhwc_k, dim3(grid), dim3(256), 0, st, s.in, op.out, npix, s.Cin, s.cs, op.out_cs);
                 IDH_CHECK_LAUNCH();
                 break;
             }

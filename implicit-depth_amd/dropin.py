@@ -49,6 +49,13 @@ def convert_cv_encoder(ref: nn.Module) -> nn.Module:
 
 
 def convert_decoder(ref: nn.Module) -> nn.Module:
+    if hasattr(ref, "block1"):  # SkipDecoder / SkipDecoderRegression (networks_fast.py)
+        blocks = [ref.block1, ref.block2, ref.block3, ref.block4]
+        outs = [b.pre_concat_conv.conv2.out_channels for b in blocks]
+        enc_rev = [ref.block1.pre_concat_conv.conv1.in_channels] + [b.post_concat_conv.conv1.in_channels - o for b, o in zip(blocks, outs)]
+        new = (net.SkipDecoderRegression if hasattr(ref, "out1") else net.SkipDecoder)(enc_rev[::-1])
+        new.load_state_dict(ref.state_dict())
+        return new.to(_device(ref))
     enc = [ref.convs[f"right_conv_{i}0"].conv1.in_channels for i in range(4)] + [ref.convs["diag_conv_40"].conv1.in_channels]
     head = len(ref.convs["output_0"]) == 2
     new = (net.DepthDecoderPP if head else net.BDDecoderPP)(enc)
@@ -76,7 +83,7 @@ def convert(model: nn.Module) -> nn.Module:
         model.cost_volume = convert_cost_volume(model.cost_volume)
     if not isinstance(model.cost_volume_net, net.CVEncoder):
         model.cost_volume_net = convert_cv_encoder(model.cost_volume_net)
-    if not isinstance(model.depth_decoder, net._DecoderPP):
+    if not isinstance(model.depth_decoder, (net._DecoderPP, net.SkipDecoder)):
         model.depth_decoder = convert_decoder(model.depth_decoder)
     if hasattr(model, "binary_mlp") and not isinstance(model.binary_mlp, net.BinaryMLPNetwork):
         model.binary_mlp = convert_binary_mlp(model.binary_mlp)

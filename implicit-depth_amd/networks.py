@@ -167,3 +167,63 @@ class ResnetMatchingEncoder(nn.Module):
         from .nhwc import matching_head_forward
 
         return matching_head_forward(self, self.backbone(input_image), channels_last)
+
+
+# --- skip decoder family (reference modules/networks_fast.py) ---------------------------------
+class ConvBlock(nn.Module):
+    """conv3x3 -> ELU -> conv3x3 -> ELU (networks_fast.py:10-28)."""
+
+    def __init__(self, in_ch, out_ch, use_elu=True, use_bn=False):
+        super().__init__()
+        if not use_elu or use_bn:
+            raise ValueError("the gfx950 drop-in covers the shipped ELU / no-BN configuration")
+        self.conv1 = nn.Conv2d(in_ch, out_ch, 3, padding=1)
+        self.conv2 = nn.Conv2d(out_ch, out_ch, 3, padding=1)
+        self.non_lin = nn.ELU(inplace=True)
+
+
+class ConvUpsampleAndConcatBlock(nn.Module):
+    """ConvBlock -> nearest x2 -> cat(skip) -> ConvBlock (networks_fast.py:31-47)."""
+
+    def __init__(self, in_ch, out_ch, skip_chns, use_elu=True, use_bn=False):
+        super().__init__()
+        self.pre_concat_conv = ConvBlock(in_ch, out_ch, use_elu, use_bn)
+        self.post_concat_conv = ConvBlock(out_ch + skip_chns, out_ch, use_elu, use_bn)
+
+
+class SkipDecoder(nn.Module):
+    """reference modules/networks_fast.py:49-99 (``depth_decoder_name: skip``)."""
+
+    depth_head = False
+    out_key = "feature_s{}_b1hw"
+
+    def __init__(self, input_channels, use_bn=False):
+        super().__init__()
+        input_channels = list(input_channels)[::-1]
+        self.input_channels = input_channels
+        self.output_channels = [256, 128, 64, 64]
+        self.num_ch_dec = self.output_channels[::-1]
+        for i in range(4):
+            # in_ch = input_channels[i] exactly as the reference (:59-82): it relies on the encoder widths
+            # [.., 64, 128, 256, 384] coinciding with the previous block's output width
+            setattr(self, f"block{i + 1}", ConvUpsampleAndConcatBlock(input_channels[i], self.output_channels[i], input_channels[i + 1], use_bn=use_bn))
+
+    def forward(self, features):
+        from .nhwc import decoder_forward_nchw
+
+        return decoder_forward_nchw(self, features)
+
+
+class SkipDecoderRegression(SkipDecoder):
+    """reference modules/networks_fast.py:102-145: SkipDecoder + per-scale 1x1 MLP heads."""
+
+    def __init__(self, input_channels, use_bn=False):
+        super().__init__(input_channels, use_bn=use_bn)
+        for i in range(4):
+            setattr(self, f"out{i + 1}", nn.Sequential(nn.Conv2d(self.output_channels[i], 128, 1), nn.ELU(inplace=True), nn.Conv2d(128, 128, 1),
+                                                       nn.ELU(inplace=True), nn.Conv2d(128, 1, 1)))
+
+    def forward(self, features):
+        from .nhwc import skip_regression_forward_nchw
+
+        return skip_regression_forward_nchw(self, features)

@@ -25,8 +25,8 @@ from torch import nn
 from . import _lib
 
 # --- ctypes mirrors of include/idh_ops.h -------------------------------------------------
-OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD, OP_INSTNORM = 1, 2, 3, 4, 5, 6, 7
-ACT_NONE, ACT_LRELU = 0, 1
+OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD, OP_INSTNORM, OP_UPSAMPLE2_NEAREST, OP_COPY = 1, 2, 3, 4, 5, 6, 7, 8, 9
+ACT_NONE, ACT_LRELU, ACT_ELU = 0, 1, 2
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 
 
@@ -237,9 +237,9 @@ class Plan:
         self._arr = None
         return out
 
-    def upsample2(self, x: View, out: View):
+    def upsample2(self, x: View, out: View, nearest: bool = False):
         op = Op()
-        op.kind, op.N = OP_UPSAMPLE2, x.N
+        op.kind, op.N = (OP_UPSAMPLE2_NEAREST if nearest else OP_UPSAMPLE2), x.N
         s = op.src[0]
         s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
         op.out, op.out_cs = out.ptr, out.cs
@@ -260,6 +260,20 @@ class Plan:
         ws = torch.empty(x.N * (-(-(x.H * x.W) // 1024)) * 2 * x.C, device=self.device, dtype=torch.float32)
         self.keep.append(ws)
         op.ws = ws.data_ptr()
+        self.ops.append(op)
+        self.meta.append({"reads": [_region(x)], "writes": [_region(out)]})
+        self._arr = None
+        return out
+
+    def copy(self, x: View, out: View):
+        """NHWC view -> NHWC view (e.g. an existing feature map into a slice of a concat buffer)."""
+        if (x.N, x.H, x.W, x.C) != (out.N, out.H, out.W, out.C):
+            raise _lib.IdhError("copy: shape mismatch")
+        op = Op()
+        op.kind, op.N = OP_COPY, x.N
+        s = op.src[0]
+        s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
+        op.out, op.out_cs = out.ptr, out.cs
         self.ops.append(op)
         self.meta.append({"reads": [_region(x)], "writes": [_region(out)]})
         self._arr = None
@@ -523,10 +537,10 @@ def decoder_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dict[str, t
             v = p.buffer(f.shape[0], f.shape[2], f.shape[3], f.shape[1])
             i_in.append(p.import_nchw(f.shape, v))
             views.append(v)
-        final = build_decoder(p, dec, views)
+        final = build_any_decoder(p, dec, views)
         i_out = {}
         for i, v in final.items():
-            if dec.depth_head:
+            if getattr(dec, "depth_head", False):
                 i_out[i] = p.head(v, dec.convs[f"output_{i}"][1], torch.empty(1, device=feats[0].device))
             else:
                 i_out[i] = p.export_nchw(v)
@@ -538,7 +552,7 @@ def decoder_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dict[str, t
         p.set_in(i, f)
     res = {}
     for i, v in final.items():
-        ch = 1 if dec.depth_head else v.C
+        ch = 1 if getattr(dec, "depth_head", False) else v.C
         t = torch.empty(v.N, ch, v.H, v.W, device=feats[0].device, dtype=torch.float32)
         p.set_out(i_out[i], t)
         res[dec.out_key.format(i)] = t
@@ -592,3 +606,91 @@ def matching_head_forward(enc, feat_nchw: torch.Tensor, channels_last: bool = Fa
     p.set_out(i_out, out)
     p.run()
     return out
+
+
+# --- SkipDecoder / SkipDecoderRegression (reference modules/networks_fast.py:10-145) ------------
+def _conv_block(p: Plan, x: View, blk, out: Optional[View] = None) -> View:
+    """ConvBlock: conv3x3 -> ELU -> conv3x3 -> ELU (networks_fast.py:10-28)."""
+    h = p.buffer(x.N, x.H, x.W, blk.conv1.out_channels)
+    p.conv(x, blk.conv1, h, act=ACT_ELU)
+    if out is None:
+        out = p.buffer(x.N, x.H, x.W, blk.conv2.out_channels)
+    p.conv(h, blk.conv2, out, act=ACT_ELU)
+    return out
+
+
+def build_skip_decoder(p: Plan, dec, feats: List[View]) -> Dict[int, View]:
+    """features[-1] -> block1..block4, each: ConvBlock, nearest x2, concat skip, ConvBlock."""
+    x = feats[-1]
+    final: Dict[int, View] = {}
+    for bi, blk in enumerate((dec.block1, dec.block2, dec.block3, dec.block4)):
+        skip = feats[-2 - bi]
+        cout = blk.pre_concat_conv.conv2.out_channels
+        y = _conv_block(p, x, blk.pre_concat_conv)
+        if (y.H * 2, y.W * 2) != (skip.H, skip.W):
+            raise _lib.IdhError("decoder pyramid levels must differ by exactly x2")
+        cat = p.buffer(skip.N, skip.H, skip.W, cout + skip.C)
+        p.upsample2(y, cat.slice(0, cout), nearest=True)
+        p.copy(skip, cat.slice(cout, skip.C))  # torch.cat([x, cat_feats], 1), networks_fast.py:44
+        x = _conv_block(p, cat, blk.post_concat_conv)
+        final[3 - bi] = x
+    return final
+
+
+def build_any_decoder(p: Plan, dec, feats: List[View]) -> Dict[int, View]:
+    """UNet++ (BDDecoderPP / DepthDecoderPP) or skip decoder, by the structure of ``dec``."""
+    if hasattr(dec, "block1"):
+        return build_skip_decoder(p, dec, feats)
+    return build_decoder(p, dec, feats)
+
+
+def build_regression_heads(p: Plan, dec, final: Dict[int, View]) -> Dict[int, "tuple"]:
+    """SkipDecoderRegression heads (networks_fast.py:106-145): 1x1 conv -> ELU -> 1x1 conv -> ELU ->
+    1x1 conv to one channel, per scale.  Returns {scale: (View of the 128-ch penultimate map, last Conv2d)}."""
+    heads = {}
+    for i, seq in ((3, dec.out1), (2, dec.out2), (1, dec.out3), (0, dec.out4)):
+        v = final[i]
+        h1 = p.buffer(v.N, v.H, v.W, seq[0].out_channels)
+        p.conv(v, seq[0], h1, act=ACT_ELU)
+        h2 = p.buffer(v.N, v.H, v.W, seq[2].out_channels)
+        p.conv(h1, seq[2], h2, act=ACT_ELU)
+        heads[i] = (h2, seq[4])
+    return heads
+
+
+def skip_regression_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """SkipDecoderRegression.forward (networks_fast.py:137-145): feature maps + log-depth heads."""
+    _check_in(*input_features)
+    feats = [f.contiguous() for f in input_features]
+    key = ("skipreg", tuple(tuple(f.shape) for f in feats), str(feats[0].device), _param_key(dec))
+    cache = _plan_cache(dec)
+    ent = cache.get(key)
+    if ent is None:
+        cache.clear()
+        p = Plan(feats[0].device)
+        views, i_in = [], []
+        for f in feats:
+            v = p.buffer(f.shape[0], f.shape[2], f.shape[3], f.shape[1])
+            i_in.append(p.import_nchw(f.shape, v))
+            views.append(v)
+        final = build_skip_decoder(p, dec, views)
+        heads = build_regression_heads(p, dec, final)
+        i_feat = {i: p.export_nchw(v) for i, v in final.items()}
+        i_head = {i: p.head(hv, last, torch.empty(1, device=feats[0].device)) for i, (hv, last) in heads.items()}
+        p.schedule()
+        ent = (p, i_in, i_feat, i_head, final)
+        cache[key] = ent
+    p, i_in, i_feat, i_head, final = ent
+    for i, f in zip(i_in, feats):
+        p.set_in(i, f)
+    res = {}
+    dev = feats[0].device
+    for i, v in final.items():
+        t = torch.empty(v.N, v.C, v.H, v.W, device=dev)
+        p.set_out(i_feat[i], t)
+        res[f"feature_s{i}_b1hw"] = t
+        d = torch.empty(v.N, 1, v.H, v.W, device=dev)
+        p.set_out(i_head[i], d)
+        res[f"log_depth_pred_s{i}_b1hw"] = d
+    p.run()
+    return res

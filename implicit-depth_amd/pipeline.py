@@ -58,11 +58,14 @@ class HotPath(nn.Module):
         i_enc = [p.import_nchw(enc_shapes[0], v0)]
         outs, i_img = nhwc.build_cv_encoder(p, self.cost_volume_net, cv_in, enc_shapes[1:])
         i_enc += i_img
-        final = nhwc.build_decoder(p, self.depth_decoder, [v0] + outs)
+        final = nhwc.build_any_decoder(p, self.depth_decoder, [v0] + outs)
         ent = {"plan": p, "state": st, "cv_in": cv_in, "i_enc": i_enc, "final": final, "heads": {}}
         if getattr(self.depth_decoder, "depth_head", False):
             for i, v in final.items():
                 ent["heads"][i] = p.head(v, self.depth_decoder.convs[f"output_{i}"][1], torch.empty(1, device=device))
+        elif hasattr(self.depth_decoder, "out1"):  # SkipDecoderRegression
+            for i, (hv, last) in nhwc.build_regression_heads(p, self.depth_decoder, final).items():
+                ent["heads"][i] = p.head(hv, last, torch.empty(1, device=device))
         p.schedule()
         self._plans[key] = ent
         return ent

@@ -38,6 +38,7 @@ extern "C" {
 /* activation codes for the conv / MLP epilogues */
 #define IDH_ACT_NONE 0
 #define IDH_ACT_LRELU 1 /* LeakyReLU(slope) */
+#define IDH_ACT_ELU 2   /* ELU(alpha=1) */
 
 int idh_version(void);
 const char *idh_error_string(int code);

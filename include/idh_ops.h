@@ -25,6 +25,8 @@ enum {
     IDH_OP_NHWC_TO_NCHW = 4,/* strided layout export: NHWC slice -> (N,C,H,W)                */
     IDH_OP_SPLITK_REDUCE = 5,/* sum split-K partials + bias + residual + activation          */
     IDH_OP_POINTWISE_HEAD = 6,/* 1x1 conv to 1 channel (DepthDecoderPP heads, networks.py:158-161) */
+    IDH_OP_COPY = 9,        /* channel-strided NHWC -> NHWC slice copy */
+    IDH_OP_UPSAMPLE2_NEAREST = 8, /* nearest x2 (SkipDecoder, networks_fast.py:43) */
     IDH_OP_INSTNORM = 7     /* nn.InstanceNorm2d (no affine, eps 1e-5) [+ LeakyReLU] on NHWC; matching-encoder
                                head networks.py:279-283.  ws: N*ceil(HW/1024)*2*C floats */
 };

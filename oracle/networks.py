@@ -192,3 +192,29 @@ def matching_head(x_b64hw: torch.Tensor, w: W, first: int = 5) -> torch.Tensor:
     h = F.pad(h, (1, 1, 1, 1), mode="replicate")
     h = F.conv2d(h, w[f"net.{first + 3}.weight"], w[f"net.{first + 3}.bias"])
     return instance_norm(h)
+
+
+def _conv_block(x: torch.Tensor, w: W) -> torch.Tensor:
+    """networks_fast.py:10-28: conv3x3-ELU-conv3x3-ELU."""
+    h = elu(F.conv2d(x, w["conv1.weight"], w["conv1.bias"], padding=1))
+    return elu(F.conv2d(h, w["conv2.weight"], w["conv2.bias"], padding=1))
+
+
+def skip_decoder(feats: List[torch.Tensor], w: W, regression: bool = False) -> Dict[str, torch.Tensor]:
+    """SkipDecoder / SkipDecoderRegression (networks_fast.py:49-145): per block ConvBlock -> nearest x2
+    -> cat(skip) -> ConvBlock; regression adds 1x1-ELU-1x1-ELU-1x1 heads per scale."""
+    out: Dict[str, torch.Tensor] = {}
+    x = feats[-1]
+    for bi in range(4):
+        bw = sub(w, f"block{bi + 1}")
+        x = _conv_block(x, sub(bw, "pre_concat_conv"))
+        x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)  # nearest x2
+        x = torch.cat([x, feats[-2 - bi]], 1)
+        x = _conv_block(x, sub(bw, "post_concat_conv"))
+        out[f"feature_s{3 - bi}_b1hw"] = x
+        if regression:
+            hw = sub(w, f"out{bi + 1}")
+            h = elu(F.conv2d(x, hw["0.weight"], hw["0.bias"]))
+            h = elu(F.conv2d(h, hw["2.weight"], hw["2.bias"]))
+            out[f"log_depth_pred_s{3 - bi}_b1hw"] = F.conv2d(h, hw["4.weight"], hw["4.bias"])
+    return out

@@ -219,6 +219,7 @@ def main():
     save("g6_geometry", planes64=planes64, planes96=planes96, pose_dist=pd, backproject=pts, project=pr)
     gen_bdmodel(syn)
     gen_matching_head(syn)
+    gen_skip_decoder(syn)
 
 
 def gen_bdmodel(syn):
@@ -277,6 +278,20 @@ def gen_matching_head(syn):
     x = syn.randn((3, 64, 24, 32), 41, "mh_x")
     y = enc.net[5:](x)
     save("g7_matching_head", y=y, keys=np.array(sorted(k for k in enc.state_dict() if k.split(".")[1] in ("5", "8"))))
+
+
+def gen_skip_decoder(syn):
+    """G8: SkipDecoder / SkipDecoderRegression (networks_fast.py) on the G3 decoder inputs."""
+    print("G8 skip decoders")
+    from modules.networks_fast import SkipDecoder, SkipDecoderRegression
+    pyr = syn.encoder_pyramid(1, 96, 128, seed=11)
+    enc = [torch.as_tensor(np.load(os.path.join(HERE, "g3_cvencoder.npz"))[f"o{i}"]) for i in range(4)]
+    feats = [pyr[0]] + enc
+    for cls, nm in ((SkipDecoder, "g8_skipdecoder"), (SkipDecoderRegression, "g8_skipdecoder_reg")):
+        dec = cls([24, 64, 128, 256, 384])
+        syn.fill_state_dict(dec, seed=45, gain=1.0)
+        out = dec(feats)
+        save(nm, **{k: v for k, v in out.items()}, keys=np.array(sorted(dec.state_dict())))
 
 
 if __name__ == "__main__":

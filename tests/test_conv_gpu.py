@@ -141,3 +141,19 @@ def test_matching_head_golden_and_layouts():
     img = syn.randn((2, 3, 48, 64), 42, "img").cuda()
     ref = onet.matching_head(enc.backbone(img).cpu().double(), {k: v.cpu().double() for k, v in enc.state_dict().items()})
     assert rel_err(enc(img).cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("reg", [False, True])
+def test_skip_decoder_golden(reg):
+    """SkipDecoder / SkipDecoderRegression (networks_fast.py): ELU convs, nearest x2, concat, 1x1 heads."""
+    from implicit_depth_amd import networks as net
+
+    g = load_golden("g8_skipdecoder_reg" if reg else "g8_skipdecoder")
+    dec = (net.SkipDecoderRegression if reg else net.SkipDecoder)([24, 64, 128, 256, 384])
+    syn.fill_state_dict(dec, seed=45)
+    pyr = syn.encoder_pyramid(1, 96, 128, seed=11)
+    enc = [torch.as_tensor(load_golden("g3_cvencoder")[f"o{i}"]) for i in range(4)]
+    out = dec.cuda()([t.cuda() for t in [pyr[0]] + enc])
+    assert sorted(out) == sorted(k for k in g if k != "keys")
+    for k in out:
+        assert rel_err(out[k].cpu(), g[k]) < TOL, k

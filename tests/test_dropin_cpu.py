@@ -25,6 +25,12 @@ def test_conversions_infer_structure_and_copy_weights():
         new = dropin.convert_decoder(dec)
         assert type(new) is cls
         _same_state(dec, new)
+    for cls in (net.SkipDecoder, net.SkipDecoderRegression):
+        dec = cls([24, 64, 128, 256, 384])
+        syn.fill_state_dict(dec, 5)
+        new = dropin.convert_decoder(dec)
+        assert type(new) is cls
+        _same_state(dec, new)
     for prior in (False, True):
         mlp = net.BinaryMLPNetwork([64, 64, 128, 256], use_prior=prior)
         syn.fill_state_dict(mlp, 3)

@@ -212,3 +212,19 @@ def test_fast_gather_equals_hand_rolled_taps():
     finally:
         ocv.FAST_GATHER = False
     assert rel_err(fast, slow) < 1e-6
+
+
+@pytest.mark.parametrize("reg", [False, True])
+def test_skip_decoder_matches_reference(reg):
+    from implicit_depth_amd import networks as net
+
+    g = load_golden("g8_skipdecoder_reg" if reg else "g8_skipdecoder")
+    dec = (net.SkipDecoderRegression if reg else net.SkipDecoder)([24, 64, 128, 256, 384])
+    syn.fill_state_dict(dec, seed=45)
+    w = dict(dec.state_dict())
+    assert sorted(w) == list(g["keys"])
+    pyr = syn.encoder_pyramid(1, 96, 128, seed=11)
+    enc = [torch.as_tensor(load_golden("g3_cvencoder")[f"o{i}"]) for i in range(4)]
+    out = onet.skip_decoder([pyr[0]] + enc, w, regression=reg)
+    for k in out:
+        assert rel_err(out[k], g[k]) < 5e-5, k
