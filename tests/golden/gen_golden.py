@@ -220,6 +220,7 @@ def main():
     gen_bdmodel(syn)
     gen_matching_head(syn)
     gen_skip_decoder(syn)
+    gen_depthmodel(syn)
 
 
 def gen_bdmodel(syn):
@@ -267,6 +268,55 @@ def gen_bdmodel(syn):
         save(name, K=np.array(K), pred_0=out["pred_0"], lowest_cost=out["lowest_cost_bhw"], matching_cur=captured["mc"],
              matching_src=captured["ms"], **{f"enc{i}": e for i, e in enumerate(captured["enc"])}, **extra,
              keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))))
+
+
+def gen_depthmodel(syn):
+    """G9: the reference's DepthModel.forward (SimpleRecon regression baseline, depth_model.py:280-440)
+    with stand-in backbones: mlp_feature_volume K=2 (DepthModel passes num_source_views) + DepthDecoderPP."""
+    print("G9 DepthModel.forward (stub backbones)")
+    import contextlib, io
+    k = sys.modules["kornia"]
+    for name in ("losses", "geometry", "utils"):
+        setattr(k, name, _stub("kornia." + name))
+    try:
+        from options import Options
+        from experiment_modules.depth_model import DepthModel
+    except Exception as e:
+        print("  DepthModel golden skipped (import):", repr(e))
+        return
+    K = 2
+    o = Options()
+    o.image_width, o.image_height = 128, 96
+    o.matching_num_depth_bins = 16
+    o.feature_volume_type = "mlp_feature_volume"
+    o.model_num_views = K + 1
+    torch.nn.Module.save_hyperparameters = lambda self, *a, **k: None
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = DepthModel(o)
+    except Exception as e:
+        print("  DepthModel golden skipped (ctor):", repr(e))
+        return
+    model.eval()
+    syn.fill_state_dict(model, seed=33, gain=1.0)
+    cur, src = syn.frame_tuple(1, K, 96, 128, seed=34, P=1)
+    captured = {}
+    orig = model.compute_matching_feats
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        captured["mc"], captured["ms"] = r
+        return r
+    model.compute_matching_feats = spy
+    enc_orig = model.encoder.forward
+    def enc_spy(x):
+        r = enc_orig(x)
+        captured["enc"] = r
+        return r
+    model.encoder.forward = enc_spy
+    out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+    keep = {k: v for k, v in out.items() if torch.is_tensor(v) and (k.startswith("log_depth_pred") or k.startswith("depth_pred") or k in ("lowest_cost_bhw", "overall_mask_bhw"))}
+    save("g9_depthmodel", K=np.array(K), matching_cur=captured["mc"], matching_src=captured["ms"], **{f"enc{i}": e for i, e in enumerate(captured["enc"])}, **keep,
+         keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder"))))
 
 
 def gen_matching_head(syn):

@@ -51,3 +51,36 @@ def test_hot_path_reproduces_reference_bdmodel_forward(volume):
         assert (out["overall_mask_bhw"].cpu() != torch.as_tensor(g["overall_mask"])).float().mean().item() < 2e-3
     else:
         assert out["overall_mask_bhw"] is None
+
+
+def test_hot_path_reproduces_reference_depthmodel_forward():
+    """DepthModel.forward (SimpleRecon regression baseline, depth_model.py:280-440), golden G9:
+    MLP feature volume built with num_source_views=K (K=2 here), DepthDecoderPP heads, exp()."""
+    from implicit_depth_amd import cost_volume as cv
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd.dropin import hot_path_of
+
+    g = load_golden("g9_depthmodel")
+    K = int(g["K"])
+    h = nn.Module()
+    H, W, D = 24, 32, 16
+    h.cost_volume = cv.FeatureVolumeManager(H, W, D, num_source_views=K)
+    h.cost_volume_net = net.CVEncoder(D, [48, 64, 160, 256], [64, 128, 256, 384])
+    h.depth_decoder = net.DepthDecoderPP([24] + h.cost_volume_net.num_ch_enc)
+    syn.fill_state_dict(h, seed=33)
+    assert sorted(h.state_dict()) == list(g["keys"])
+    h.cuda()
+    cur, src = syn.frame_tuple(1, K, 96, 128, seed=34, P=1)
+    cur = {k: v.cuda() for k, v in cur.items()}
+    src = {k: v.cuda() for k, v in src.items()}
+    src_cam_T_cur_cam = src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1)
+    cur_cam_T_src_cam = cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"]
+    hot = hot_path_of(h)
+    t = lambda name: torch.as_tensor(g[name]).cuda()
+    out = hot(t("matching_cur"), t("matching_src"), [t(f"enc{i}") for i in range(5)], src_cam_T_cur_cam, cur_cam_T_src_cam,
+              src["K_s1_b44"], cur["invK_s1_b44"], return_mask=True)
+    for i in range(4):
+        assert rel_err(out[f"log_depth_pred_s{i}_b1hw"].cpu(), g[f"log_depth_pred_s{i}_b1hw"]) < TOL
+        assert rel_err(out[f"depth_pred_s{i}_b1hw"].cpu(), g[f"depth_pred_s{i}_b1hw"]) < 5 * TOL  # exp() amplifies
+    assert ((out["lowest_cost_bhw"].cpu() - torch.as_tensor(g["lowest_cost_bhw"])).abs() > 1e-5).float().mean().item() < 5e-3
+    assert (out["overall_mask_bhw"].cpu() != torch.as_tensor(g["overall_mask_bhw"])).float().mean().item() < 2e-3
