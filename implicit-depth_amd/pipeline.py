@@ -257,8 +257,17 @@ class HotPathWorkload:
         return dom_res, all_res
 
     def metrics(self):
+        """Per-frame metric rows (B, 120): PlaneEvaluator IoU / IoU+ / IoU- for 5 thresholds x 8 query
+        planes against a synthetic ground-truth depth — the shape of the dict test_bd.py:288-339
+        builds per frame, computed on the GPU (csrc/metrics.hip) and then all-gathered."""
+        import implicit_depth_amd.synthetic as syn
+        from .metrics import PlaneEvaluator, metric_rows
+
         o = self.out
-        return torch.stack([torch.sigmoid(o["pred_0"]).mean((1, 2, 3)), o["lowest_cost_bhw"].mean((1, 2))], 1)
+        B, P, H, W = o["pred_0"].shape
+        gt = (1.0 + 3.5 * torch.sigmoid(syn.randn((B, 1, H, W), 7, "bench_gt"))).to(o["pred_0"].device)
+        rows, self.metric_keys = metric_rows(PlaneEvaluator().compute_batch_scores(self.rd, gt, torch.sigmoid(o["pred_0"])))
+        return rows
 
     def cpu_baseline(self, seconds):
         """oracle (torch CPU fp32 restatement) of the same path, one frame at a time."""

@@ -138,6 +138,21 @@ int idh_sample_prior_fwd(const float *rendered_depth_bphw, const float *prior_pr
                          const float *K_44, const float *invK_44, int B, int P, int H, int W,
                          float *out_bphw, void *stream);
 
+/* ---- evaluation metrics (the step right after the path; rows of the metrics all-gather) ---- */
+/* Plane IoU — PlaneEvaluator.compute_batch_scores / compute_batch_scores_test (reference
+ * utils/binary_metrics_utils.py:59-192): out[b,d,t,{iou, iou_pos, iou_neg}] over pixels with gt > 0 and
+ * query > 0; target = query < gt; prediction = pred > threshold.  Either T (<= 8) constant thresholds
+ * (bins == NULL) or the per-depth Thresholder (:42-52): bins (n_bins sorted edges), thresholds has
+ * n_bins entries, T must be 1.  Depth metrics — compute_depth_metrics_batched (utils/metrics_utils.py:52-120):
+ * out[b, 12] = abs_diff, abs_rel, sq_rel, rmse, rmse_log, a5, a10, a25, a0, a1, a2, a3 over valid_bn != 0.
+ * workspace >= idh_metrics_workspace_bytes(B, D, N, T) (8-byte aligned). */
+size_t idh_metrics_workspace_bytes(int B, int D, int N, int T);
+int idh_plane_iou_fwd(const float *query_depth_bdn, const float *gt_depth_b1n, const float *prediction_bdn,
+                      const float *thresholds, int T, const float *bins, int n_bins, int B, int D, int N,
+                      float *out_bdt3, void *workspace, size_t workspace_bytes, void *stream);
+int idh_depth_metrics_fwd(const float *gt_bn, const float *pred_bn, const unsigned char *valid_bn, int B, int N,
+                          int mult_a, float *out_b12, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

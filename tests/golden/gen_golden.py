@@ -221,6 +221,7 @@ def main():
     gen_matching_head(syn)
     gen_skip_decoder(syn)
     gen_depthmodel(syn)
+    gen_metrics(syn)
 
 
 def gen_bdmodel(syn):
@@ -317,6 +318,46 @@ def gen_depthmodel(syn):
     keep = {k: v for k, v in out.items() if torch.is_tensor(v) and (k.startswith("log_depth_pred") or k.startswith("depth_pred") or k in ("lowest_cost_bhw", "overall_mask_bhw"))}
     save("g9_depthmodel", K=np.array(K), matching_cur=captured["mc"], matching_src=captured["ms"], **{f"enc{i}": e for i, e in enumerate(captured["enc"])}, **keep,
          keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder"))))
+
+
+def metric_inputs(syn, B=2, D=8, H=24, W=32):
+    q = syn.rendered_depth_planes(B, H, W, D).clone()
+    q[:, 2, :3, :5] = -1.0                      # masked-out query pixels (surface/boundary style)
+    gt = 1.0 + 3.5 * torch.sigmoid(syn.randn((B, 1, H, W), 60, "gt"))
+    gt[:, :, -4:, :6] = 0.0                     # missing ground truth
+    pred = torch.sigmoid(1.5 * syn.randn((B, D, H, W), 61, "pred"))
+    return q, gt, pred
+
+
+def gen_metrics(syn):
+    """G10: PlaneEvaluator IoU scores (constant thresholds + per-depth Thresholder) and
+    compute_depth_metrics_batched from the reference's utils/."""
+    print("G10 evaluation metrics")
+    for name in ("pytorch3d", "pytorch3d.io", "pytorch3d.renderer", "pytorch3d.structures", "pytorch3d.utils"):
+        _stub(name)
+    sys.modules["pytorch3d.io"].load_ply = None
+    for n in ("FoVPerspectiveCameras", "HardFlatShader", "MeshRasterizer", "MeshRenderer", "RasterizationSettings", "TexturesAtlas", "TexturesVertex"):
+        setattr(sys.modules["pytorch3d.renderer"], n, None)
+    sys.modules["pytorch3d.structures"].Meshes = None
+    sys.modules["pytorch3d.utils"].cameras_from_opencv_projection = None
+    from utils.binary_metrics_utils import PlaneEvaluator, Thresholder
+    from utils.metrics_utils import compute_depth_metrics_batched
+    q, gt, pred = metric_inputs(syn)
+    ev = PlaneEvaluator()
+    sc = ev.compute_batch_scores(q, gt, pred, tag="surface")
+    keys = sorted(sc)
+    planes = torch.tensor([1.5 + 0.5 * x for x in range(8)])
+    thr = torch.linspace(0.35, 0.65, 8)
+    th = Thresholder.__new__(Thresholder)
+    th.bins = torch.zeros_like(planes); th.bins[:-1] = (planes[1:] + planes[:-1]) / 2; th.bins[-1] = 100.0
+    th.thresholds = thr
+    sc2 = ev.compute_batch_scores_test(q, gt, pred, th)
+    keys2 = sorted(sc2)
+    valid = gt.flatten(1) > 0.5
+    dm = compute_depth_metrics_batched(gt.flatten(1), (gt * (1 + 0.2 * syn.randn(gt.shape, 62, "noise"))).clamp_min(0.1).flatten(1), valid)
+    keys3 = sorted(dm)
+    save("g10_metrics", iou_keys=np.array(keys), iou=torch.stack([sc[k] for k in keys], 1), iou_thr_keys=np.array(keys2),
+         iou_thr=torch.stack([sc2[k] for k in keys2], 1), thr_values=thr, dm_keys=np.array(keys3), dm=torch.stack([dm[k] for k in keys3], 1))
 
 
 def gen_matching_head(syn):

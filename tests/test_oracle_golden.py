@@ -228,3 +228,32 @@ def test_skip_decoder_matches_reference(reg):
     out = onet.skip_decoder([pyr[0]] + enc, w, regression=reg)
     for k in out:
         assert rel_err(out[k], g[k]) < 5e-5, k
+
+
+def _metric_inputs(B=2, D=8, H=24, W=32):
+    q = syn.rendered_depth_planes(B, H, W, D).clone()
+    q[:, 2, :3, :5] = -1.0
+    gt = 1.0 + 3.5 * torch.sigmoid(syn.randn((B, 1, H, W), 60, "gt"))
+    gt[:, :, -4:, :6] = 0.0
+    pred = torch.sigmoid(1.5 * syn.randn((B, D, H, W), 61, "pred"))
+    return q, gt, pred
+
+
+def test_metrics_oracle_matches_reference():
+    from oracle import metrics as om
+
+    g = load_golden("g10_metrics")
+    q, gt, pred = _metric_inputs()
+    thr = [0.3, 0.4, 0.5, 0.6, 0.7]
+    iou = om.plane_iou(q, gt, pred, np.linspace(0.3, 0.7, 5).tolist())
+    planes = [1.5 + 0.5 * x for x in range(8)]
+    got = {}
+    for t, tv in enumerate(np.linspace(0.3, 0.7, 5)):
+        for d in range(8):
+            for j, kind in enumerate(("iou", "iou_pos", "iou_neg")):
+                got[f"surface_{kind}_{tv:.1f}_d_{planes[d]:.1f}"] = iou[:, d, t, j]
+    keys = list(g["iou_keys"])
+    assert sorted(got) == keys
+    np.testing.assert_allclose(torch.stack([got[k] for k in keys], 1).numpy(), g["iou"], rtol=1e-6, equal_nan=True)
+    dm = om.depth_metrics(gt.flatten(1), (gt * (1 + 0.2 * syn.randn(gt.shape, 62, "noise"))).clamp_min(0.1).flatten(1), gt.flatten(1) > 0.5)
+    np.testing.assert_allclose(torch.stack([dm[k] for k in g["dm_keys"]], 1).float().numpy(), g["dm"], rtol=2e-5)
