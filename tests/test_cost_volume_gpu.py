@@ -125,3 +125,26 @@ def test_non_contiguous_matrix_arguments():
         assert not dev[key].is_contiguous()
     cv = CostVolumeManager(H, W, D).cuda()(**dev)[0]
     assert rel_err(cv.cpu(), ref) < TOL
+
+
+def test_empty_batch_and_limits():
+    """B = 0 is a no-op with correctly shaped outputs; documented limits fail loudly."""
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd.cost_volume import CostVolumeManager, FeatureVolumeManager
+
+    inp = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 2, 16, 8, 8, 0).items()}
+    empty = {k: (v[:0] if v.shape[0] == 1 and k not in ("min_depth", "max_depth") else v) for k, v in inp.items()}
+    cv, low, planes, mask = CostVolumeManager(8, 8, 4).cuda()(**empty)
+    assert cv.shape == (0, 4, 8, 8) and low.shape == (0, 8, 8)
+    # D at the kernel's table limit, K at IDH_MAX_SOURCE_VIEWS
+    big = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 16, 16, 8, 8, 1).items()}
+    cv = CostVolumeManager(8, 8, 512).cuda()(**big)[0]
+    ref = ocv.cost_volume_dot(*[big[k].cpu() for k in ("cur_feats", "src_feats", "src_extrinsics", "src_Ks", "cur_invK")], 0.25, 5.0, 512)[0]
+    assert rel_err(cv.cpu(), ref) < TOL
+    with pytest.raises(_lib.IdhError):
+        CostVolumeManager(8, 8, 513).cuda()(**big)
+    # the MLP feature volume keeps W1/W2 LDS-resident: K <= 7
+    k8 = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 8, 16, 8, 8, 2).items()}
+    m = FeatureVolumeManager(8, 8, 4, num_source_views=8).cuda()
+    with pytest.raises(_lib.IdhError):
+        m(**k8)
