@@ -19,7 +19,7 @@
 //       - the 3K pose-distance inputs -> a per-batch-element bias (setup kernel).
 //   * layers are computed transposed (out^T = W . act^T, see csrc/mlp.hip) so activations stay in
 //     registers from the gather to the final dot product; W1 (per-voxel part) and W2 live in LDS in
-//     MFMA fragment order (152 KiB for K = 7) and are shared by the 8 waves of a persistent
+//     MFMA fragment order (152 KiB for K = 7, all 160 KiB for K = 8) and are shared by the 8 waves of a persistent
 //     workgroup; per plane a wave issues (K+4+8)*32 MFMAs.
 // Roofline: fp32 MFMA (2*D*N*(16K+64+128)*128 + ... ~ 66.6 GFLOP per 96x128x64 frame).
 #include "idh_common.h"
@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kC = 16;
 constexpr int kHid = 128;
 constexpr int kNS = 8;            // 128 / 16
-constexpr int kMaxK = 7;          // LDS budget: (K+4)*8 KiB + 64 KiB + 1 KiB <= 160 KiB
+constexpr int kMaxK = 8;          // LDS budget: (K+4)*8 KiB + 64 KiB = 160 KiB exactly at K = 8 (b2 / w3 stay in L1)
 
 // per-b workspace layout (floats): [0,96) hom[k][12]   [96,128) tsrc[k][4]   [128,137) invK 3x3
 //                                  [144, 144+128) bias1_b
@@ -58,7 +58,7 @@ __global__ void fv_setup_k(const float *__restrict__ src_K, const float *__restr
                            float *__restrict__ ws) {
     const int b = blockIdx.x, t = threadIdx.x;
     float *o = ws + (size_t)b * kWsStrideReal;
-    __shared__ float s_pd[3 * kMaxK];
+    __shared__ float s_pd[3 * kMaxK];  // kMaxK = 8
     if (t < K) {
         const float *Km = src_K + (size_t)(b * K + t) * 16, *Em = src_E + (size_t)(b * K + t) * 16;
         const float *iK = cur_invK + (size_t)b * 16, *Pm = src_poses + (size_t)(b * K + t) * 16;
@@ -118,18 +118,17 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4 *sW1 = reinterpret_cast<f32x4 *>(smem_raw);            // (K+4)*8*64
     f32x4 *sW2 = sW1 + (a.K + 4) * kNS * 64;                       // 8*8*64
-    float *sVec = reinterpret_cast<float *>(sW2 + kNS * kNS * 64); // 3*128 floats (b2, w3, b3)
     {
         const f32x4 *g1 = reinterpret_cast<const f32x4 *>(a.w1v);
         const f32x4 *g2 = reinterpret_cast<const f32x4 *>(a.w2);
         const int n1 = (a.K + 4) * kNS * 64, n2 = kNS * kNS * 64;
         for (int i = threadIdx.x; i < n1; i += 512) sW1[i] = g1[i];
         for (int i = threadIdx.x; i < n2; i += 512) sW2[i] = g2[i];
-        for (int i = threadIdx.x; i < 3 * kHid; i += 512) sVec[i] = a.vecs[i];
     }
     __syncthreads();
-    const float *s_b2 = sVec, *s_w3 = sVec + kHid;
-    const float b3 = sVec[2 * kHid];
+    // b2 / w3 / b3 (1 KiB) are read through L1: at K = 8 the weights use the whole 160 KiB of LDS
+    const float *s_b2 = a.vecs, *s_w3 = a.vecs + kHid;
+    const float b3 = a.vecs[2 * kHid];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -403,7 +402,7 @@ extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nh
     const long long ntasks = pix_tasks * a.G;
     int grid = (int)((ntasks + 7) / 8);
     if (grid > 256) grid = 256;  // persistent: one 512-thread workgroup per CU (LDS-resident weights)
-    const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4) + 3 * kHid * sizeof(float);
+    const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -71,7 +71,7 @@ int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const 
 
 /* ---- plane-sweep MLP feature volume ---------------------------------------------------- */
 /* Replaces FeatureVolumeManager.build_cost_volume + forward (reference
- * modules/cost_volume.py:437-706, 324-358) for K <= 7 source views, C = 16, hidden width 128:
+ * modules/cost_volume.py:437-706, 324-358) for K <= 8 source views, C = 16, hidden width 128:
  *   vol[b,d,y,x] = MLP([warped src feats (16K), cur feats (16), mask (K), depths (K), plane depth,
  *                       dot products (K), ray angles (K), rays (3(K+1)), pose distances (3K)])
  * with MLP = Linear -> LeakyReLU(.01) -> Linear -> LeakyReLU(.01) -> Linear (networks.py:218-233).

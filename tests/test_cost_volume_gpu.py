@@ -143,8 +143,8 @@ def test_empty_batch_and_limits():
     assert rel_err(cv.cpu(), ref) < TOL
     with pytest.raises(_lib.IdhError):
         CostVolumeManager(8, 8, 513).cuda()(**big)
-    # the MLP feature volume keeps W1/W2 LDS-resident: K <= 7
-    k8 = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 8, 16, 8, 8, 2).items()}
-    m = FeatureVolumeManager(8, 8, 4, num_source_views=8).cuda()
+    # the MLP feature volume keeps W1/W2 LDS-resident: K <= 8 (160 KiB)
+    k9 = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 9, 16, 8, 8, 2).items()}
+    m = FeatureVolumeManager(8, 8, 4, num_source_views=9).cuda()
     with pytest.raises(_lib.IdhError):
-        m(**k8)
+        m(**k9)

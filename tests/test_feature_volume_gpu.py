@@ -36,7 +36,7 @@ def test_matches_reference_golden(name):
     assert m(**{k: v.cuda() for k, v in inp.items()})[3] is None
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 9, 13, 3), (2, 5, 17, 23, 6), (1, 7, 24, 32, 64), (3, 4, 8, 8, 2)])
+@pytest.mark.parametrize("shape", [(1, 1, 9, 13, 3), (2, 5, 17, 23, 6), (1, 7, 24, 32, 64), (3, 4, 8, 8, 2), (1, 8, 12, 20, 5)])
 def test_matches_oracle_fp64(shape):
     B, K, H, W, D = shape
     inp = syn.cost_volume_inputs(B, K, 16, H, W, seed=K, behind_view=K - 1 if K > 2 else -1, big_rotation_view=0 if K > 3 else -1)
