@@ -3,8 +3,8 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
 
-One "step" = one pass of the hot path over one batch of B synthetic frames per GPU (weak
-scaling: per-GPU batch fixed).  Inputs are generated once and are resident in HBM before the
+One "step" = one pass of the hot path over the GLOBAL batch of 32 synthetic frames (BASELINE.json
+configs[3]), sharded by frame over the GPUs (strong scaling: total work fixed, 32/N frames per GPU).  Inputs are generated once and are resident in HBM before the
 timed region.  For N>1 launch with torch.distributed.run (one rank per GPU, RCCL); the batch
 dimension is sharded, there is no data-path collective, and the only message is an
 all-gather of per-frame metric vectors after the timed region.
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="auto", help="auto | warp_match_dot | hot_path")
-    ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="GLOBAL frames per step (BASELINE.json configs[3]: batch_size=32), sharded over the GPUs")
     ap.add_argument("--views", type=int, default=0, help="source views K; 0 = 7 for --volume mlp (reference-native 8-frame tuple = 1 cur + 7 src), 8 for --volume dot (BASELINE.json literal)")
     ap.add_argument("--volume", default="mlp", choices=["mlp", "dot"], help="mlp = FeatureVolumeManager (every shipped BDModel config), dot = CostVolumeManager")
     ap.add_argument("--planes", type=int, default=64)
@@ -162,6 +162,13 @@ def main():
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # strong scaling: the global batch is fixed (32 ScanNet-shaped tuples) and sharded by frame
+    from implicit_depth_amd.dist import shard_range
+
+    global_batch = args.batch
+    lo, hi = shard_range(global_batch, world, rank)
+    args.batch = hi - lo  # frames of THIS rank
+    counts = [shard_range(global_batch, world, r)[1] - shard_range(global_batch, world, r)[0] for r in range(world)]
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun: exercise RCCL even at N=1
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -198,8 +205,8 @@ def main():
     # the path's only collective: all-gather of per-frame metric vectors (RCCL over xGMI)
     from implicit_depth_amd.dist import all_gather_metrics
 
-    m = all_gather_metrics(wl.metrics().float().contiguous(), counts=[wl.B] * world)
-    frames_total = wl.B * world * args.steps
+    m = all_gather_metrics(wl.metrics().float().contiguous(), counts=counts)
+    frames_total = global_batch * args.steps
 
     if rank == 0:
         if wl.bound == "hbm":
@@ -239,11 +246,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": wl.config(),
+            "config": dict(wl.config(), global_batch=global_batch),
             "roofline": roof,
             "gathered_metric_rows": int(m.shape[0]),
         }
