@@ -122,6 +122,10 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
 
     float best = -INFINITY;
     int bidx = d0 < D ? d0 : 0;
+    // NHWC output: batch 4 consecutive planes into one 16-byte store (4-byte stores into 256-byte
+    // pixel rows are partial-line writes: ~10x write amplification at the HBM counters)
+    float ob0 = 0.f, ob1 = 0.f, ob2 = 0.f, ob3 = 0.f;
+    const bool vec_ok = cost_cs > 0 && ((d0 & 3) == 0) && ((cost_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(cost) & 15) == 0);
     for (int d = d0; d < d1; ++d) {
         const float depth = s_planes[d];
         float acc = 0.f;
@@ -157,9 +161,16 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
             const float bot = fmaf(wx1, t11, wx0 * t10);
             acc += fmaf(wy1, bot, wy0 * top);
         }
-        if (live) {
-            if (cost_cs > 0) cost[((size_t)b * N + p) * cost_cs + d] = acc;
-            else cost[((size_t)b * D + d) * N + p] = acc;
+        if (cost_cs > 0) {
+            const int e = (d - d0) & 3;
+            ob0 = e == 0 ? acc : ob0; ob1 = e == 1 ? acc : ob1; ob2 = e == 2 ? acc : ob2; ob3 = e == 3 ? acc : ob3;
+            if (live && (e == 3 || d == d1 - 1)) {
+                float *o = cost + ((size_t)b * N + p) * cost_cs + (d - e);
+                if (e == 3 && vec_ok) *reinterpret_cast<float4 *>(o) = make_float4(ob0, ob1, ob2, ob3);
+                else { o[0] = ob0; if (e >= 1) o[1] = ob1; if (e >= 2) o[2] = ob2; if (e >= 3) o[3] = ob3; }
+            }
+        } else if (live) {
+            cost[((size_t)b * D + d) * N + p] = acc;
         }
         if (acc > best) { best = acc; bidx = d; }
     }

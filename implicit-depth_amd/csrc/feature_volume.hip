@@ -180,6 +180,8 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             }
         }
 
+        f32x4 ob = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool vec_ok = ((d0 & 3) == 0) && ((a.vol_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.vol) & 15) == 0);
 #pragma unroll 1
         for (int d = d0; d < d1; ++d) {
             const float depth = fv_depth_plane(d, a.D, a.dmin, a.dmax);
@@ -319,12 +321,22 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             }
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            if (q == 0 && live) {
-                if (a.vol_cs > 0) a.vol[((size_t)b * N + p) * a.vol_cs + d] = s + b3;
-                else a.vol[((size_t)b * a.D + d) * N + p] = s + b3;
-                // overall mask: the reference overwrites it every plane, the LAST plane survives
-                if (a.mask != nullptr && d == a.D - 1) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
+            const float val = s + b3;
+            if (a.vol_cs > 0) {
+                // NHWC output: collect 4 consecutive planes and write one 16-byte vector (a 4-byte store
+                // per plane into 256-byte pixel rows cost ~10x write amplification in the PMC counters)
+                const int e = (d - d0) & 3;
+                ob[0] = e == 0 ? val : ob[0]; ob[1] = e == 1 ? val : ob[1]; ob[2] = e == 2 ? val : ob[2]; ob[3] = e == 3 ? val : ob[3];
+                if (q == 0 && live && (e == 3 || d == d1 - 1)) {
+                    float *o = a.vol + ((size_t)b * N + p) * a.vol_cs + (d - e);
+                    if (e == 3 && vec_ok) *reinterpret_cast<f32x4 *>(o) = ob;
+                    else { o[0] = ob[0]; if (e >= 1) o[1] = ob[1]; if (e >= 2) o[2] = ob[2]; if (e >= 3) o[3] = ob[3]; }
+                }
+            } else if (q == 0 && live) {
+                a.vol[((size_t)b * a.D + d) * N + p] = val;
             }
+            // overall mask: the reference overwrites it every plane, the LAST plane survives
+            if (q == 0 && live && a.mask != nullptr && d == a.D - 1) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
         }
     }
 }
