@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libidh.so")
+# IDH_LIB: developer override used by the ablation builds of tools/abl_split.sh
+LIB_PATH = os.environ.get("IDH_LIB") or os.path.join(_HERE, "lib", "libidh.so")
 
 _lib = None
 
@@ -31,6 +32,8 @@ _SIGS = {
     "idh_nhwc_to_nchw_f32": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idh_packed_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "idh_pack_conv_weight": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "idh_packed_split_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "idh_pack_conv_weight_split": (C.c_int, [f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idh_sizeof_op": (C.c_size_t, []),
     "idh_run_ops": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "idh_packed_mlp_weight_floats": (C.c_size_t, [C.c_int]),

@@ -28,44 +28,15 @@
 //     residual + LeakyReLU are applied on the accumulators before the single store;
 //   * layers with too few tiles to fill 256 CUs (12x16 / 24x32 maps) split K over `split_k`
 //     waves that write raw partials; a reduce kernel applies the epilogue (deterministic, no atomics).
-#include "idh_common.h"
+#include "conv_args.h"
 #include "../../include/idh_ops.h"
+
+using namespace idh_conv;
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvSrc {
-    const float *in;
-    const float *w;
-    int cs, H, W, Cin;
-    int ks, stride, pad_mode, cblocks;  // cblocks = Cin_pad / 16
-};
-
-struct ConvArgs {
-    ConvSrc s[2];
-    const float *bias;
-    const float *res;
-    float *out;
-    float *ws;
-    int res_cs, out_cs;
-    int Ho, Wo, Cout, Cout_pad;
-    int M;  // N*Ho*Wo
-    int MT, NT, S;
-    int steps_total;
-    int act;
-    float slope;
-};
-
-__device__ __forceinline__ float act_apply(float v, int act, float slope) {
-    if (act == IDH_ACT_LRELU) return v < 0.f ? v * slope : v;
-    if (act == IDH_ACT_ELU) return v > 0.f ? v : expm1f(v);  // nn.ELU(alpha=1), networks_fast.py:17
-    return v;
-}
-
 // Zero page: out-of-image taps (zero padding) read from here instead of being predicated,
 // so the K loop is branch-free.  Must cover the widest Cin_pad (host-checked).
-constexpr int kZeroFloats = 4096;
 __device__ float g_zero_page[kZeroFloats];
 
 template <int TM, int TN>
@@ -710,7 +681,8 @@ inline int ceil16(int v) { return (v + 15) & ~15; }
 struct PreparedConv {
     ConvArgs a;
     LdsConvArgs la;
-    int lds_rows, tm, tn;
+    int lds_rows, tm, tn;  // lds_rows = 16: split-precision kernel, tm = IDH_SPLIT_* mode
+    int n_img;
     unsigned blocks;
     ReduceDesc red;  // valid when a.S > 1
 };
@@ -755,7 +727,15 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     const bool lds_ok = a.s[0].ks == 3 && a.s[0].stride == 1 && a.s[0].pad_mode == IDH_PAD_ZEROS && (op.Cout % kLT_N) == 0 &&
                         (!a.s[1].in || (a.s[1].ks == 1 && a.s[1].stride == 1)) && op.Wo >= kLT_W;
     pc.lds_rows = 0;
-    if (lds_ok && (op.tile_m == 8 || op.tile_m == 0 || op.tile_m == 9)) {
+    if (op.tile_m == IDH_SPLIT_BF16X6 || op.tile_m == IDH_SPLIT_F16X3) {
+        // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
+        if (!lds_ok || a.s[1].in || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1) return IDH_EUNSUPPORTED;
+        a.NT = op.Cout / 64;
+        pc.lds_rows = 16;
+        pc.tm = op.tile_m;
+        pc.n_img = op.N;
+        pc.blocks = 0;
+    } else if (lds_ok && (op.tile_m == 8 || op.tile_m == 0 || op.tile_m == 9)) {
         const int rows = op.tile_m == 9 ? 4 : 8;
         const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
         if (a.S > chunks) a.S = chunks;
@@ -787,6 +767,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
 }
 
 int launch_conv(const PreparedConv &pc, hipStream_t st) {
+    if (pc.lds_rows == 16) return launch_conv_split(pc.a, pc.n_img, pc.tm, st);
     if (pc.lds_rows == 8) hipLaunchKernelGGL(conv3x3_lds_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 4) hipLaunchKernelGGL(conv3x3_lds_k<1>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else {

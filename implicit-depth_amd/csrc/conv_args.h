@@ -1,0 +1,44 @@
+// Kernel-argument structs shared by the conv kernels (conv.hip: fp32 MFMA; conv_split.hip:
+// split-bf16 MFMA).  Internal to the library — the public descriptor is idh_op (include/idh_ops.h).
+#pragma once
+#include "idh_common.h"
+
+namespace idh_conv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvSrc {
+    const float *in;
+    const float *w;
+    int cs, H, W, Cin;
+    int ks, stride, pad_mode, cblocks;  // cblocks = Cin_pad / 16
+};
+
+struct ConvArgs {
+    ConvSrc s[2];
+    const float *bias;
+    const float *res;
+    float *out;
+    float *ws;
+    int res_cs, out_cs;
+    int Ho, Wo, Cout, Cout_pad;
+    int M;  // N*Ho*Wo
+    int MT, NT, S;
+    int steps_total;
+    int act;
+    float slope;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    if (act == IDH_ACT_LRELU) return v < 0.f ? v * slope : v;
+    if (act == IDH_ACT_ELU) return v > 0.f ? v : expm1f(v);  // nn.ELU(alpha=1), networks_fast.py:17
+    return v;
+}
+
+constexpr int kZeroFloats = 4096;
+
+// conv_split.hip
+constexpr int kSplitTile = 16;  // 16x16 output pixels x 64 channels per workgroup
+int launch_conv_split(const ConvArgs &a, int N, int mode, hipStream_t st);  // mode = IDH_SPLIT_*
+
+}  // namespace idh_conv

@@ -1,0 +1,441 @@
+// 3x3 stride-1 convolution on the 16-bit matrix cores with fp32-equivalent results ("split
+// precision").  gfx950 runs bf16 / f16 MFMA at 16x the fp32-MFMA rate (2.5 PFLOP/s vs 157 TFLOP/s
+// dense) and has no TF32, so the fp32 operands are expanded into 16-bit pieces whose cross
+// products are accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16}.  Opt-in (IDH_OP_CONV with
+// tile_m = 10 / 11); the default path stays on v_mfma_f32_16x16x4_f32.
+//
+//  MODE_BF16X6 (tile_m = 10): x = x0 + x1 + x2 EXACTLY, three truncated bf16 pieces (8+8+8 bits,
+//     bf16 keeps fp32's exponent range so no scaling is involved).  x*w expands into 9 products;
+//     the 6 with piece-index sum <= 2 carry everything above 2^-24 relative:
+//     x0w0 + x0w1 + x1w0 + x0w2 + x1w1 + x2w0.  Every bf16 product is exact in fp32.
+//  MODE_F16X3 (tile_m = 11): x/s = x0 + x1, two round-to-nearest f16 pieces (11+11 bits + sign:
+//     |x/s - x0 - x1| <= 2^-23 |x/s|), products x0w0 + x0w1 + x1w0 (the dropped x1w1 is 2^-22).
+//     f16 has a 5-bit exponent, so operands are scaled by exact powers of two into [2^14, 2^15):
+//     weights per output channel at pack time, activations per 18x18x16 halo chunk by the running
+//     maximum of the workgroup's chunk maxima (the accumulators are rescaled, again by an exact
+//     power of two, when that maximum grows).  Elements more than 2^18 below the running maximum
+//     fall into f16's subnormal range and keep an absolute error of 2^-40 of that maximum.
+//  Measured against fp64 (tests/test_conv_split_gpu.py): both modes err by ~4e-7 of the output
+//  scale at K = 576..1728, the fp32-MFMA kernel by ~5e-7 (bar: 1e-4).
+//
+// Shape family: the layers that carry the flops of CVEncoder / UNet++ (layers.py:59-95): 3x3,
+// stride 1, zero padding, Cout % 64 == 0, one source.
+//
+// Workgroup = 16x16 output pixels x 64 channels.  D^T = W * X^T: weights are the A operand, so a
+// lane ends up with 4 consecutive output channels of one pixel -> 16-byte NHWC stores.
+// Per 16-channel K chunk the 18x18 halo is split into pieces while it is written to LDS
+//     sH[piece][kg 2][18*18 (+4 pad)] x 16 B   (kg = which 8 of the 16 channels; one slot = one
+//                                                MFMA operand of one pixel)
+// and per (chunk, tap row) the pre-split weight panel (packed by idh_pack_conv_weight_split in
+// exactly this order) is copied to one of two LDS buffers
+//     sW[buf 2][tap-in-row 3][piece][kg 2][co 64] x 16 B
+// so a phase = 3 taps between barriers; the weight buffer is double-buffered (one barrier per
+// phase), the halo single-buffered (one extra barrier per chunk); global loads for the next phase /
+// chunk are register-prefetched under the MFMAs.
+#include <stdlib.h>
+
+#include "conv_args.h"
+#include "../../include/idh_ops.h"
+
+using namespace idh_conv;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int MODE_BF16X6 = 0, MODE_F16X3 = 1;
+constexpr int kHalo = kSplitTile + 2;    // 18
+constexpr int kHaloPix = kHalo * kHalo;  // 324
+constexpr int kPlane = 328;              // slots per (piece, kg) plane: 328*16 B = bank offset 32 -> conflict-free b64 writes
+constexpr int kMinExp = -100;            // lower clamp of the scaling exponents (all-zero tiles)
+
+constexpr int pieces_of(int mode) { return mode == MODE_BF16X6 ? 3 : 2; }
+constexpr int wslots_of(int mode) { return 3 * pieces_of(mode) * 2 * 64; }  // 16-B slots per (chunk, tap row, 64-channel tile)
+constexpr int lds_bytes_of(int mode) { return (pieces_of(mode) * 2 * kPlane + 2 * wslots_of(mode)) * 16 + 64; }
+
+__device__ float g_zero16[16];
+
+// x = h0 + h1 + h2 exactly; the bf16 payload of each piece is the top half of the returned word.
+__device__ __forceinline__ void split3_bf16(float x, unsigned &h0, unsigned &h1, unsigned &h2) {
+    const unsigned u0 = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(u0);
+    const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(u1);
+    h0 = u0;
+    h1 = u1;
+    h2 = __float_as_uint(r2);
+}
+// {bf16(lo), bf16(hi)} -> one dword (element 0 in the low half)
+__device__ __forceinline__ unsigned pack2_hi(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// x (already scaled into f16 range) ~= h0 + h1, both round-to-nearest-even
+__device__ __forceinline__ void split2_f16(float x, _Float16 &h0, _Float16 &h1) {
+    h0 = (_Float16)x;
+    h1 = (_Float16)(x - (float)h0);
+}
+__device__ __forceinline__ unsigned pack2_f16(_Float16 lo, _Float16 hi) {
+    f16x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float exp2_int(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }  // e in [-126, 127]
+// floor(log2(v)) for finite v > 0 from the exponent field, clamped below; inf/nan -> 128
+__device__ __forceinline__ int exponent_of(unsigned bits) {
+    const int e = (int)((bits >> 23) & 0xFF) - 127;
+    return e < kMinExp ? kMinExp : e;
+}
+
+// WAVES = 4: each wave owns 4 tile rows (2 pixel groups, 64 accumulator registers), 2 waves per SIMD;
+// WAVES = 8: each wave owns 2 tile rows (1 pixel group, 32 accumulators, <= 128 VGPRs), 4 waves per SIMD.
+template <int WAVES, int MODE>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void conv3x3_split_k(const ConvArgs a, int tiles_x, int tiles_y) {
+    constexpr int NP = pieces_of(MODE);
+    constexpr int kWSlots = wslots_of(MODE);
+    constexpr int kHaloSlots = NP * 2 * kPlane;
+    constexpr int NT_ = 64 * WAVES;                          // threads
+    constexpr int G = 8 / WAVES;                             // 32-pixel groups per wave
+    constexpr int kHaloLoads = (kHaloPix * 4 + NT_ - 1) / NT_;
+    constexpr int kWLoads = (kWSlots + NT_ - 1) / NT_;
+    constexpr int kWFullWaves = (kWSlots - (kWLoads - 1) * NT_) / 64;  // waves that own a slot in the last round
+    extern __shared__ u32x4 smem[];
+    u32x4 *sH = smem;
+    u32x4 *sW = smem + kHaloSlots;
+    float *sMax = reinterpret_cast<float *>(smem + kHaloSlots + 2 * kWSlots);  // [2][8] chunk maxima (MODE_F16X3)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31, kg = lane >> 5;
+    // lanes 16..31 (second tile row) take their 16 pixels rotated by 14: with the 18-slot row pitch
+    // this puts every ds_read_b128 lane group {0-3,12-15,20-27}, ... on 16 distinct bank quads
+    const int prow = p >> 4, px = (p - 2 * prow) & 15;
+
+    unsigned blk = idh_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = blk % a.NT; blk /= a.NT;
+    const int tx = blk % tiles_x; blk /= tiles_x;
+    const int ty = blk % tiles_y;
+    const int n = blk / tiles_y;
+    const int y0 = ty * kSplitTile, x0 = tx * kSplitTile;
+    const int n0 = nt * 64;
+    const ConvSrc &s = a.s[0];
+    const int nC = s.cblocks;
+    const int nPh = 3 * nC;
+
+    f32x16 acc[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[g][j][e] = 0.f;
+    int E = kMinExp - 20;  // MODE_F16X3: exponent of the running activation maximum (accumulator unit = 2^(E-14))
+
+    f32x4 ph_[kHaloLoads];
+    u32x4 pw_[kWLoads];
+    auto issue_halo = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < kHaloLoads; ++k) {
+            const int slot = tid + NT_ * k;
+            const int q = slot & 3, pix = slot >> 2;
+            const int hy = pix / kHalo, hx = pix - hy * kHalo;
+            const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+            const bool ok = (pix < kHaloPix) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            const float *src = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero16;
+            ph_[k] = *reinterpret_cast<const f32x4 *>(src);
+        }
+    };
+    // max |x| of this thread's prefetched halo values -> per-wave slot of parity `par`
+    auto publish_max = [&](int par) {
+        float m = 0.f;
+        bool bad = false;  // inf / nan must reach the scale (fmaxf drops nan)
+#pragma unroll
+        for (int k = 0; k < kHaloLoads; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m = fmaxf(m, fabsf(ph_[k][e]));
+                bad |= (__float_as_uint(ph_[k][e]) & 0x7F800000u) == 0x7F800000u;
+            }
+        if (bad) m = __uint_as_float(0x7F800000u);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) sMax[par * 8 + wave] = m;
+    };
+    auto commit_halo = [&](float mul) {
+        u32x2 *sH2 = reinterpret_cast<u32x2 *>(sH);
+#pragma unroll
+        for (int k = 0; k < kHaloLoads; ++k) {
+            const int slot = tid + NT_ * k;
+            const int q = slot & 3, pix = slot >> 2;
+            unsigned w[NP][2];
+            if constexpr (MODE == MODE_BF16X6) {
+                unsigned h[4][3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3_bf16(ph_[k][e], h[e][0], h[e][1], h[e][2]);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    w[pc][0] = pack2_hi(h[0][pc], h[1][pc]);
+                    w[pc][1] = pack2_hi(h[2][pc], h[3][pc]);
+                }
+            } else {
+                _Float16 h[4][2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2_f16(ph_[k][e] * mul, h[e][0], h[e][1]);
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    w[pc][0] = pack2_f16(h[0][pc], h[1][pc]);
+                    w[pc][1] = pack2_f16(h[2][pc], h[3][pc]);
+                }
+            }
+            if (pix < kHaloPix) {
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                    u32x2 v = {w[pc][0], w[pc][1]};
+                    sH2[((pc * 2 + (q >> 1)) * kPlane + pix) * 2 + (q & 1)] = v;
+                }
+            }
+        }
+    };
+    auto issue_w = [&](int ph) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(s.w) + ((size_t)ph * a.NT + nt) * kWSlots;
+#pragma unroll
+        for (int k = 0; k < kWLoads; ++k) {
+            const int slot = tid + NT_ * k;
+            pw_[k] = src[slot < kWSlots ? slot : kWSlots - 1];
+        }
+    };
+    auto commit_w = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < kWLoads; ++k)
+            if (k < kWLoads - 1 || wave < kWFullWaves) sW[buf * kWSlots + tid + NT_ * k] = pw_[k];
+    };
+    auto compute = [&](int r, int buf) {
+        const u32x4 *wb = sW + buf * kWSlots + kg * 64 + p;
+        const u32x4 *hb = sH + kg * kPlane + (2 * G * wave + prow + r) * kHalo + px;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            u32x4 A[2][NP], B[G][NP];
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) A[j][pc] = wb[((t * NP + pc) * 2) * 64 + 32 * j];
+#pragma unroll
+                for (int g = 0; g < G; ++g) B[g][pc] = hb[pc * 2 * kPlane + 2 * g * kHalo + t];
+            }
+            // smallest terms first; independent accumulators between dependent MFMAs
+            constexpr int kTerms = MODE == MODE_BF16X6 ? 6 : 3;
+            constexpr int kPa6[6] = {2, 0, 1, 1, 0, 0}, kPb6[6] = {0, 2, 1, 0, 1, 0};  // weight / activation piece
+            constexpr int kPa3[3] = {1, 0, 0}, kPb3[3] = {0, 1, 0};
+#pragma unroll
+            for (int m = 0; m < kTerms; ++m)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (MODE == MODE_BF16X6)
+                            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[j][kPa6[m]]),
+                                                                                __builtin_bit_cast(bf16x8, B[g][kPb6[m]]), acc[g][j], 0, 0, 0);
+                        else
+                            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[j][kPa3[m]]),
+                                                                               __builtin_bit_cast(f16x8, B[g][kPb3[m]]), acc[g][j], 0, 0, 0);
+                    }
+        }
+    };
+
+    issue_halo(0);
+    issue_w(0);
+    int ph = 0;
+#pragma unroll 1
+    for (int c = 0; c < nC; ++c) {
+        float mul = 1.f;
+        if constexpr (MODE == MODE_F16X3) {
+            publish_max(c & 1);
+            __syncthreads();  // every wave is done reading the previous chunk's halo; chunk maxima visible
+            float bm = sMax[(c & 1) * 8];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) bm = fmaxf(bm, sMax[(c & 1) * 8 + w]);
+            const int e = exponent_of(__builtin_amdgcn_readfirstlane(__float_as_uint(bm)));
+            if (e > E) {  // workgroup-uniform: the running maximum grew -> shrink the accumulators to the new unit
+                const int d = E - e;
+                const float f = d < -126 ? 0.f : exp2_int(d);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[g][j][i] *= f;
+                E = e;
+            }
+            mul = exp2_int(14 - E);
+        } else {
+            if (c > 0) __syncthreads();  // every wave is done reading the previous chunk's halo
+        }
+        commit_halo(mul);
+#pragma unroll
+        for (int r = 0; r < 3; ++r, ++ph) {
+            commit_w(ph & 1);
+            __syncthreads();
+            issue_w(ph + 1 < nPh ? ph + 1 : ph);  // unconditional (re-reads the last panel at the end)
+            if (r == 0) issue_halo(c + 1 < nC ? c + 1 : c);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ahead of the MFMAs that hide them
+            compute(r, ph & 1);
+        }
+    }
+
+    // epilogue: C/D of 32x32: column = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (channel)
+    const float *wscale = reinterpret_cast<const float *>(reinterpret_cast<const u32x4 *>(s.w) + (size_t)nPh * a.NT * kWSlots);
+    const float sx = MODE == MODE_F16X3 ? exp2_int(E - 14 < -126 ? -126 : E - 14) : 1.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int oy = y0 + 2 * G * wave + 2 * g + prow, ox = x0 + px;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t m = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+        float *o = a.out + m * a.out_cs;
+        const float *rp = a.res ? a.res + m * a.res_cs : nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int co = n0 + 32 * j + 8 * gg + 4 * kg;
+                f32x4 v = {acc[g][j][4 * gg], acc[g][j][4 * gg + 1], acc[g][j][4 * gg + 2], acc[g][j][4 * gg + 3]};
+                if constexpr (MODE == MODE_F16X3) v = (v * sx) * *reinterpret_cast<const f32x4 *>(wscale + co);
+                if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
+                if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
+                if (a.act != IDH_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act, a.slope);
+                }
+                *reinterpret_cast<f32x4 *>(o + co) = v;
+            }
+    }
+}
+
+// per output channel: exponent of max |w| (MODE_F16X3 weight scale); one workgroup per channel
+__global__ __launch_bounds__(256) void weight_exponent_k(const float *__restrict__ w, int *__restrict__ wexp, float *__restrict__ wscale,
+                                                         int per_cout) {
+    __shared__ float sm[256];
+    const int co = blockIdx.x;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < per_cout; i += 256) {
+        const float v = w[(size_t)co * per_cout + i];
+        m = fmaxf(m, fabsf(v));
+        if ((__float_as_uint(v) & 0x7F800000u) == 0x7F800000u) m = __uint_as_float(0x7F800000u);
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int e = exponent_of(__float_as_uint(sm[0]));
+        wexp[co] = e;
+        wscale[co] = exp2_int(e - 14 < -126 ? -126 : e - 14);  // epilogue factor: undoes w * 2^(14-e)
+    }
+}
+
+// OIHW fp32 -> [chunk][tap row][co tile][tap in row][piece][kg][co 64][8 x 16 bit], zero padded
+template <int MODE>
+__global__ __launch_bounds__(256) void pack_split_weight_k(const float *__restrict__ w, u32x4 *__restrict__ dst,
+                                                           const int *__restrict__ wexp, int Cout, int Cin, int nC, int NT) {
+    constexpr int NP = pieces_of(MODE);
+    constexpr int kWSlots = wslots_of(MODE);
+    const long long total = (long long)nC * 3 * NT * 3 * 2 * 64;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+        long long rr = i;
+        const int co = (int)(rr % 64); rr /= 64;
+        const int kg = (int)(rr % 2); rr /= 2;
+        const int t = (int)(rr % 3); rr /= 3;
+        const int nt = (int)(rr % NT); rr /= NT;
+        const int r = (int)(rr % 3);
+        const int c = (int)(rr / 3);
+        const int cout = 64 * nt + co, tap = 3 * r + t;
+        unsigned h[8][NP];
+        float mul = 1.f;
+        if constexpr (MODE == MODE_F16X3) mul = exp2_int(14 - wexp[cout]);
+        for (int e = 0; e < 8; ++e) {
+            const int ci = 16 * c + 8 * kg + e;
+            const float v = (ci < Cin && cout < Cout) ? w[((size_t)cout * Cin + ci) * 9 + tap] : 0.f;
+            if constexpr (MODE == MODE_BF16X6) {
+                split3_bf16(v, h[e][0], h[e][1], h[e][2]);
+            } else {
+                _Float16 a0, a1;
+                split2_f16(v * mul, a0, a1);
+                h[e][0] = __builtin_bit_cast(unsigned short, a0);
+                h[e][1] = __builtin_bit_cast(unsigned short, a1);
+            }
+        }
+        const size_t base = ((size_t)(c * 3 + r) * NT + nt) * kWSlots;
+        for (int pc = 0; pc < NP; ++pc) {
+            u32x4 v;
+            if constexpr (MODE == MODE_BF16X6)
+                v = (u32x4){pack2_hi(h[0][pc], h[1][pc]), pack2_hi(h[2][pc], h[3][pc]), pack2_hi(h[4][pc], h[5][pc]), pack2_hi(h[6][pc], h[7][pc])};
+            else
+                v = (u32x4){h[0][pc] | (h[1][pc] << 16), h[2][pc] | (h[3][pc] << 16), h[4][pc] | (h[5][pc] << 16), h[6][pc] | (h[7][pc] << 16)};
+            dst[base + ((t * NP + pc) * 2 + kg) * 64 + co] = v;
+        }
+    }
+}
+
+inline int ceil16i(int v) { return (v + 15) & ~15; }
+inline size_t panel_bytes(int mode, int Cout, int Cin) { return (size_t)(ceil16i(Cin) / 16) * 3 * (Cout / 64) * wslots_of(mode) * 16; }
+
+template <int WAVES, int MODE>
+int launch_one(const ConvArgs &a, int N, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_k<WAVES, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes_of(MODE)) != hipSuccess)
+            return IDH_ELAUNCH;
+        attr_done = true;
+    }
+    const int tiles_x = (a.Wo + kSplitTile - 1) / kSplitTile, tiles_y = (a.Ho + kSplitTile - 1) / kSplitTile;
+    const long long blocks = (long long)N * tiles_x * tiles_y * a.NT;
+    if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    hipLaunchKernelGGL((conv3x3_split_k<WAVES, MODE>), dim3((unsigned)blocks), dim3(64 * WAVES), lds_bytes_of(MODE), st, a, tiles_x,
+                       tiles_y);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
+
+}  // namespace
+
+namespace idh_conv {
+
+int launch_conv_split(const ConvArgs &a, int N, int mode, hipStream_t st) {
+    static const int waves = getenv("IDH_SPLIT_WAVES") ? atoi(getenv("IDH_SPLIT_WAVES")) : 8;
+    if (mode == IDH_SPLIT_BF16X6) return waves == 4 ? launch_one<4, MODE_BF16X6>(a, N, st) : launch_one<8, MODE_BF16X6>(a, N, st);
+    if (mode == IDH_SPLIT_F16X3) return waves == 4 ? launch_one<4, MODE_F16X3>(a, N, st) : launch_one<8, MODE_F16X3>(a, N, st);
+    return IDH_EINVAL;
+}
+
+}  // namespace idh_conv
+
+extern "C" size_t idh_packed_split_weight_bytes(int Cout, int Cin, int mode) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 64 || (mode != IDH_SPLIT_BF16X6 && mode != IDH_SPLIT_F16X3)) return 0;
+    const int m = mode == IDH_SPLIT_BF16X6 ? MODE_BF16X6 : MODE_F16X3;
+    return panel_bytes(m, Cout, Cin) + (size_t)Cout * 8;  // + per-channel scale floats + exponents
+}
+
+extern "C" int idh_pack_conv_weight_split(const float *w, void *dst, int Cout, int Cin, int mode, void *stream) {
+    if (!w || !dst || Cout <= 0 || Cin <= 0 || (mode != IDH_SPLIT_BF16X6 && mode != IDH_SPLIT_F16X3)) return IDH_EINVAL;
+    if (Cout % 64) return IDH_EUNSUPPORTED;
+    const int m = mode == IDH_SPLIT_BF16X6 ? MODE_BF16X6 : MODE_F16X3;
+    const int nC = ceil16i(Cin) / 16, NT = Cout / 64;
+    float *wscale = reinterpret_cast<float *>(static_cast<char *>(dst) + panel_bytes(m, Cout, Cin));
+    int *wexp = reinterpret_cast<int *>(wscale + Cout);
+    hipStream_t st = idh_stream(stream);
+    hipLaunchKernelGGL(weight_exponent_k, dim3(Cout), dim3(256), 0, st, w, wexp, wscale, Cin * 9);
+    IDH_CHECK_LAUNCH();
+    const long long total = (long long)nC * 3 * NT * 3 * 2 * 64;
+    int grid = idh_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    if (m == MODE_BF16X6)
+        hipLaunchKernelGGL(pack_split_weight_k<MODE_BF16X6>, dim3(grid), dim3(256), 0, st, w, reinterpret_cast<u32x4 *>(dst), wexp, Cout, Cin, nC, NT);
+    else
+        hipLaunchKernelGGL(pack_split_weight_k<MODE_F16X3>, dim3(grid), dim3(256), 0, st, w, reinterpret_cast<u32x4 *>(dst), wexp, Cout, Cin, nC, NT);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}

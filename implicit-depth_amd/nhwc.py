@@ -16,6 +16,7 @@ What the plans encode (reference modules/networks.py + modules/layers.py):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -120,6 +121,50 @@ def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
     return dst
 
 
+SPLIT_CODE = {"bf16x6": 10, "f16x3": 11}  # IDH_SPLIT_* of include/idh_ops.h == the op's tile_m
+
+
+def split_packed_weight(conv: nn.Conv2d, math: str) -> torch.Tensor:
+    """16-bit-piece copy of a 3x3 Conv2d weight in the LDS image order of csrc/conv_split.hip
+    (idh_pack_conv_weight_split); cached like ``packed_weight``."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device), math)
+    cached = getattr(conv, "_idh_packed_split", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    _lib.require_cuda_f32(w)
+    L = _bind()
+    co, ci, kh, kw = w.shape
+    n = L.idh_packed_split_weight_bytes(co, ci, SPLIT_CODE[math])
+    if kh != 3 or kw != 3 or n == 0:
+        raise _lib.IdhError("split-precision conv covers 3x3 kernels with Cout % 64 == 0")
+    dst = torch.empty(n // 4, device=w.device, dtype=torch.int32)
+    wc = w.detach().contiguous()
+    _lib.check(L.idh_pack_conv_weight_split(wc.data_ptr(), dst.data_ptr(), co, ci, SPLIT_CODE[math], _lib.stream_ptr()),
+               "idh_pack_conv_weight_split")
+    conv._idh_packed_split = (key, dst)
+    return dst
+
+
+# Arithmetic of the 3x3 stride-1 convs: "fp32" = v_mfma_f32_16x16x4_f32 everywhere (default);
+# "bf16x6" / "f16x3" = the layers of the split_eligible() family run on the 16-bit matrix cores
+# with every fp32 operand expanded into 3 bf16 / 2 scaled f16 pieces and the 6 / 3 significant
+# cross products accumulated in fp32 (csrc/conv_split.hip) — fp32-equivalent results at 6/16 resp.
+# 3/16 of the fp32-MFMA cost.
+MATH_MODES = ("fp32", "bf16x6", "f16x3")
+DEFAULT_MATH = os.environ.get("IDH_CONV_MATH", "fp32")
+SPLIT_MIN_BLOCKS = 256  # fewer 16x16x64 tiles than CUs: the fp32 kernels' finer tiles win
+
+
+def split_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> bool:
+    (v0, c0) = srcs[0]
+    if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64:
+        return False
+    if Wo < 16 or Ho < 16:
+        return False
+    return N * (-(-Ho // 16)) * (-(-Wo // 16)) * (cout // 64) >= SPLIT_MIN_BLOCKS
+
+
 TARGET_WAVES = 2048  # ~2 waves per SIMD over 256 CUs x 4 SIMDs
 MIN_WAVES = 1024
 
@@ -167,8 +212,11 @@ def choose_tiles(M: int, cout: int, steps: int):
 class Plan:
     """Ordered op list + owned buffers.  ``run()`` = one C-ABI call."""
 
-    def __init__(self, device):
+    def __init__(self, device, math: Optional[str] = None):
         self.device = device
+        self.math = DEFAULT_MATH if math is None else math
+        if self.math not in MATH_MODES:
+            raise _lib.IdhError(f"unknown conv math mode {self.math!r} (expected one of {MATH_MODES})")
         self.ops: List[Op] = []
         self.meta: List[dict] = []  # per op: regions read / written, for the level scheduler
         self.keep: List[torch.Tensor] = []  # buffers / packed weights referenced by raw pointer
@@ -194,13 +242,14 @@ class Plan:
         op.N = x.N
         srcs = [(x, conv)] + ([(x2, conv2)] if x2 is not None else [])
         steps = 0
+        use_split = self.math != "fp32" and split_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode)
         for i, (v, cv) in enumerate(srcs):
             ks, st = cv.kernel_size[0], cv.stride[0]
             if v.C != cv.in_channels:
                 raise _lib.IdhError(f"conv expects {cv.in_channels} input channels, view has {v.C}")
             if v.C % 16 and (v.c0 != 0 or v.cs != ceil16(v.C)):
                 raise _lib.IdhError("a conv input whose channel count is not a multiple of 16 must be a whole zero-padded buffer")
-            w = packed_weight(cv)
+            w = split_packed_weight(cv, self.math) if use_split else packed_weight(cv)
             self.keep.append(w)
             s = op.src[i]
             s.in_, s.w, s.cs, s.H, s.W, s.Cin = v.ptr, w.data_ptr(), v.cs, v.H, v.W, v.C
@@ -220,7 +269,9 @@ class Plan:
         op.Ho, op.Wo, op.Cout = out.H, out.W, conv.out_channels
         op.act, op.slope = act, slope
         M = out.N * out.H * out.W
-        if lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
+        if use_split:
+            tm, tn, split = SPLIT_CODE[self.math], 0, 1
+        elif lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
             chunks = sum(ceil16(v.C) // 16 for v, _ in srcs)
             tm, split = choose_lds_tile(out.N, out.H, out.W, conv.out_channels, chunks)
             tn = 0
@@ -336,6 +387,13 @@ class Plan:
             out = self.buffer(x.N, Ho, Wo, planes)
         if blk.downsample is None:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=x)
+        elif (self.math != "fp32" and blk.downsample[0].kernel_size[0] == 1 and st == 1
+              and split_eligible([(h, blk.conv2)], planes, x.N, Ho, Wo, PAD_ZEROS)):
+            # the split-precision kernel takes one source: the 1x1 projection runs on its own (fp32 MFMA)
+            # and enters conv2's epilogue as the residual
+            proj = self.buffer(x.N, Ho, Wo, planes)
+            self.conv(x, blk.downsample[0], proj)
+            self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=proj)
         else:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, x2=x, conv2=blk.downsample[0])
         return out
@@ -399,7 +457,7 @@ def _plan_cache(module: nn.Module) -> Dict:
 
 
 def _param_key(module: nn.Module):
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+    return (DEFAULT_MATH,) + tuple((p.data_ptr(), p._version) for p in module.parameters())
 
 
 def _check_in(*ts):

@@ -58,7 +58,10 @@ typedef struct idh_op {
     float slope;
     int32_t split_k;      /* 1 = no split */
     int32_t tile_m, tile_n; /* direct kernel: wave tile in 16-wide MFMA sub-tiles (1,2,4), 0 = auto;
-                               tile_m = 8 / 9 selects the LDS-staged kernel with 8- / 4-row tiles */
+                               tile_m = 8 / 9 selects the LDS-staged kernel with 8- / 4-row tiles;
+                               tile_m = IDH_SPLIT_BF16X6 / IDH_SPLIT_F16X3 selects the split-precision
+                               kernel (3x3 stride 1, one source, Cout % 64 == 0; src[0].w =
+                               idh_pack_conv_weight_split output of the same mode) */
     int32_t group;        /* != 0: consecutive conv ops with the same id are mutually independent and
                                may be launched as ONE grid (see Plan.schedule in nhwc.py) */
 } idh_op;
@@ -68,6 +71,20 @@ typedef struct idh_op {
  * dst must hold idh_packed_weight_floats(Cout,Cin,ks) floats. */
 size_t idh_packed_weight_floats(int Cout, int Cin, int ks);
 int idh_pack_conv_weight(const float *w_oihw, float *dst, int Cout, int Cin, int ks, void *stream);
+
+/* Split-precision convolution (csrc/conv_split.hip): fp32 operands expanded into 16-bit pieces,
+ * cross products accumulated in fp32 on the bf16 / f16 matrix cores — fp32-equivalent results
+ * (error ~4e-7 of the output scale, like an fp32 FMA chain) at 6/16 resp. 3/16 of the fp32-MFMA cost.
+ *   IDH_SPLIT_BF16X6: x = x0+x1+x2 exactly (3 bf16 pieces, no scaling), 6 products.
+ *   IDH_SPLIT_F16X3:  x/s = x0+x1 (2 f16 pieces, power-of-two scaling per output channel for the
+ *                     weights and per halo chunk for the activations), 3 products.
+ * Packed weights: [Cin_pad/16][tap row 3][Cout/64][tap in row 3][piece][ci half 2][co 64][8] 16-bit,
+ * followed by Cout per-channel scale floats and Cout exponents.  3x3 kernels, Cout % 64 == 0
+ * (IDH_EUNSUPPORTED otherwise). */
+#define IDH_SPLIT_BF16X6 10
+#define IDH_SPLIT_F16X3 11
+size_t idh_packed_split_weight_bytes(int Cout, int Cin, int mode);
+int idh_pack_conv_weight_split(const float *w_oihw, void *dst, int Cout, int Cin, int mode, void *stream);
 
 /* sizeof(idh_op) as compiled into the library (bindings assert their mirror matches). */
 size_t idh_sizeof_op(void);
