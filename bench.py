@@ -32,6 +32,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak (no xf32/TF32 on gfx950)
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # bf16 / f16 MFMA dense peak
 
 
 def parse():
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--conv-math", default="fp32", choices=["fp32", "bf16x6", "f16x3"],
+                    help="arithmetic of the 3x3 stride-1 convs: fp32 MFMA (default) or the fp32-equivalent split-precision kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -220,18 +223,27 @@ def main():
             # launches of the step as a secondary figure
             (dom_ms, dom_n, dom_fl), (all_ms, all_n, all_fl) = wl.conv_only_ms()
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+            math = getattr(wl, "conv_math", "fp32")
+            # split-precision convs execute 6 (bf16x6) / 3 (f16x3) 16-bit MFMA products per fp32-equivalent
+            # MAC: their roofline is the dense 16-bit MFMA peak divided by that count
+            peak = {"fp32": MFMA_F32_PEAK_TFLOPS, "bf16x6": MFMA_16BIT_PEAK_TFLOPS / 6, "f16x3": MFMA_16BIT_PEAK_TFLOPS / 3}[math]
+            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": None, "kernel": wl.dominant_kernel, "kernel_ms": dom_ms / dom_n, "launches_per_step": dom_n,
                     "kernel_ms_per_step": dom_ms, "algorithmic_flops_per_launch": dom_fl / dom_n,
-                    "all_conv_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "frac": all_fl / (all_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "all_conv_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "frac": all_fl / (all_ms * 1e-3) / 1e12 / peak,
                                          "launches_per_step": all_n, "ms_per_step": all_ms, "algorithmic_flops_per_step": all_fl},
                     "step_ms_hip_events": kernel_ms}
+            if math != "fp32":
+                roof["peak_note"] = (f"fp32-equivalent flops; peak = {MFMA_16BIT_PEAK_TFLOPS:.0f} TFLOP/s dense 16-bit MFMA / "
+                                     f"{6 if math == 'bf16x6' else 3} products per MAC; the fp32-MFMA peak is 157.3")
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the
         # process, so the figure comes from the committed rocprofv3 --pmc passes of this same command
         # (profiles/pmc_traffic.json, tools/pmc_bench.sh) when the configuration matches, else null.
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = f"{wl.name}/{getattr(wl, 'volume', 'dot')}/b{wl.B}" if wl.name == "hot_path" else f"{wl.name}/b{wl.B}"
+            if getattr(wl, "conv_math", "fp32") != "fp32":
+                key += "/" + wl.conv_math
             if key in pmc and (wl.name != "warp_match_dot" or (wl.K, wl.D) == (8, 64)):
                 roof["traffic"] = pmc[key]["traffic_bytes_per_launch"]
                 roof["traffic_source"] = "profiles/pmc_traffic.json"
@@ -248,7 +260,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"fp32": "f32", "bf16x6": "f32 (3x3 convs: bf16x3-split operands, 6 products, f32 accumulate)",
+                      "f16x3": "f32 (3x3 convs: scaled f16x2-split operands, 3 products, f32 accumulate)"}[getattr(wl, "conv_math", "fp32")],
             "data": "synthetic",
             "config": dict(wl.config(), global_batch=global_batch),
             "roofline": roof,

@@ -32,8 +32,10 @@ class HotPath(nn.Module):
     """Owns (or shares) the four hot-path modules of a BDModel / DepthModel."""
 
     def __init__(self, cost_volume: nn.Module, cost_volume_net: nn.Module, depth_decoder: nn.Module,
-                 binary_mlp: Optional[nn.Module] = None, min_depth: float = 0.25, max_depth: float = 5.0):
+                 binary_mlp: Optional[nn.Module] = None, min_depth: float = 0.25, max_depth: float = 5.0,
+                 conv_math: Optional[str] = None):
         super().__init__()
+        self.conv_math = conv_math  # None = nhwc.DEFAULT_MATH ("fp32"); "bf16x6" / "f16x3": see nhwc.MATH_MODES
         self.cost_volume = cost_volume
         self.cost_volume_net = cost_volume_net
         self.depth_decoder = depth_decoder
@@ -43,14 +45,14 @@ class HotPath(nn.Module):
 
     # ------------------------------------------------------------------------------------
     def _plan(self, B, K, C, H, W, enc_shapes: Sequence[Sequence[int]], device):
-        key = (B, K, C, H, W, tuple(tuple(s) for s in enc_shapes), str(device),
+        key = (B, K, C, H, W, tuple(tuple(s) for s in enc_shapes), str(device), self.conv_math,
                nhwc._param_key(self.cost_volume_net), nhwc._param_key(self.depth_decoder))
         ent = self._plans.get(key)
         if ent is not None:
             return ent
         self._plans.clear()
         D = self.cost_volume.num_depth_bins
-        p = nhwc.Plan(device)
+        p = nhwc.Plan(device, math=self.conv_math)
         st = {"cur_n": torch.empty(B, H, W, C, device=device), "src_n": torch.empty(B, K, H, W, C, device=device),
               "lowest": None, "planes": torch.empty(D, device=device)}
         cv_in = p.buffer(B, H, W, D)
@@ -193,7 +195,8 @@ class HotPathWorkload:
         mlp = net.BinaryMLPNetwork(dec.num_ch_dec, mlp_size=128, use_prior=False)
         for i, m in enumerate((cve, dec, mlp)):
             syn.fill_state_dict(m, seed=100 + i)
-        self.model = HotPath(cv, cve, dec, mlp).to(device)
+        self.conv_math = getattr(args, "conv_math", "fp32")
+        self.model = HotPath(cv, cve, dec, mlp, conv_math=self.conv_math).to(device)
         inp = syn.cost_volume_inputs(self.B, self.K, self.C, self.H, self.W, seed=rank)
         self.host_inputs = inp
         self.host_pyr = syn.encoder_pyramid(self.B, self.Hi, self.Wi, seed=rank)
@@ -208,7 +211,8 @@ class HotPathWorkload:
         return {"workload": f"{self.name}: matching feats -> {vol} -> CVEncoder -> BDDecoderPP (UNet++) -> occlusion MLP x{self.P} planes; "
                             f"{self.Wi}x{self.Hi} image, matching map {self.W}x{self.H}, K={self.K} source views, D={self.D} planes, fp32; "
                             "image/matching backbones (third-party) replaced by resident synthetic feature maps",
-                "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D, "query_planes": self.P, "volume": self.volume}
+                "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D, "query_planes": self.P, "volume": self.volume,
+                "conv_math": self.conv_math}
 
     def step(self, ev=None):
         d = self.d
@@ -249,6 +253,9 @@ class HotPathWorkload:
         p = ent["plan"]
         convs = [op for op in p.ops if op.kind == nhwc.OP_CONV]
         dom = [op for op in convs if op.tile_m == 8]
+        if self.conv_math != "fp32":
+            dom = [op for op in convs if op.tile_m in (10, 11)]
+            self.dominant_kernel = "conv3x3_split_k<8, %d>" % (0 if self.conv_math == "bf16x6" else 1)
         if not dom:  # small batches: every layer runs on the 4-row tile variant
             dom = [op for op in convs if op.tile_m == 9]
             self.dominant_kernel = "conv3x3_lds_k<1> + conv3x3_lds_group_k<1>"

@@ -43,7 +43,8 @@ def _worker(rank, world, port, B, q):
         if rank == 0 and rows.shape[0] > 0:
             rows[0, 1] = float("nan")
         g = all_gather_metrics(rows)
-        q.put((rank, g.clone(), nanmean_rows(g).clone()))
+        # numpy payloads: torch tensors travel by file descriptor, which races with the worker's exit
+        q.put((rank, g.numpy().copy(), nanmean_rows(g).numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -65,6 +66,7 @@ def test_two_rank_gather_matches_single_process(B):
     ref = torch.stack([x.sum(1), x[:, 0] * 2], 1)
     ref[0, 1] = float("nan")
     for rank, g, m in got:
+        g, m = torch.from_numpy(g), torch.from_numpy(m)
         assert g.shape == ref.shape
         assert torch.equal(torch.nan_to_num(g, nan=-1), torch.nan_to_num(ref, nan=-1))
         assert torch.allclose(m, torch.nanmean(ref, 0))
