@@ -49,9 +49,16 @@ def parse():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "bf16x6", "f16x3"],
                     help="arithmetic of the 3x3 stride-1 convs: fp32 MFMA (default) or the fp32-equivalent split-precision kernels")
+    ap.add_argument("--mlp-math", default="fp32", choices=["fp32", "f16x3"], help="arithmetic of the MLP kernels (feature volume)")
+    ap.add_argument("--math", default=None, choices=["fp32", "bf16x6", "f16x3"],
+                    help="shorthand: sets --conv-math, and --mlp-math f16x3 when f16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.math is not None:
+        args.conv_math = args.math
+        args.mlp_math = "f16x3" if args.math == "f16x3" else "fp32"
+    return args
 
 
 # ------------------------------------------------------------------------------------------

@@ -44,6 +44,12 @@ _SIGS = {
         C.c_int,
         [f32p] * 6 + [C.c_float, C.c_float] + [C.c_int] * 6 + [f32p] * 6 + [f32p, C.c_int, f32p, C.c_void_p, f32p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "idh_feature_volume_f16x3_fwd": (
+        C.c_int,
+        [f32p] * 6 + [C.c_float, C.c_float] + [C.c_int] * 6 + [f32p] * 6 + [f32p, C.c_int, f32p, C.c_void_p, f32p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "idh_packed_mlp_weight_f16_bytes": (C.c_size_t, [C.c_int]),
+    "idh_pack_mlp_weight_f16": (C.c_int, [f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idh_binary_mlp_search_fwd": (C.c_int, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.c_float, C.c_float, f32p, f32p, C.c_void_p]),
     "idh_metrics_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

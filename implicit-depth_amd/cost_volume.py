@@ -9,6 +9,9 @@ torch is only used to own device memory and the stream.
 """
 from __future__ import annotations
 
+import os
+from typing import Optional
+
 import torch
 from torch import Tensor, nn
 
@@ -158,6 +161,12 @@ def feature_mlp_column_maps(K: int, C: int = 16):
     return voxel, pixel, pose
 
 
+# Arithmetic of the MLP kernels (feature volume, BinaryMLP): "fp32" = v_mfma_f32_16x16x4_f32 (default),
+# "f16x3" = split precision on the f16 matrix cores (csrc/feature_volume.hip, fp32-equivalent results).
+MLP_MATH_MODES = ("fp32", "f16x3")
+DEFAULT_MLP_MATH = os.environ.get("IDH_MLP_MATH", "fp32")
+
+
 class FeatureVolumeManager(CostVolumeManager):
     """MLP feature volume (reference modules/cost_volume.py:369-715): same constructor, ``mlp``
     attribute (state_dict keys ``mlp.net.{0,2,4}.*``) and forward contract."""
@@ -171,11 +180,19 @@ class FeatureVolumeManager(CostVolumeManager):
         self.matching_dim_size = matching_dim_size
         self.num_source_views = num_source_views
         self.mlp = MLP(channel_list=mlp_channels, disable_final_activation=True)
+        self.mlp_math: Optional[str] = None  # None = DEFAULT_MLP_MATH
+
+    def _math(self) -> str:
+        m = DEFAULT_MLP_MATH if self.__dict__.get("mlp_math") is None else self.mlp_math
+        if m not in MLP_MATH_MODES:
+            raise _lib.IdhError(f"unknown MLP math mode {m!r} (expected one of {MLP_MATH_MODES})")
+        return m
 
     # -- weights in kernel order, cached until a parameter changes ------------------------------
     def _packed(self):
         lins = [self.mlp.net[0], self.mlp.net[2], self.mlp.net[4]]
-        key = tuple((p.data_ptr(), p._version) for p in self.mlp.parameters())
+        math = self._math()
+        key = (math,) + tuple((p.data_ptr(), p._version) for p in self.mlp.parameters())
         c = self.__dict__.get("_idh_fv")
         if c is not None and c[0] == key:
             return c[1]
@@ -195,10 +212,21 @@ class FeatureVolumeManager(CostVolumeManager):
             _lib.check(L.idh_pack_mlp_weight(mat.data_ptr(), dst.data_ptr(), mat.shape[1], 0, mat.shape[1], st), "idh_pack_mlp_weight")
             return dst
 
+        def frag16(mat):
+            dst = torch.empty(L.idh_packed_mlp_weight_f16_bytes(mat.shape[1]) // 4, device=dev, dtype=torch.int32)
+            _lib.check(L.idh_pack_mlp_weight_f16(mat.data_ptr(), dst.data_ptr(), mat.shape[1], 0, mat.shape[1], st), "idh_pack_mlp_weight_f16")
+            return dst
+
+        if math == "f16x3":  # kernel order of the split-precision variant: [4 metadata blocks][K view blocks]
+            vox = vox[C * K:] + vox[:C * K]
+            fragv = frag16
+        else:
+            fragv = frag
+
         vecs = torch.zeros(3, 128, device=dev)
         vecs[0], vecs[1], vecs[2, 0] = lins[1].bias.detach(), w3[0], lins[2].bias.detach()[0]
-        out = {"w1v": frag(pick(vox)), "w1p": frag(pick(pix)), "pose": pick(pose), "b1": lins[0].bias.detach().contiguous(),
-               "w2": frag(w2.contiguous()), "vecs": vecs.contiguous()}
+        out = {"w1v": fragv(pick(vox)), "w1p": frag(pick(pix)), "pose": pick(pose), "b1": lins[0].bias.detach().contiguous(),
+               "w2": fragv(w2.contiguous()), "vecs": vecs.contiguous(), "math": math}
         self.__dict__["_idh_fv"] = (key, out)
         return out
 
@@ -216,8 +244,9 @@ class FeatureVolumeManager(CostVolumeManager):
         wsb = L.idh_feature_volume_workspace_bytes(B)
         ws = torch.empty(max(wsb // 4, 1), device=dev)
         Ks_c, E_c, P_c, iK_c = src_Ks.contiguous(), src_extrinsics.contiguous(), src_poses.contiguous(), cur_invK.contiguous()
+        fwd = L.idh_feature_volume_f16x3_fwd if pk["math"] == "f16x3" else L.idh_feature_volume_fwd
         _lib.check(
-            L.idh_feature_volume_fwd(cur_n.data_ptr(), src_n.data_ptr(), Ks_c.data_ptr(), E_c.data_ptr(),
+            fwd(cur_n.data_ptr(), src_n.data_ptr(), Ks_c.data_ptr(), E_c.data_ptr(),
                                      P_c.data_ptr(), iK_c.data_ptr(), dmin, dmax, B, K, C, H, W, D,
                                      pk["w1v"].data_ptr(), pk["w1p"].data_ptr(), pk["pose"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(),
                                      pk["vecs"].data_ptr(), vol.data_ptr() if torch.is_tensor(vol) else vol, vol_cs, lowest.data_ptr(),

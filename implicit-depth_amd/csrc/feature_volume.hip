@@ -341,6 +341,359 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-precision variant (IDH "f16x3", see csrc/conv_split.hip for the arithmetic): the two
+// 128-wide layers run on v_mfma_f32_16x16x32_f16 with every fp32 operand expanded into two
+// round-to-nearest f16 pieces (x/s = x0 + x1, |err| <= 2^-23) and the three significant cross
+// products accumulated in fp32.  Scaling is by exact powers of two: weights per hidden unit (row)
+// at pack time, activations per voxel (= per MFMA column, so the scale factors out of the GEMM) from
+// the maximum of that voxel's own input / hidden vector.  Operand order: a 32-wide K block is two
+// consecutive 16-blocks of the fp32 kernel's order — lane quarter q holds k = 16(2c)+4q+e and
+// 16(2c+1)+4q+e — and the voxel inputs are ordered [4 metadata blocks][K view blocks] so every
+// register index is a compile-time constant.  C/D layout of 16x16x32 equals 16x16x4's, so the
+// layer-1 accumulators are again exactly the layer-2 B operand (after scale + split).
+// LDS: ceil((K+4)/2) x 16 KiB + 64 KiB = 160 KiB for K = 7, 8.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int kMinExp = -100;
+__device__ __forceinline__ float exp2_int(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ __forceinline__ int exponent_of(unsigned bits) {
+    const int e = (int)((bits >> 23) & 0xFF) - 127;
+    return e < kMinExp ? kMinExp : e;
+}
+__device__ __forceinline__ unsigned pack_f16(_Float16 lo, _Float16 hi) {
+    f16x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+// two 16-blocks (4 + 4 values of this lane) -> hi / lo f16 operand of one 32-wide K block
+__device__ __forceinline__ void split_block(const f32x4 &x0, const f32x4 &x1, float mul, u32x4 &hi, u32x4 &lo) {
+    _Float16 h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = (e < 4 ? x0[e] : x1[e - 4]) * mul;
+        h[e] = (_Float16)v;
+        l[e] = (_Float16)(v - (float)h[e]);
+    }
+    hi = (u32x4){pack_f16(h[0], h[1]), pack_f16(h[2], h[3]), pack_f16(h[4], h[5]), pack_f16(h[6], h[7])};
+    lo = (u32x4){pack_f16(l[0], l[1]), pack_f16(l[2], l[3]), pack_f16(l[4], l[5]), pack_f16(l[6], l[7])};
+}
+// exponent of the voxel's max |x| over the values of its 4 lanes (lanes ln, ln+16, ln+32, ln+48)
+template <int NV>
+__device__ __forceinline__ int column_exponent(const f32x4 (&x)[NV]) {
+    float m = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m = fmaxf(m, fabsf(x[j][e]));
+            bad |= (__float_as_uint(x[j][e]) & 0x7F800000u) == 0x7F800000u;
+        }
+    if (bad) m = __uint_as_float(0x7F800000u);
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    return exponent_of(__float_as_uint(m));
+}
+__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &A, const u32x4 &B, const f32x4 &C) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float *__restrict__ sw1g, const float *__restrict__ sw2g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nb32 = (a.K + 5) / 2;                               // 32-wide K blocks of layer 1
+    u32x4 *sW1 = reinterpret_cast<u32x4 *>(smem_raw);             // nb32 * 8 * 2 * 64
+    u32x4 *sW2 = sW1 + nb32 * kNS * 2 * 64;                       // 4 * 8 * 2 * 64
+    {
+        const u32x4 *g1 = reinterpret_cast<const u32x4 *>(a.w1v);
+        const u32x4 *g2 = reinterpret_cast<const u32x4 *>(a.w2);
+        const int n1 = nb32 * kNS * 2 * 64, n2 = 4 * kNS * 2 * 64;
+        for (int i = threadIdx.x; i < n1; i += 512) sW1[i] = g1[i];
+        for (int i = threadIdx.x; i < n2; i += 512) sW2[i] = g2[i];
+    }
+    __syncthreads();
+    const float *s_b2 = a.vecs, *s_w3 = a.vecs + kHid;
+    const float b3 = a.vecs[2 * kHid];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ln = lane & 15, q = lane >> 4;
+    const int N = a.H * a.W;
+    const int K = a.K;
+    const float Wf = (float)a.W, Hf = (float)a.H;
+    const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
+
+    for (long long task = (long long)blockIdx.x * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
+        const int g = __builtin_amdgcn_readfirstlane((int)(task % a.G));
+        const int tile = __builtin_amdgcn_readfirstlane((int)((task / a.G) % a.tiles_per_img));
+        const int b = __builtin_amdgcn_readfirstlane((int)(task / ((long long)a.G * a.tiles_per_img)));
+        const int p_raw = tile * 16 + ln;
+        const bool live = p_raw < N;
+        const int p = live ? p_raw : N - 1;
+        const int py = p / a.W, px = p - py * a.W;
+        const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+        const float *pb = a.ws + (size_t)b * kWsStrideReal;
+
+        const f32x4 cur4 = *reinterpret_cast<const f32x4 *>(a.cur + ((size_t)b * N + p) * kC + 4 * q);
+        const float *iK = pb + kWsInvK;
+        const float rx = fmaf(iK[0], pxf, fmaf(iK[1], pyf, iK[2]));
+        const float ry = fmaf(iK[3], pxf, fmaf(iK[4], pyf, iK[5]));
+        const float rz = fmaf(iK[6], pxf, fmaf(iK[7], pyf, iK[8]));
+
+        // per-pixel pre-activation (fp32 MFMA, once per task): bias_b + W1[:,cur].cur + W1[:,cur_ray].ray
+        f32x4 pre[kNS];
+#pragma unroll
+        for (int i = 0; i < kNS; ++i) pre[i] = *reinterpret_cast<const f32x4 *>(pb + kWsBias + 16 * i + 4 * q);
+        const int d0 = g * a.DP, d1 = min(a.D, d0 + a.DP);
+        if (d0 >= d1) continue;
+        const float rn = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+        const float crx = rx / rn, cry = ry / rn, crz = rz / rn;
+        {
+            const f32x4 rayB = (q == 0) ? (f32x4){crx, cry, crz, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 *w1p = reinterpret_cast<const f32x4 *>(a.w1p);
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+                const f32x4 A0 = w1p[(0 * kNS + i) * 64 + lane];
+                const f32x4 A1 = w1p[(1 * kNS + i) * 64 + lane];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) pre[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[kk], cur4[kk], pre[i], 0, 0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) pre[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[kk], rayB[kk], pre[i], 0, 0, 0);
+            }
+        }
+
+        f32x4 ob = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool vec_ok = ((d0 & 3) == 0) && ((a.vol_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.vol) & 15) == 0);
+#pragma unroll 1
+        for (int d = d0; d < d1; ++d) {
+            const float depth = fv_depth_plane(d, a.D, a.dmin, a.dmax);
+            const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
+            f32x4 X[12];  // [0..3] metadata blocks, [4 + k] warped features of view k
+#pragma unroll
+            for (int j = 0; j < 12; ++j) X[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m7 = 0.f, m8 = 0.f, m9 = 0.f;
+            bool any_inb = false, any_front = false;
+            struct Tap {
+                f32x4 t00, t01, t10, t11;
+                float w00, w01, w10, w11, z, u, v;
+            };
+            auto issue = [&](int k) {
+                Tap t;
+                const float *hm = pb + kWsHom + 12 * k;
+                const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+                const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+                const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+                const float cx = fmaf(depth, qx, hm[9]);
+                const float cy = fmaf(depth, qy, hm[10]);
+                const float cz = fmaf(depth, qz, hm[11]);
+                t.z = fmaxf(cz, 1e-5f);
+                float r = __builtin_amdgcn_rcpf(t.z);
+                r = r * fmaf(-t.z, r, 2.0f);
+                t.u = cx * r;
+                t.v = cy * r;
+                const float sx = fminf(fmaxf(t.u - 0.5f, -1.0f), Wf);
+                const float sy = fminf(fmaxf(t.v - 0.5f, -1.0f), Hf);
+                const float x0f = floorf(sx), y0f = floorf(sy);
+                const float fx = sx - x0f, fy = sy - y0f;
+                const int x0 = (int)x0f, y0 = (int)y0f;
+                const float wx0 = (x0 >= 0 && x0 < a.W) ? 1.0f - fx : 0.f;
+                const float wx1 = (x0 + 1 < a.W) ? fx : 0.f;
+                const float wy0 = (y0 >= 0 && y0 < a.H) ? 1.0f - fy : 0.f;
+                const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
+                const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
+                const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
+                const float *sb = a.src + (size_t)(b * K + k) * N * kC + 4 * q;
+                t.t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kC);
+                t.t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kC);
+                t.t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kC);
+                t.t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kC);
+                t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
+                return t;
+            };
+            Tap cur = issue(0);
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k < K) {  // wave-uniform
+                    const Tap nxt = issue(min(k + 1, K - 1));
+                    any_inb |= (cur.u > 2.f) & (cur.u < Wf - 2.f) & (cur.v > 2.f) & (cur.v < Hf - 2.f);
+                    const float z = cur.z;
+                    const float maskv = z > 0.f ? 1.f : 0.f;
+                    any_front |= z > 0.f;
+                    f32x4 wv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        wv[e] = fmaf(cur.w11, cur.t11[e], fmaf(cur.w10, cur.t10[e], fmaf(cur.w01, cur.t01[e], cur.w00 * cur.t00[e])));
+                    float part = wv[0] * cur4[0];
+                    part = fmaf(wv[1], cur4[1], part); part = fmaf(wv[2], cur4[2], part); part = fmaf(wv[3], cur4[3], part);
+                    part += __shfl_xor(part, 16, 64);
+                    part += __shfl_xor(part, 32, 64);
+                    const float dotv = part * maskv;
+                    const bool s0 = (k == q), s1 = (k == q + 4);
+                    m0 = s0 ? maskv : m0; m1 = s0 ? z : m1; m2 = s0 ? dotv : m2;
+                    m7 = s1 ? maskv : m7; m8 = s1 ? z : m8; m9 = s1 ? dotv : m9;
+                    X[4 + k] = wv;
+                    cur = nxt;
+                }
+            }
+            float m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m10 = 0.f, m11 = 0.f, m12 = 0.f, m13 = 0.f;
+            {
+                const int v0 = q, v1 = q + 4;
+                if (v0 < K) {
+                    const float *t = pb + kWsT + 4 * v0;
+                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
+                    const float in = 1.0f / fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
+                    m4 = ax * in; m5 = ay * in; m6 = az * in;
+                    const float n1 = fmaxf(sqrtf(crx * crx + cry * cry + crz * crz), 1e-5f);
+                    const float n2 = fmaxf(sqrtf(m4 * m4 + m5 * m5 + m6 * m6), 1e-5f);
+                    m3 = (crx * m4 + cry * m5 + crz * m6) / (n1 * n2);
+                }
+                if (v1 < K) {
+                    const float *t = pb + kWsT + 4 * v1;
+                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
+                    const float in = 1.0f / fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
+                    m11 = ax * in; m12 = ay * in; m13 = az * in;
+                    const float n1 = fmaxf(sqrtf(crx * crx + cry * cry + crz * crz), 1e-5f);
+                    const float n2 = fmaxf(sqrtf(m11 * m11 + m12 * m12 + m13 * m13), 1e-5f);
+                    m10 = (crx * m11 + cry * m12 + crz * m13) / (n1 * n2);
+                }
+            }
+            X[0] = (f32x4){m0, m1, m2, m3};
+            X[1] = (f32x4){m4, m5, m6, m7};
+            X[2] = (f32x4){m8, m9, m10, m11};
+            X[3] = (f32x4){m12, m13, depth, 0.f};
+
+            // ---- layer 1: scale + split the voxel's inputs, 3 f16 products per K block ------------
+            f32x4 h[kNS];
+            {
+                const int ex = column_exponent<12>(X);
+                const float mul = exp2_int(14 - ex), sx = exp2_int(ex - 14);
+                f32x4 acc[kNS];
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    if (c < nb32) {
+                        u32x4 Bh, Bl;  // split right before use: X dies block by block
+                        split_block(X[2 * c], X[2 * c + 1], mul, Bh, Bl);
+#pragma unroll
+                        for (int i4 = 0; i4 < kNS; i4 += 4) {
+                            u32x4 Ah[4], Al[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                Ah[i] = sW1[((c * kNS + i4 + i) * 2 + 0) * 64 + lane];
+                                Al[i] = sW1[((c * kNS + i4 + i) * 2 + 1) * 64 + lane];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i4 + i] = mfma_f16(Al[i], Bh, acc[i4 + i]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i4 + i] = mfma_f16(Ah[i], Bl, acc[i4 + i]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i4 + i] = mfma_f16(Ah[i], Bh, acc[i4 + i]);
+                            __builtin_amdgcn_sched_barrier(0);  // no hoisting of later blocks' LDS reads (register pressure)
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const f32x4 sw = *reinterpret_cast<const f32x4 *>(sw1g + 16 * i + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[i][r] = lrelu01(fmaf(acc[i][r], sx * sw[r], pre[i][r]));
+                }
+            }
+            // ---- layer 2 (same scheme on the hidden vector) -> LeakyReLU -> layer 3 ----------------
+            float s = 0.f;
+            {
+                const int ex = column_exponent<kNS>(h);
+                const float mul = exp2_int(14 - ex), sx = exp2_int(ex - 14);
+                f32x4 acc[kNS];
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    u32x4 Bh, Bl;
+                    split_block(h[2 * c], h[2 * c + 1], mul, Bh, Bl);
+#pragma unroll
+                    for (int i4 = 0; i4 < kNS; i4 += 4) {
+                        u32x4 Ah[4], Al[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            Ah[i] = sW2[((c * kNS + i4 + i) * 2 + 0) * 64 + lane];
+                            Al[i] = sW2[((c * kNS + i4 + i) * 2 + 1) * 64 + lane];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i4 + i] = mfma_f16(Al[i], Bh, acc[i4 + i]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i4 + i] = mfma_f16(Ah[i], Bl, acc[i4 + i]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i4 + i] = mfma_f16(Ah[i], Bh, acc[i4 + i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const f32x4 sw = *reinterpret_cast<const f32x4 *>(sw2g + 16 * i + 4 * q);
+                    const f32x4 b2 = *reinterpret_cast<const f32x4 *>(s_b2 + 16 * i + 4 * q);
+                    const f32x4 w3 = *reinterpret_cast<const f32x4 *>(s_w3 + 16 * i + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = fmaf(w3[r], lrelu01(fmaf(acc[i][r], sx * sw[r], b2[r])), s);
+                }
+            }
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float val = s + b3;
+            if (a.vol_cs > 0) {
+                const int e = (d - d0) & 3;
+                ob[0] = e == 0 ? val : ob[0]; ob[1] = e == 1 ? val : ob[1]; ob[2] = e == 2 ? val : ob[2]; ob[3] = e == 3 ? val : ob[3];
+                if (q == 0 && live && (e == 3 || d == d1 - 1)) {
+                    float *o = a.vol + ((size_t)b * N + p) * a.vol_cs + (d - e);
+                    if (e == 3 && vec_ok) *reinterpret_cast<f32x4 *>(o) = ob;
+                    else { o[0] = ob[0]; if (e >= 1) o[1] = ob[1]; if (e >= 2) o[2] = ob[2]; if (e >= 3) o[3] = ob[3]; }
+                }
+            } else if (q == 0 && live) {
+                a.vol[((size_t)b * a.D + d) * N + p] = val;
+            }
+            if (q == 0 && live && a.mask != nullptr && d == a.D - 1) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
+        }
+    }
+}
+
+// ---- f16x3 weight packing: rows scaled by 2^(14 - e_row), two f16 pieces, 32-wide K blocks ----
+// dst: [ceil(n_in/32)][8 n-subtiles][piece 2][lane 64][8 halves], then 128 floats 2^(e_row - 14)
+__global__ __launch_bounds__(256) void pack_mlp_weight_f16_k(const float *__restrict__ w, u32x4 *__restrict__ dst, int ld, int col0,
+                                                             int n_in, int nb32) {
+    __shared__ float s_mul[kHid];
+    float *scale_out = reinterpret_cast<float *>(dst + (size_t)nb32 * kNS * 2 * 64);
+    if (threadIdx.x < kHid) {
+        const int n = threadIdx.x;
+        float m = 0.f;
+        for (int k = 0; k < n_in; ++k) {
+            const float v = w[(size_t)n * ld + col0 + k];
+            m = fmaxf(m, fabsf(v));
+            if ((__float_as_uint(v) & 0x7F800000u) == 0x7F800000u) m = __uint_as_float(0x7F800000u);
+        }
+        const int e = exponent_of(__float_as_uint(m));
+        s_mul[n] = exp2_int(14 - e);
+        if (blockIdx.x == 0) scale_out[n] = exp2_int(e - 14 < -126 ? -126 : e - 14);
+    }
+    __syncthreads();
+    const int total = nb32 * kNS * 64;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int lane = t & 63, i = (t >> 6) % kNS, c = (t >> 6) / kNS;
+        const int n = 16 * i + (lane & 15), q = lane >> 4;
+        f32x4 x0, x1;
+        for (int e = 0; e < 4; ++e) {
+            const int k0 = 16 * (2 * c) + 4 * q + e, k1 = 16 * (2 * c + 1) + 4 * q + e;
+            x0[e] = k0 < n_in ? w[(size_t)n * ld + col0 + k0] : 0.f;
+            x1[e] = k1 < n_in ? w[(size_t)n * ld + col0 + k1] : 0.f;
+        }
+        u32x4 hi, lo;
+        split_block(x0, x1, s_mul[n], hi, lo);
+        dst[((size_t)(c * kNS + i) * 2 + 0) * 64 + lane] = hi;
+        dst[((size_t)(c * kNS + i) * 2 + 1) * 64 + lane] = lo;
+    }
+}
+
 // lowest[b,p] = plane_{argmax_d vol[b,d,p]} (first maximum wins), reference cost_volume.py:352-356
 __global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__ vol, int vol_cs, int B, int N, int D,
                                                        float dmin, float dmax, float *__restrict__ lowest,
@@ -364,6 +717,42 @@ __global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__
 
 extern "C" size_t idh_feature_volume_workspace_bytes(int B) { return B <= 0 ? 0 : (size_t)B * kWsStrideReal * sizeof(float); }
 
+extern "C" size_t idh_packed_mlp_weight_f16_bytes(int n_in) {
+    if (n_in <= 0) return 0;
+    return (size_t)((n_in + 31) / 32) * kNS * 2 * 64 * 16 + kHid * sizeof(float);
+}
+
+extern "C" int idh_pack_mlp_weight_f16(const float *w_row_major, void *dst, int ld, int col0, int n_in, void *stream) {
+    if (!w_row_major || !dst || n_in <= 0 || ld < col0 + n_in || col0 < 0) return IDH_EINVAL;
+    const int nb32 = (n_in + 31) / 32;
+    hipLaunchKernelGGL(pack_mlp_weight_f16_k, dim3(idh_cdiv(nb32 * kNS * 64, 256)), dim3(256), 0, idh_stream(stream), w_row_major,
+                       reinterpret_cast<u32x4 *>(dst), ld, col0, n_in, nb32);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
+
+static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                               const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
+                               float dmin, float dmax, int B, int K, int C, int H, int W, int D,
+                               const void *w1_voxel_packed, const float *w1_pixel_packed,
+                               const float *w1_pose_rowmajor, const float *b1, const void *w2_packed,
+                               const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
+                               unsigned char *mask_bhw, float *planes_d, void *workspace,
+                               size_t workspace_bytes, void *stream, bool f16x3);
+
+extern "C" int idh_feature_volume_f16x3_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                                            const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
+                                            float dmin, float dmax, int B, int K, int C, int H, int W, int D,
+                                            const void *w1_voxel_f16, const float *w1_pixel_packed,
+                                            const float *w1_pose_rowmajor, const float *b1, const void *w2_f16,
+                                            const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
+                                            unsigned char *mask_bhw, float *planes_d, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
+    return feature_volume_impl(cur_nhwc, src_nhwc, src_K_44, src_E_44, src_poses_44, cur_invK_44, dmin, dmax, B, K, C, H, W, D,
+                               w1_voxel_f16, w1_pixel_packed, w1_pose_rowmajor, b1, w2_f16, vecs_b2_w3_b3, vol, vol_nhwc_cs,
+                               lowest_bhw, mask_bhw, planes_d, workspace, workspace_bytes, stream, true);
+}
+
 extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
                                       const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
                                       float dmin, float dmax, int B, int K, int C, int H, int W, int D,
@@ -372,6 +761,19 @@ extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nh
                                       const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
                                       unsigned char *mask_bhw, float *planes_d, void *workspace,
                                       size_t workspace_bytes, void *stream) {
+    return feature_volume_impl(cur_nhwc, src_nhwc, src_K_44, src_E_44, src_poses_44, cur_invK_44, dmin, dmax, B, K, C, H, W, D,
+                               w1_voxel_packed, w1_pixel_packed, w1_pose_rowmajor, b1, w2_packed, vecs_b2_w3_b3, vol, vol_nhwc_cs,
+                               lowest_bhw, mask_bhw, planes_d, workspace, workspace_bytes, stream, false);
+}
+
+static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                               const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
+                               float dmin, float dmax, int B, int K, int C, int H, int W, int D,
+                               const void *w1_voxel_packed, const float *w1_pixel_packed,
+                               const float *w1_pose_rowmajor, const float *b1, const void *w2_packed,
+                               const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
+                               unsigned char *mask_bhw, float *planes_d, void *workspace,
+                               size_t workspace_bytes, void *stream, bool f16x3) {
     if (B < 0 || K <= 0 || H <= 0 || W <= 0 || D <= 0 || !(dmin > 0.f) || !(dmax > 0.f)) return IDH_EINVAL;
     if (C != kC || K > kMaxK || D > 4096) return IDH_EUNSUPPORTED;
     if (B == 0) return IDH_OK;
@@ -387,7 +789,8 @@ extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nh
     IDH_CHECK_LAUNCH();
 
     FvArgs a{};
-    a.cur = cur_nhwc; a.src = src_nhwc; a.ws = ws; a.w1v = w1_voxel_packed; a.w1p = w1_pixel_packed; a.w2 = w2_packed;
+    a.cur = cur_nhwc; a.src = src_nhwc; a.ws = ws; a.w1v = static_cast<const float *>(w1_voxel_packed); a.w1p = w1_pixel_packed;
+    a.w2 = static_cast<const float *>(w2_packed);
     a.vecs = vecs_b2_w3_b3; a.vol = vol; a.mask = mask_bhw; a.vol_cs = vol_nhwc_cs;
     a.B = B; a.K = K; a.H = H; a.W = W; a.D = D; a.dmin = dmin; a.dmax = dmax;
     const int N = H * W;
@@ -414,15 +817,25 @@ extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nh
     const long long ntasks = pix_tasks * a.G;
     int grid = (int)((ntasks + 7) / 8);
     if (grid > 256) grid = 256;  // persistent: one 512-thread workgroup per CU (LDS-resident weights)
-    const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return IDH_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(fv_mlp_k, dim3(grid), dim3(512), lds, st, a);
+    if (f16x3) {
+        const int nb32 = (K + 5) / 2;
+        const size_t lds = ((size_t)nb32 * kNS * 2 * 64 + 4 * kNS * 2 * 64) * 16;
+        const float *sw1 = reinterpret_cast<const float *>(static_cast<const char *>(w1_voxel_packed) + (size_t)nb32 * kNS * 2 * 64 * 16);
+        const float *sw2 = reinterpret_cast<const float *>(static_cast<const char *>(w2_packed) + (size_t)4 * kNS * 2 * 64 * 16);
+        hipLaunchKernelGGL(fv_mlp_f16_k, dim3(grid), dim3(512), lds, st, a, sw1, sw2);
+    } else {
+        const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4);
+        hipLaunchKernelGGL(fv_mlp_k, dim3(grid), dim3(512), lds, st, a);
+    }
     IDH_CHECK_LAUNCH();
     if (lowest_bhw) {
         int g2 = idh_cdiv((long long)B * N, 256);

@@ -196,6 +196,9 @@ class HotPathWorkload:
         for i, m in enumerate((cve, dec, mlp)):
             syn.fill_state_dict(m, seed=100 + i)
         self.conv_math = getattr(args, "conv_math", "fp32")
+        self.mlp_math = getattr(args, "mlp_math", "fp32")
+        if self.volume == "mlp":
+            cv.mlp_math = self.mlp_math
         self.model = HotPath(cv, cve, dec, mlp, conv_math=self.conv_math).to(device)
         inp = syn.cost_volume_inputs(self.B, self.K, self.C, self.H, self.W, seed=rank)
         self.host_inputs = inp
@@ -212,7 +215,7 @@ class HotPathWorkload:
                             f"{self.Wi}x{self.Hi} image, matching map {self.W}x{self.H}, K={self.K} source views, D={self.D} planes, fp32; "
                             "image/matching backbones (third-party) replaced by resident synthetic feature maps",
                 "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D, "query_planes": self.P, "volume": self.volume,
-                "conv_math": self.conv_math}
+                "conv_math": self.conv_math, "mlp_math": self.mlp_math}
 
     def step(self, ev=None):
         d = self.d

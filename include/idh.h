@@ -97,6 +97,26 @@ int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nhwc, const f
                            unsigned char *mask_bhw, float *planes_d, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* Split-precision ("f16x3") variant of the same kernel: the two 128-wide layers run on
+ * v_mfma_f32_16x16x32_f16 with every fp32 operand expanded into two round-to-nearest f16 pieces
+ * (power-of-two scaled per hidden unit for the weights, per voxel for the activations) and the three
+ * significant cross products accumulated in fp32 — fp32-equivalent results (tests/test_mlp_split_gpu.py)
+ * at 3/16 of the fp32-MFMA cost.  Same arguments, except that w1_voxel_f16 / w2_f16 come from
+ * idh_pack_mlp_weight_f16 and the voxel columns are ordered [4 metadata blocks | warped K*16]
+ * (implicit-depth_amd/cost_volume.py).  idh_pack_mlp_weight_f16 packs columns [col0, col0+n_in) of a
+ * row-major (128, ld) matrix as [ceil(n_in/32)][8][piece 2][lane 64][8 halves] followed by the 128
+ * per-row scale floats. */
+size_t idh_packed_mlp_weight_f16_bytes(int n_in);
+int idh_pack_mlp_weight_f16(const float *w_row_major, void *dst, int ld, int col0, int n_in, void *stream);
+int idh_feature_volume_f16x3_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                                 const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
+                                 float dmin, float dmax, int B, int K, int C, int H, int W, int D,
+                                 const void *w1_voxel_f16, const float *w1_pixel_packed,
+                                 const float *w1_pose_rowmajor, const float *b1, const void *w2_f16,
+                                 const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
+                                 unsigned char *mask_bhw, float *planes_d, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+
 /* ---- per-pixel occlusion MLP over all query planes ---------------------------------- */
 /* Replaces the per-plane loop bd_model.py:293-304 -> run_mlp_val (:412-442) ->
  * BinaryMLPNetwork scale 0 (modules/networks.py:98-115): for every pixel m and plane p
