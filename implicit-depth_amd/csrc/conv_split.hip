@@ -405,7 +405,10 @@ int launch_one(const ConvArgs &a, int N, hipStream_t st) {
 namespace idh_conv {
 
 int launch_conv_split(const ConvArgs &a, int N, int mode, hipStream_t st) {
-    static const int waves = getenv("IDH_SPLIT_WAVES") ? atoi(getenv("IDH_SPLIT_WAVES")) : 8;
+    // measured on MI355X (tools/perf_split.py): f16x3 is 5-9 % faster with 4 waves (166 VGPRs, 44.5 KiB ->
+    // 3 workgroups per CU), bf16x6 is indifferent (4 waves: 206 VGPRs -> 2 workgroups either way)
+    static const int env_waves = getenv("IDH_SPLIT_WAVES") ? atoi(getenv("IDH_SPLIT_WAVES")) : 0;
+    const int waves = env_waves ? env_waves : (mode == IDH_SPLIT_F16X3 ? 4 : 8);
     if (mode == IDH_SPLIT_BF16X6) return waves == 4 ? launch_one<4, MODE_BF16X6>(a, N, st) : launch_one<8, MODE_BF16X6>(a, N, st);
     if (mode == IDH_SPLIT_F16X3) return waves == 4 ? launch_one<4, MODE_F16X3>(a, N, st) : launch_one<8, MODE_F16X3>(a, N, st);
     return IDH_EINVAL;

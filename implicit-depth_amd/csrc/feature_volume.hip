@@ -23,10 +23,11 @@
 //     workgroup; per plane a wave issues (K+4+8)*32 MFMAs.
 // Roofline: fp32 MFMA (2*D*N*(16K+64+128)*128 + ... ~ 66.6 GFLOP per 96x128x64 frame).
 #include "idh_common.h"
+#include "split_f16.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace idh_f16;
 
 constexpr int kC = 16;
 constexpr int kHid = 128;
@@ -353,53 +354,6 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 // register index is a compile-time constant.  C/D layout of 16x16x32 equals 16x16x4's, so the
 // layer-1 accumulators are again exactly the layer-2 B operand (after scale + split).
 // LDS: ceil((K+4)/2) x 16 KiB + 64 KiB = 160 KiB for K = 7, 8.
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-constexpr int kMinExp = -100;
-__device__ __forceinline__ float exp2_int(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
-__device__ __forceinline__ int exponent_of(unsigned bits) {
-    const int e = (int)((bits >> 23) & 0xFF) - 127;
-    return e < kMinExp ? kMinExp : e;
-}
-__device__ __forceinline__ unsigned pack_f16(_Float16 lo, _Float16 hi) {
-    f16x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, v);
-}
-// two 16-blocks (4 + 4 values of this lane) -> hi / lo f16 operand of one 32-wide K block
-__device__ __forceinline__ void split_block(const f32x4 &x0, const f32x4 &x1, float mul, u32x4 &hi, u32x4 &lo) {
-    _Float16 h[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float v = (e < 4 ? x0[e] : x1[e - 4]) * mul;
-        h[e] = (_Float16)v;
-        l[e] = (_Float16)(v - (float)h[e]);
-    }
-    hi = (u32x4){pack_f16(h[0], h[1]), pack_f16(h[2], h[3]), pack_f16(h[4], h[5]), pack_f16(h[6], h[7])};
-    lo = (u32x4){pack_f16(l[0], l[1]), pack_f16(l[2], l[3]), pack_f16(l[4], l[5]), pack_f16(l[6], l[7])};
-}
-// exponent of the voxel's max |x| over the values of its 4 lanes (lanes ln, ln+16, ln+32, ln+48)
-template <int NV>
-__device__ __forceinline__ int column_exponent(const f32x4 (&x)[NV]) {
-    float m = 0.f;
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            m = fmaxf(m, fabsf(x[j][e]));
-            bad |= (__float_as_uint(x[j][e]) & 0x7F800000u) == 0x7F800000u;
-        }
-    if (bad) m = __uint_as_float(0x7F800000u);
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    return exponent_of(__float_as_uint(m));
-}
-__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &A, const u32x4 &B, const f32x4 &C) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0);
-}
-
 __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float *__restrict__ sw1g, const float *__restrict__ sw2g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nb32 = (a.K + 5) / 2;                               // 32-wide K blocks of layer 1
@@ -658,42 +612,6 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
     }
 }
 
-// ---- f16x3 weight packing: rows scaled by 2^(14 - e_row), two f16 pieces, 32-wide K blocks ----
-// dst: [ceil(n_in/32)][8 n-subtiles][piece 2][lane 64][8 halves], then 128 floats 2^(e_row - 14)
-__global__ __launch_bounds__(256) void pack_mlp_weight_f16_k(const float *__restrict__ w, u32x4 *__restrict__ dst, int ld, int col0,
-                                                             int n_in, int nb32) {
-    __shared__ float s_mul[kHid];
-    float *scale_out = reinterpret_cast<float *>(dst + (size_t)nb32 * kNS * 2 * 64);
-    if (threadIdx.x < kHid) {
-        const int n = threadIdx.x;
-        float m = 0.f;
-        for (int k = 0; k < n_in; ++k) {
-            const float v = w[(size_t)n * ld + col0 + k];
-            m = fmaxf(m, fabsf(v));
-            if ((__float_as_uint(v) & 0x7F800000u) == 0x7F800000u) m = __uint_as_float(0x7F800000u);
-        }
-        const int e = exponent_of(__float_as_uint(m));
-        s_mul[n] = exp2_int(14 - e);
-        if (blockIdx.x == 0) scale_out[n] = exp2_int(e - 14 < -126 ? -126 : e - 14);
-    }
-    __syncthreads();
-    const int total = nb32 * kNS * 64;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        const int lane = t & 63, i = (t >> 6) % kNS, c = (t >> 6) / kNS;
-        const int n = 16 * i + (lane & 15), q = lane >> 4;
-        f32x4 x0, x1;
-        for (int e = 0; e < 4; ++e) {
-            const int k0 = 16 * (2 * c) + 4 * q + e, k1 = 16 * (2 * c + 1) + 4 * q + e;
-            x0[e] = k0 < n_in ? w[(size_t)n * ld + col0 + k0] : 0.f;
-            x1[e] = k1 < n_in ? w[(size_t)n * ld + col0 + k1] : 0.f;
-        }
-        u32x4 hi, lo;
-        split_block(x0, x1, s_mul[n], hi, lo);
-        dst[((size_t)(c * kNS + i) * 2 + 0) * 64 + lane] = hi;
-        dst[((size_t)(c * kNS + i) * 2 + 1) * 64 + lane] = lo;
-    }
-}
-
 // lowest[b,p] = plane_{argmax_d vol[b,d,p]} (first maximum wins), reference cost_volume.py:352-356
 __global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__ vol, int vol_cs, int B, int N, int D,
                                                        float dmin, float dmax, float *__restrict__ lowest,
@@ -716,20 +634,6 @@ __global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__
 }  // namespace
 
 extern "C" size_t idh_feature_volume_workspace_bytes(int B) { return B <= 0 ? 0 : (size_t)B * kWsStrideReal * sizeof(float); }
-
-extern "C" size_t idh_packed_mlp_weight_f16_bytes(int n_in) {
-    if (n_in <= 0) return 0;
-    return (size_t)((n_in + 31) / 32) * kNS * 2 * 64 * 16 + kHid * sizeof(float);
-}
-
-extern "C" int idh_pack_mlp_weight_f16(const float *w_row_major, void *dst, int ld, int col0, int n_in, void *stream) {
-    if (!w_row_major || !dst || n_in <= 0 || ld < col0 + n_in || col0 < 0) return IDH_EINVAL;
-    const int nb32 = (n_in + 31) / 32;
-    hipLaunchKernelGGL(pack_mlp_weight_f16_k, dim3(idh_cdiv(nb32 * kNS * 64, 256)), dim3(256), 0, idh_stream(stream), w_row_major,
-                       reinterpret_cast<u32x4 *>(dst), ld, col0, n_in, nb32);
-    IDH_CHECK_LAUNCH();
-    return IDH_OK;
-}
 
 static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
                                const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,

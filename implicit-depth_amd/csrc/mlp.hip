@@ -18,15 +18,19 @@
 // Weights are pre-packed in "fragment order" so every A-fragment load is one coalesced 1 KiB
 // wave read (idh_pack_mlp_weight).
 #include "idh_common.h"
+#include "split_f16.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace idh_f16;
 
 constexpr int kHidden = 128;           // mlp_size (networks.py:88)
 constexpr int kNS = kHidden / 16;      // 8 sub-tiles of 16 hidden units
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU of the split-precision kernel: exp via v_exp_f32 (2 ulp of a value near 1 -> |err| ~1e-7
+// absolute, the size of one fp32 rounding of the O(1) sums around it) instead of ocml expm1f (~25 VALU)
+__device__ __forceinline__ float elu1_fast(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 __device__ __forceinline__ float lrelu(float x, float s) { return x >= 0.f ? x : x * s; }
 
 // One 128 -> 128 layer on register-resident activations (transposed form), TM pixel sub-tiles.
@@ -68,6 +72,7 @@ struct BinArgs {
     int search_iters;
     float search_lo, search_hi, thr_logit;
     float *search_out;    // B,1,HW final search depths
+    const float *sw2;     // F16 kernel: per-row scale of the f16-packed W2 (w2 then points to idh_pack_mlp_weight_f16 output)
 };
 
 // Persistent 512-thread workgroups (one per CU): W2 (64 KiB) and, when it fits, the feature part
@@ -76,8 +81,12 @@ struct BinArgs {
 constexpr int kBinThreads = 512, kBinWaves = kBinThreads / 64;
 constexpr int kW1LdsMaxBlocks = 4;  // Cf <= 64 -> W1f in LDS (32 KiB); wider scales read it via L1/L2
 
-template <int TM>
+// F16 = true: layer 2 (the per-plane 128x128 GEMM, ~95 % of the flops) runs in "f16x3" split precision
+// on v_mfma_f32_16x16x32_f16 (csrc/split_f16.h): W2 in LDS as two f16 pieces (same 64 KiB), the hidden
+// vector of each pixel scaled by its own power of two, 96 MFMAs per plane instead of 256 fp32 ones.
+template <int TM, bool F16>
 __global__ __launch_bounds__(kBinThreads) void binary_mlp_k(const BinArgs a) {
+    static_assert(!F16 || TM == 1, "split-precision path is written for one pixel sub-tile per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4 *sW2 = reinterpret_cast<f32x4 *>(smem_raw);
     const int cblocks = (a.Cf + 15) >> 4;
@@ -173,12 +182,48 @@ __global__ __launch_bounds__(kBinThreads) void binary_mlp_k(const BinArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         float v = fmaf(wd[r], dv[t], pre1[i][t][r]);
                         v = fmaf(wp[r], pv[t], v);
-                        h1[i][t][r] = elu1(v);
+                        h1[i][t][r] = F16 ? elu1_fast(v) : elu1(v);
                     }
                     acc[i][t] = b2;
                 }
             }
-            dense128<TM>(h1, sW2, lane, acc);
+            if constexpr (F16) {
+                f32x4 hv[kNS], a2[kNS];
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) { hv[i] = h1[i][0]; a2[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                const int ex = column_exponent<kNS>(hv);
+                const float mul = exp2_int(14 - ex), sx = exp2_int(ex - 14);
+                const u32x4 *w2 = reinterpret_cast<const u32x4 *>(sW2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    u32x4 Bh, Bl;
+                    split_block(hv[2 * c], hv[2 * c + 1], mul, Bh, Bl);
+#pragma unroll
+                    for (int i4 = 0; i4 < kNS; i4 += 4) {
+                        u32x4 Ah[4], Al[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            Ah[i] = w2[((c * kNS + i4 + i) * 2 + 0) * 64 + lane];
+                            Al[i] = w2[((c * kNS + i4 + i) * 2 + 1) * 64 + lane];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a2[i4 + i] = mfma_f16(Al[i], Bh, a2[i4 + i]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a2[i4 + i] = mfma_f16(Ah[i], Bl, a2[i4 + i]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a2[i4 + i] = mfma_f16(Ah[i], Bh, a2[i4 + i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const f32x4 sw = *reinterpret_cast<const f32x4 *>(a.sw2 + 16 * i + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][0][r] = fmaf(a2[i][r], sx * sw[r], acc[i][0][r]);
+                }
+            } else {
+                dense128<TM>(h1, sW2, lane, acc);
+            }
             // ---- layer 3: logit = w3 . ELU(h2) + b3; reduce over the 4 lane quarters ----------
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
@@ -187,7 +232,7 @@ __global__ __launch_bounds__(kBinThreads) void binary_mlp_k(const BinArgs a) {
                 for (int i = 0; i < kNS; ++i) {
                     const f32x4 w3 = *reinterpret_cast<const f32x4 *>(s_w3 + 16 * i + 4 * q);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s = fmaf(w3[r], elu1(acc[i][t][r]), s);
+                    for (int r = 0; r < 4; ++r) s = fmaf(w3[r], F16 ? elu1_fast(acc[i][t][r]) : elu1(acc[i][t][r]), s);
                 }
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
@@ -207,6 +252,42 @@ __global__ __launch_bounds__(kBinThreads) void binary_mlp_k(const BinArgs a) {
             for (int t = 0; t < TM; ++t)
                 if (q == 0 && mok[t]) a.search_out[poff[t]] = sd[t];
         }
+    }
+}
+
+// ---- f16x3 weight packing: rows scaled by 2^(14 - e_row), two f16 pieces, 32-wide K blocks ----
+// dst: [ceil(n_in/32)][8 n-subtiles][piece 2][lane 64][8 halves], then 128 floats 2^(e_row - 14)
+__global__ __launch_bounds__(256) void pack_mlp_weight_f16_k(const float *__restrict__ w, u32x4 *__restrict__ dst, int ld, int col0,
+                                                             int n_in, int nb32) {
+    __shared__ float s_mul[kHidden];
+    float *scale_out = reinterpret_cast<float *>(dst + (size_t)nb32 * kNS * 2 * 64);
+    if (threadIdx.x < kHidden) {
+        const int n = threadIdx.x;
+        float m = 0.f;
+        for (int k = 0; k < n_in; ++k) {
+            const float v = w[(size_t)n * ld + col0 + k];
+            m = fmaxf(m, fabsf(v));
+            if ((__float_as_uint(v) & 0x7F800000u) == 0x7F800000u) m = __uint_as_float(0x7F800000u);
+        }
+        const int e = exponent_of(__float_as_uint(m));
+        s_mul[n] = exp2_int(14 - e);
+        if (blockIdx.x == 0) scale_out[n] = exp2_int(e - 14 < -126 ? -126 : e - 14);
+    }
+    __syncthreads();
+    const int total = nb32 * kNS * 64;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int lane = t & 63, i = (t >> 6) % kNS, c = (t >> 6) / kNS;
+        const int n = 16 * i + (lane & 15), q = lane >> 4;
+        f32x4 x0, x1;
+        for (int e = 0; e < 4; ++e) {
+            const int k0 = 16 * (2 * c) + 4 * q + e, k1 = 16 * (2 * c + 1) + 4 * q + e;
+            x0[e] = k0 < n_in ? w[(size_t)n * ld + col0 + k0] : 0.f;
+            x1[e] = k1 < n_in ? w[(size_t)n * ld + col0 + k1] : 0.f;
+        }
+        u32x4 hi, lo;
+        split_block(x0, x1, s_mul[n], hi, lo);
+        dst[((size_t)(c * kNS + i) * 2 + 0) * 64 + lane] = hi;
+        dst[((size_t)(c * kNS + i) * 2 + 1) * 64 + lane] = lo;
     }
 }
 
@@ -312,7 +393,21 @@ extern "C" int idh_pack_mlp_weight(const float *w, float *dst, int ld, int col0,
     return IDH_OK;
 }
 
-static int binary_mlp_launch(BinArgs a, int B, void *stream);
+extern "C" size_t idh_packed_mlp_weight_f16_bytes(int n_in) {
+    if (n_in <= 0) return 0;
+    return (size_t)((n_in + 31) / 32) * kNS * 2 * 64 * 16 + kHidden * sizeof(float);
+}
+
+extern "C" int idh_pack_mlp_weight_f16(const float *w_row_major, void *dst, int ld, int col0, int n_in, void *stream) {
+    if (!w_row_major || !dst || n_in <= 0 || ld < col0 + n_in || col0 < 0) return IDH_EINVAL;
+    const int nb32 = (n_in + 31) / 32;
+    hipLaunchKernelGGL(pack_mlp_weight_f16_k, dim3(idh_cdiv(nb32 * kNS * 64, 256)), dim3(256), 0, idh_stream(stream), w_row_major,
+                       reinterpret_cast<u32x4 *>(dst), ld, col0, n_in, nb32);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
+
+static int binary_mlp_launch(BinArgs a, int B, void *stream, bool f16 = false);
 
 extern "C" int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *depth_bphw,
                                   const float *prior_bphw, int has_prior, float prior_const, const float *w1f_packed,
@@ -324,8 +419,22 @@ extern "C" int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, c
     const long long M = (long long)B * HW;
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
     BinArgs a{feat_nhwc, depth_bphw, prior_bphw, w1f_packed, w2_packed, vecs6x128, out_bphw,
-              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr};
+              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr};
     return binary_mlp_launch(a, B, stream);
+}
+
+extern "C" int idh_binary_mlp_f16x3_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *depth_bphw,
+                                        const float *prior_bphw, int has_prior, float prior_const, const float *w1f_packed,
+                                        const void *w2_f16, const float *vecs6x128, int B, int P, int HW,
+                                        float *out_bphw, void *stream) {
+    if (B < 0 || P < 0 || HW <= 0 || Cf <= 0 || (Cf & 3) || (feat_cs & 3) || feat_cs < Cf) return IDH_EINVAL;
+    if (B == 0 || P == 0) return IDH_OK;
+    if (!feat_nhwc || !depth_bphw || !w1f_packed || !w2_f16 || !vecs6x128 || !out_bphw) return IDH_EINVAL;
+    const long long M = (long long)B * HW;
+    if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    BinArgs a{feat_nhwc, depth_bphw, prior_bphw, w1f_packed, static_cast<const float *>(w2_f16), vecs6x128, out_bphw,
+              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr};
+    return binary_mlp_launch(a, B, stream, true);
 }
 
 // Per-pixel binary search for the depth at which the occlusion MLP flips (reference
@@ -346,11 +455,11 @@ extern "C" int idh_binary_mlp_search_fwd(const float *feat_nhwc, int feat_cs, in
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
     BinArgs a{feat_nhwc, nullptr, prior_b1hw, w1f_packed, w2_packed, vecs6x128, last_logits_b1hw,
               (int)M, HW, 1, feat_cs, Cf, has_prior, prior_const, iters, lo, hi, logf(threshold / (1.f - threshold)),
-              search_depths_b1hw};
+              search_depths_b1hw, nullptr};
     return binary_mlp_launch(a, B, stream);
 }
 
-static int binary_mlp_launch(BinArgs a, int B, void *stream) {
+static int binary_mlp_launch(BinArgs a, int B, void *stream, bool f16) {
     const long long M = a.M;
     constexpr int TM = 1;
     const int tiles = (int)((M + 16 * TM - 1) / (16 * TM));
@@ -362,12 +471,18 @@ static int binary_mlp_launch(BinArgs a, int B, void *stream) {
                        6 * kHidden * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(binary_mlp_k<TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(binary_mlp_k<TM, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(binary_mlp_k<TM, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return IDH_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(binary_mlp_k<TM>, dim3(grid), dim3(kBinThreads), lds, idh_stream(stream), a);
+    if (f16) {
+        a.sw2 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.w2) + (size_t)4 * kNS * 2 * 64 * 16);
+        hipLaunchKernelGGL((binary_mlp_k<TM, true>), dim3(grid), dim3(kBinThreads), lds, idh_stream(stream), a);
+    } else
+        hipLaunchKernelGGL((binary_mlp_k<TM, false>), dim3(grid), dim3(kBinThreads), lds, idh_stream(stream), a);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }

@@ -15,10 +15,21 @@ from torch import nn
 from . import _lib
 
 
-def _prepared(seq: nn.Sequential, n_feat: int, use_prior: bool):
+def mlp_math_of(net) -> str:
+    """Arithmetic of the per-plane 128x128 layer: ``net.mlp_math`` if set, else
+    ``cost_volume.DEFAULT_MLP_MATH`` ("fp32" | "f16x3", see cost_volume.MLP_MATH_MODES)."""
+    from . import cost_volume as _cv
+
+    m = getattr(net, "mlp_math", None) or _cv.DEFAULT_MLP_MATH
+    if m not in _cv.MLP_MATH_MODES:
+        raise _lib.IdhError(f"unknown MLP math mode {m!r} (expected one of {_cv.MLP_MATH_MODES})")
+    return m
+
+
+def _prepared(seq: nn.Sequential, n_feat: int, use_prior: bool, math: str = "fp32"):
     """Fragment-ordered copies of one scale's three Linear layers, cached on the module."""
     l1, l2, l3 = seq[0], seq[2], seq[4]
-    key = tuple((p.data_ptr(), p._version) for p in seq.parameters())
+    key = (math,) + tuple((p.data_ptr(), p._version) for p in seq.parameters())
     c = seq.__dict__.get("_idh_mlp")
     if c is not None and c[0] == key:
         return c[1]
@@ -31,10 +42,14 @@ def _prepared(seq: nn.Sequential, n_feat: int, use_prior: bool):
     L = _lib.lib()
     dev = w1.device
     w1p = torch.empty(L.idh_packed_mlp_weight_floats(n_feat), device=dev)
-    w2p = torch.empty(L.idh_packed_mlp_weight_floats(128), device=dev)
     st = _lib.stream_ptr()
     _lib.check(L.idh_pack_mlp_weight(w1.data_ptr(), w1p.data_ptr(), w1.shape[1], 1, n_feat, st), "idh_pack_mlp_weight")
-    _lib.check(L.idh_pack_mlp_weight(w2.data_ptr(), w2p.data_ptr(), 128, 0, 128, st), "idh_pack_mlp_weight")
+    if math == "f16x3":
+        w2p = torch.empty(L.idh_packed_mlp_weight_f16_bytes(128) // 4, device=dev, dtype=torch.int32)
+        _lib.check(L.idh_pack_mlp_weight_f16(w2.data_ptr(), w2p.data_ptr(), 128, 0, 128, st), "idh_pack_mlp_weight_f16")
+    else:
+        w2p = torch.empty(L.idh_packed_mlp_weight_floats(128), device=dev)
+        _lib.check(L.idh_pack_mlp_weight(w2.data_ptr(), w2p.data_ptr(), 128, 0, 128, st), "idh_pack_mlp_weight")
     vecs = torch.zeros(6, 128, device=dev)
     vecs[0] = l1.bias.detach()
     vecs[1] = w1[:, 0]
@@ -58,7 +73,8 @@ def occlusion_logits(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, de
     P = depth_bphw.shape[1]
     if tuple(depth_bphw.shape) != (B, P, H, W):
         raise _lib.IdhError(f"rendered depth {tuple(depth_bphw.shape)} does not match features {(B, H, W)}")
-    w1p, w2p, vecs = _prepared(net.mlps[f"s{scale}"], n_feat, net.use_prior)
+    math = mlp_math_of(net)
+    w1p, w2p, vecs = _prepared(net.mlps[f"s{scale}"], n_feat, net.use_prior, math)
     depth = depth_bphw.contiguous()
     prior = None
     if prior_bphw is not None:
@@ -68,9 +84,10 @@ def occlusion_logits(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, de
     if out is None:
         out = torch.empty(B, P, H, W, device=feat_nhwc.device, dtype=torch.float32)
     L = _lib.lib()
+    fwd = L.idh_binary_mlp_f16x3_fwd if math == "f16x3" else L.idh_binary_mlp_fwd
     _lib.check(
-        L.idh_binary_mlp_fwd(feat_nhwc.data_ptr() + 4 * feat_c0, CS, n_feat, depth.data_ptr(), _lib.ptr(prior), int(net.use_prior), -1.0,
-                             w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(), B, P, H * W, out.data_ptr(), _lib.stream_ptr()),
+        fwd(feat_nhwc.data_ptr() + 4 * feat_c0, CS, n_feat, depth.data_ptr(), _lib.ptr(prior), int(net.use_prior), -1.0,
+            w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(), B, P, H * W, out.data_ptr(), _lib.stream_ptr()),
         "idh_binary_mlp_fwd")
     return out
 

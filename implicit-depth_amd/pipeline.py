@@ -199,6 +199,7 @@ class HotPathWorkload:
         self.mlp_math = getattr(args, "mlp_math", "fp32")
         if self.volume == "mlp":
             cv.mlp_math = self.mlp_math
+        mlp.mlp_math = self.mlp_math
         self.model = HotPath(cv, cve, dec, mlp, conv_math=self.conv_math).to(device)
         inp = syn.cost_volume_inputs(self.B, self.K, self.C, self.H, self.W, seed=rank)
         self.host_inputs = inp
@@ -258,7 +259,7 @@ class HotPathWorkload:
         dom = [op for op in convs if op.tile_m == 8]
         if self.conv_math != "fp32":
             dom = [op for op in convs if op.tile_m in (10, 11)]
-            self.dominant_kernel = "conv3x3_split_k<8, %d>" % (0 if self.conv_math == "bf16x6" else 1)
+            self.dominant_kernel = "conv3x3_split_k<8, 0>" if self.conv_math == "bf16x6" else "conv3x3_split_k<4, 1>"
         if not dom:  # small batches: every layer runs on the 4-row tile variant
             dom = [op for op in convs if op.tile_m == 9]
             self.dominant_kernel = "conv3x3_lds_k<1> + conv3x3_lds_group_k<1>"

@@ -134,6 +134,13 @@ int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float 
                        const float *prior_bphw, int has_prior, float prior_const,
                        const float *w1f_packed, const float *w2_packed, const float *vecs6x128, int B,
                        int P, int HW, float *out_bphw, void *stream);
+/* Same, with the per-plane 128x128 layer in "f16x3" split precision (w2_f16 from
+ * idh_pack_mlp_weight_f16, csrc/split_f16.h) and ELU's exp on v_exp_f32: fp32-equivalent results
+ * (tests/test_mlp_split_gpu.py) at a fraction of the fp32-MFMA cost. */
+int idh_binary_mlp_f16x3_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *depth_bphw,
+                             const float *prior_bphw, int has_prior, float prior_const,
+                             const float *w1f_packed, const void *w2_f16, const float *vecs6x128, int B,
+                             int P, int HW, float *out_bphw, void *stream);
 
 /* Fused per-pixel binary depth search (reference bd_model.py:273-292, infer_depth=True): `iters`
  * dependent evaluations of the same MLP at each pixel's current query depth, bounds [lo,hi], first

@@ -53,3 +53,22 @@ def test_f16x3_vs_fp32_kernel_with_scaled_inputs(K):
             vols[math] = vol
         a, b = vols["fp32"], vols["f16x3"]
         assert float((a - b).abs().max() / a.abs().max()) < 1e-5, gain
+
+
+# ---- BinaryMLP (csrc/mlp.hip binary_mlp_k<1, true>) ------------------------------------------------
+import test_mlp_gpu as mlp_base
+
+
+@pytest.mark.parametrize("use_prior", [False, True])
+def test_binary_mlp_golden_f16x3(use_prior, f16_mlp):
+    mlp_base.test_fused_logits_golden(use_prior)
+
+
+@pytest.mark.parametrize("use_prior", [False, True])
+def test_binary_mlp_module_interface_f16x3(use_prior, f16_mlp):
+    mlp_base.test_module_interface_matches_oracle(use_prior)
+
+
+def test_binary_mlp_odd_sizes_and_scales_f16x3(f16_mlp):
+    mlp_base.test_prior_absent_is_minus_one_and_odd_sizes()
+    mlp_base.test_all_scales_interface()
