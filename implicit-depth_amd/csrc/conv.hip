@@ -729,10 +729,12 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     pc.lds_rows = 0;
     if (op.tile_m == IDH_SPLIT_BF16X6 || op.tile_m == IDH_SPLIT_F16X3) {
         // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
-        if (!lds_ok || a.s[1].in || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1) return IDH_EUNSUPPORTED;
+        if (!lds_ok || a.s[1].in || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1 || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16))
+            return IDH_EUNSUPPORTED;
         a.NT = op.Cout / 64;
         pc.lds_rows = 16;
         pc.tm = op.tile_m;
+        pc.tn = op.tile_n == 8 ? 8 : 16;  // tile rows
         pc.n_img = op.N;
         pc.blocks = 0;
     } else if (lds_ok && (op.tile_m == 8 || op.tile_m == 0 || op.tile_m == 9)) {
@@ -767,7 +769,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
 }
 
 int launch_conv(const PreparedConv &pc, hipStream_t st) {
-    if (pc.lds_rows == 16) return launch_conv_split(pc.a, pc.n_img, pc.tm, st);
+    if (pc.lds_rows == 16) return launch_conv_split(pc.a, pc.n_img, pc.tm, pc.tn, st);
     if (pc.lds_rows == 8) hipLaunchKernelGGL(conv3x3_lds_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 4) hipLaunchKernelGGL(conv3x3_lds_k<1>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else {

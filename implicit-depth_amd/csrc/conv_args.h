@@ -39,6 +39,6 @@ constexpr int kZeroFloats = 4096;
 
 // conv_split.hip
 constexpr int kSplitTile = 16;  // 16x16 output pixels x 64 channels per workgroup
-int launch_conv_split(const ConvArgs &a, int N, int mode, hipStream_t st);  // mode = IDH_SPLIT_*
+int launch_conv_split(const ConvArgs &a, int N, int mode, int rows, hipStream_t st);  // mode = IDH_SPLIT_*, rows = 16 | 8
 
 }  // namespace idh_conv

@@ -49,14 +49,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int MODE_BF16X6 = 0, MODE_F16X3 = 1;
-constexpr int kHalo = kSplitTile + 2;    // 18
-constexpr int kHaloPix = kHalo * kHalo;  // 324
-constexpr int kPlane = 328;              // slots per (piece, kg) plane: 328*16 B = bank offset 32 -> conflict-free b64 writes
+constexpr int kHalo = kSplitTile + 2;    // 18 halo columns
 constexpr int kMinExp = -100;            // lower clamp of the scaling exponents (all-zero tiles)
 
 constexpr int pieces_of(int mode) { return mode == MODE_BF16X6 ? 3 : 2; }
 constexpr int wslots_of(int mode) { return 3 * pieces_of(mode) * 2 * 64; }  // 16-B slots per (chunk, tap row, 64-channel tile)
-constexpr int lds_bytes_of(int mode) { return (pieces_of(mode) * 2 * kPlane + 2 * wslots_of(mode)) * 16 + 64; }
+// slots per (piece, kg) plane of a (rows+2) x 18 halo, padded to 8 mod 16 slots (bank offset 32 between the
+// two kg planes -> conflict-free ds_write_b64): 324 -> 328 (16 rows), 180 -> 184 (8 rows)
+constexpr int plane_of(int rows) { return (((rows + 2) * kHalo + 7) / 16) * 16 + 8; }
+constexpr int lds_bytes_of(int mode, int rows) { return (pieces_of(mode) * 2 * plane_of(rows) + 2 * wslots_of(mode)) * 16 + 64; }
 
 __device__ float g_zero16[16];
 
@@ -89,15 +90,19 @@ __device__ __forceinline__ int exponent_of(unsigned bits) {
     return e < kMinExp ? kMinExp : e;
 }
 
-// WAVES = 4: each wave owns 4 tile rows (2 pixel groups, 64 accumulator registers), 2 waves per SIMD;
-// WAVES = 8: each wave owns 2 tile rows (1 pixel group, 32 accumulators, <= 128 VGPRs), 4 waves per SIMD.
-template <int WAVES, int MODE>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 2) void conv3x3_split_k(const ConvArgs a, int tiles_x, int tiles_y) {
+// Tile = (2 G WAVES) rows x 16 columns x 64 channels; each wave owns 2G rows = G 32-pixel MFMA column groups.
+//   <4, 2>: 16 rows, 64 accumulator registers per wave, 166 VGPRs (f16x3) -> 3 workgroups / CU
+//   <8, 1>: 16 rows, 32 accumulators, <= 128 VGPRs -> 2 workgroups x 8 waves
+//   <4, 1>:  8 rows (twice the workgroups: small maps / small batches), 36 KiB (f16x3) -> 4 workgroups / CU
+template <int WAVES, int G, int MODE>
+__global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(const ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int NP = pieces_of(MODE);
     constexpr int kWSlots = wslots_of(MODE);
+    constexpr int kRows = 2 * G * WAVES;
+    constexpr int kHaloPix = (kRows + 2) * kHalo;
+    constexpr int kPlane = plane_of(kRows);
     constexpr int kHaloSlots = NP * 2 * kPlane;
     constexpr int NT_ = 64 * WAVES;                          // threads
-    constexpr int G = 8 / WAVES;                             // 32-pixel groups per wave
     constexpr int kHaloLoads = (kHaloPix * 4 + NT_ - 1) / NT_;
     constexpr int kWLoads = (kWSlots + NT_ - 1) / NT_;
     constexpr int kWFullWaves = (kWSlots - (kWLoads - 1) * NT_) / 64;  // waves that own a slot in the last round
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void conv3x3_split_k(const C
     const int tx = blk % tiles_x; blk /= tiles_x;
     const int ty = blk % tiles_y;
     const int n = blk / tiles_y;
-    const int y0 = ty * kSplitTile, x0 = tx * kSplitTile;
+    const int y0 = ty * kRows, x0 = tx * kSplitTile;
     const int n0 = nt * 64;
     const ConvSrc &s = a.s[0];
     const int nC = s.cblocks;
@@ -293,7 +298,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void conv3x3_split_k(const C
         if (oy >= a.Ho || ox >= a.Wo) continue;
         const size_t m = ((size_t)n * a.Ho + oy) * a.Wo + ox;
         float *o = a.out + m * a.out_cs;
+#ifdef IDH_ABL_NORES
+        const float *rp = nullptr;
+#else
         const float *rp = a.res ? a.res + m * a.res_cs : nullptr;
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -307,6 +316,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 2) void conv3x3_split_k(const C
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act, a.slope);
                 }
+#ifdef IDH_ABL_NOSTORE
+                if (v[0] == 123.456f)
+#endif
                 *reinterpret_cast<f32x4 *>(o + co) = v;
             }
     }
@@ -382,20 +394,21 @@ __global__ __launch_bounds__(256) void pack_split_weight_k(const float *__restri
 inline int ceil16i(int v) { return (v + 15) & ~15; }
 inline size_t panel_bytes(int mode, int Cout, int Cin) { return (size_t)(ceil16i(Cin) / 16) * 3 * (Cout / 64) * wslots_of(mode) * 16; }
 
-template <int WAVES, int MODE>
+template <int WAVES, int G, int MODE>
 int launch_one(const ConvArgs &a, int N, hipStream_t st) {
+    constexpr int kRows = 2 * G * WAVES;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_k<WAVES, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes_of(MODE)) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_k<WAVES, G, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes_of(MODE, kRows)) != hipSuccess)
             return IDH_ELAUNCH;
         attr_done = true;
     }
-    const int tiles_x = (a.Wo + kSplitTile - 1) / kSplitTile, tiles_y = (a.Ho + kSplitTile - 1) / kSplitTile;
+    const int tiles_x = (a.Wo + kSplitTile - 1) / kSplitTile, tiles_y = (a.Ho + kRows - 1) / kRows;
     const long long blocks = (long long)N * tiles_x * tiles_y * a.NT;
     if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3x3_split_k<WAVES, MODE>), dim3((unsigned)blocks), dim3(64 * WAVES), lds_bytes_of(MODE), st, a, tiles_x,
-                       tiles_y);
+    hipLaunchKernelGGL((conv3x3_split_k<WAVES, G, MODE>), dim3((unsigned)blocks), dim3(64 * WAVES), lds_bytes_of(MODE, kRows), st, a,
+                       tiles_x, tiles_y);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }
@@ -404,13 +417,18 @@ int launch_one(const ConvArgs &a, int N, hipStream_t st) {
 
 namespace idh_conv {
 
-int launch_conv_split(const ConvArgs &a, int N, int mode, hipStream_t st) {
+int launch_conv_split(const ConvArgs &a, int N, int mode, int rows, hipStream_t st) {
+    if (rows == 8) {
+        if (mode == IDH_SPLIT_BF16X6) return launch_one<4, 1, MODE_BF16X6>(a, N, st);
+        if (mode == IDH_SPLIT_F16X3) return launch_one<4, 1, MODE_F16X3>(a, N, st);
+        return IDH_EINVAL;
+    }
     // measured on MI355X (tools/perf_split.py): f16x3 is 5-9 % faster with 4 waves (166 VGPRs, 44.5 KiB ->
     // 3 workgroups per CU), bf16x6 is indifferent (4 waves: 206 VGPRs -> 2 workgroups either way)
     static const int env_waves = getenv("IDH_SPLIT_WAVES") ? atoi(getenv("IDH_SPLIT_WAVES")) : 0;
     const int waves = env_waves ? env_waves : (mode == IDH_SPLIT_F16X3 ? 4 : 8);
-    if (mode == IDH_SPLIT_BF16X6) return waves == 4 ? launch_one<4, MODE_BF16X6>(a, N, st) : launch_one<8, MODE_BF16X6>(a, N, st);
-    if (mode == IDH_SPLIT_F16X3) return waves == 4 ? launch_one<4, MODE_F16X3>(a, N, st) : launch_one<8, MODE_F16X3>(a, N, st);
+    if (mode == IDH_SPLIT_BF16X6) return waves == 4 ? launch_one<4, 2, MODE_BF16X6>(a, N, st) : launch_one<8, 1, MODE_BF16X6>(a, N, st);
+    if (mode == IDH_SPLIT_F16X3) return waves == 4 ? launch_one<4, 2, MODE_F16X3>(a, N, st) : launch_one<8, 1, MODE_F16X3>(a, N, st);
     return IDH_EINVAL;
 }
 

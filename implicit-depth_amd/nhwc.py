@@ -153,16 +153,26 @@ def split_packed_weight(conv: nn.Conv2d, math: str) -> torch.Tensor:
 # 3/16 of the fp32-MFMA cost.
 MATH_MODES = ("fp32", "bf16x6", "f16x3")
 DEFAULT_MATH = os.environ.get("IDH_CONV_MATH", "fp32")
-SPLIT_MIN_BLOCKS = 256  # fewer 16x16x64 tiles than CUs: the fp32 kernels' finer tiles win
+SPLIT_MIN_BLOCKS = 256  # fewer 8x16x64 tiles than CUs: the fp32 kernels' finer tiles win
 
 
 def split_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> bool:
     (v0, c0) = srcs[0]
     if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64:
         return False
-    if Wo < 16 or Ho < 16:
+    if Wo < 16 or Ho < 8:
         return False
-    return N * (-(-Ho // 16)) * (-(-Wo // 16)) * (cout // 64) >= SPLIT_MIN_BLOCKS
+    return N * (-(-Ho // 8)) * (-(-Wo // 16)) * (cout // 64) >= SPLIT_MIN_BLOCKS
+
+
+def choose_split_rows(N: int, Ho: int, Wo: int, cout: int) -> int:
+    """16-row tiles (best weight-panel amortisation) when they fill 256 CUs x 3 resident workgroups
+    without wasting rows, else 8-row tiles (twice the workgroups, no waste on 24-row maps)."""
+    def eff(rows, bonus):
+        ty = -(-Ho // rows)
+        blocks = N * ty * (-(-Wo // 16)) * (cout // 64)
+        return bonus * (Ho / (ty * rows)) * min(1.0, blocks / 768.0)
+    return 16 if Ho >= 16 and eff(16, 1.0) >= eff(8, 0.93) else 8
 
 
 TARGET_WAVES = 2048  # ~2 waves per SIMD over 256 CUs x 4 SIMDs
@@ -270,7 +280,7 @@ class Plan:
         op.act, op.slope = act, slope
         M = out.N * out.H * out.W
         if use_split:
-            tm, tn, split = SPLIT_CODE[self.math], 0, 1
+            tm, tn, split = SPLIT_CODE[self.math], choose_split_rows(out.N, out.H, out.W, conv.out_channels), 1
         elif lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
             chunks = sum(ceil16(v.C) // 16 for v, _ in srcs)
             tm, split = choose_lds_tile(out.N, out.H, out.W, conv.out_channels, chunks)

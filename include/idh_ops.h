@@ -61,7 +61,8 @@ typedef struct idh_op {
                                tile_m = 8 / 9 selects the LDS-staged kernel with 8- / 4-row tiles;
                                tile_m = IDH_SPLIT_BF16X6 / IDH_SPLIT_F16X3 selects the split-precision
                                kernel (3x3 stride 1, one source, Cout % 64 == 0; src[0].w =
-                               idh_pack_conv_weight_split output of the same mode) */
+                               idh_pack_conv_weight_split output of the same mode); there tile_n = 8
+                               selects 8-row instead of 16-row tiles */
     int32_t group;        /* != 0: consecutive conv ops with the same id are mutually independent and
                                may be launched as ONE grid (see Plan.schedule in nhwc.py) */
 } idh_op;

@@ -29,8 +29,11 @@ def split_math(request):
     nhwc.DEFAULT_MATH = old
 
 
+rows_used = set()
+
+
 def _rel(a, b):
-    return float((a - b).abs().max() / b.abs().max())
+    return float((a - b).detach().abs().max() / b.detach().abs().max())
 
 
 def _conv_plan(x, conv, act=nhwc.ACT_NONE, res=None, math="bf16x6"):
@@ -56,7 +59,8 @@ def _conv_plan(x, conv, act=nhwc.ACT_NONE, res=None, math="bf16x6"):
 
 
 @pytest.mark.parametrize("math", MODES)
-@pytest.mark.parametrize("cin,cout,H,W,N", [(64, 64, 32, 48, 8), (48, 128, 16, 16, 4), (192, 64, 40, 72, 2), (20, 64, 33, 50, 3)])
+@pytest.mark.parametrize("cin,cout,H,W,N", [(64, 64, 32, 48, 8), (48, 128, 16, 16, 4), (192, 64, 40, 72, 2), (20, 64, 33, 50, 3), (32, 64, 8, 16, 1),
+                                            (64, 64, 64, 64, 48)])
 def test_split_conv_matches_fp64(cin, cout, H, W, N, math):
     torch.manual_seed(cin + cout)
     dev = torch.device("cuda:0")
@@ -68,6 +72,7 @@ def test_split_conv_matches_fp64(cin, cout, H, W, N, math):
     try:
         y, p = _conv_plan(x, conv, act=nhwc.ACT_LRELU, res=res, math=math)
         assert [op.tile_m for op in p.ops if op.kind == nhwc.OP_CONV] == [nhwc.SPLIT_CODE[math]]
+        rows_used.add([op.tile_n for op in p.ops if op.kind == nhwc.OP_CONV][0])
         y32, _ = _conv_plan(x, conv, act=nhwc.ACT_LRELU, res=res, math="fp32")
     finally:
         nhwc.SPLIT_MIN_BLOCKS = old
@@ -144,3 +149,7 @@ def test_split_basic_block_matches_oracle(split_math):
             assert _rel(y.cpu(), ref) < 1e-5
     finally:
         nhwc.SPLIT_MIN_BLOCKS = old
+
+
+def test_zz_both_tile_heights_were_exercised():
+    assert rows_used >= {8, 16}, rows_used

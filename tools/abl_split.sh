@@ -10,6 +10,6 @@ if [ "$1" = build ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls implicit-depth_amd/_obj/*.o | grep -v conv_split.o) /tmp/conv_split_$name.o -o implicit-depth_amd/lib/libidh_abl_$name.so && echo built $name
   done
 else
-  echo "== base"; python tools/perf_split.py 32 | cut -c1-30,68-120
-  for v in $VARS; do name=${v//,/_}; echo "== $name"; IDH_LIB=$PWD/implicit-depth_amd/lib/libidh_abl_$name.so python tools/perf_split.py 32 | cut -c1-30,68-120; done
+  echo "== base"; python tools/perf_split.py 32 | cut -c1-30,100-200
+  for v in $VARS; do name=${v//,/_}; echo "== $name"; IDH_LIB=$PWD/implicit-depth_amd/lib/libidh_abl_$name.so python tools/perf_split.py 32 | cut -c1-30,100-200; done
 fi
