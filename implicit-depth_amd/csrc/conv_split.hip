@@ -34,6 +34,8 @@
 // chunk are register-prefetched under the MFMAs.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_args.h"
 #include "../../include/idh_ops.h"
 
@@ -94,7 +96,8 @@ __device__ __forceinline__ int exponent_of(unsigned bits) {
 //   <4, 2>: 16 rows, 64 accumulator registers per wave, 166 VGPRs (f16x3) -> 3 workgroups / CU
 //   <8, 1>: 16 rows, 32 accumulators, <= 128 VGPRs -> 2 workgroups x 8 waves
 //   <4, 1>:  8 rows (twice the workgroups: small maps / small batches), 36 KiB (f16x3) -> 4 workgroups / CU
-template <int WAVES, int G, int MODE>
+//   SRC2: compiled with the fused 1x1 second source (its extra loop costs registers: <4, 2> drops to 2 workgroups / CU)
+template <int WAVES, int G, int MODE, bool SRC2>
 __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(const ConvArgs a, int tiles_x, int tiles_y) {
     constexpr int NP = pieces_of(MODE);
     constexpr int kWSlots = wslots_of(MODE);
@@ -128,6 +131,11 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
     const ConvSrc &s = a.s[0];
     const int nC = s.cblocks;
     const int nPh = 3 * nC;
+    // optional second source: 1x1 projection of another tensor (BasicBlock's downsample(x), layers.py:68-75),
+    // one centre-tap phase per 16-channel chunk, accumulated into the same tile
+    const int nC2 = SRC2 ? a.s[1].cblocks : 0;
+    const int nChunks = nC + nC2, nPhases = nPh + nC2;
+    constexpr int kW1Slots = kWSlots / 3;  // one tap
 
     f32x16 acc[G][2];
 #pragma unroll
@@ -140,7 +148,11 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
 
     f32x4 ph_[kHaloLoads];
     u32x4 pw_[kWLoads];
-    auto issue_halo = [&](int c) {
+    auto issue_halo = [&](int cc) {  // cc indexes [source-0 chunks][source-1 chunks]
+        const bool second = SRC2 && cc >= nC;
+        const float *base = second ? a.s[1].in : s.in;
+        const int cs = second ? a.s[1].cs : s.cs;
+        const int ch = 16 * (second ? cc - nC : cc);
 #pragma unroll
         for (int k = 0; k < kHaloLoads; ++k) {
             const int slot = tid + NT_ * k;
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
             const int hy = pix / kHalo, hx = pix - hy * kHalo;
             const int iy = y0 + hy - 1, ix = x0 + hx - 1;
             const bool ok = (pix < kHaloPix) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
-            const float *src = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero16;
+            const float *src = ok ? base + ((size_t)(n * s.H + iy) * s.W + ix) * cs + ch + 4 * q : g_zero16;
             ph_[k] = *reinterpret_cast<const f32x4 *>(src);
         }
     };
@@ -203,12 +215,16 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
             }
         }
     };
-    auto issue_w = [&](int ph) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(s.w) + ((size_t)ph * a.NT + nt) * kWSlots;
+    auto issue_w = [&](int ph) {  // ph indexes [3x3 tap-row panels][1x1 panels]
+        const u32x4 *w0 = reinterpret_cast<const u32x4 *>(s.w);
+        const bool second = SRC2 && ph >= nPh;
+        const u32x4 *src = second ? w0 + (size_t)nPh * a.NT * kWSlots + ((size_t)(ph - nPh) * a.NT + nt) * kW1Slots
+                                  : w0 + ((size_t)ph * a.NT + nt) * kWSlots;
+        const int last = (second ? kW1Slots : kWSlots) - 1;
 #pragma unroll
         for (int k = 0; k < kWLoads; ++k) {
             const int slot = tid + NT_ * k;
-            pw_[k] = src[slot < kWSlots ? slot : kWSlots - 1];
+            pw_[k] = src[slot < last ? slot : last];
         }
     };
     auto commit_w = [&](int buf) {
@@ -216,11 +232,13 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
         for (int k = 0; k < kWLoads; ++k)
             if (k < kWLoads - 1 || wave < kWFullWaves) sW[buf * kWSlots + tid + NT_ * k] = pw_[k];
     };
-    auto compute = [&](int r, int buf) {
+    // taps (r, t0 .. t0 + NTAPS - 1) of the staged halo against weight taps 0 .. NTAPS - 1 of buffer `buf`
+    auto compute = [&](int r, int buf, auto ntaps_c, int t0) {
+        constexpr int NTAPS = decltype(ntaps_c)::value;
         const u32x4 *wb = sW + buf * kWSlots + kg * 64 + p;
-        const u32x4 *hb = sH + kg * kPlane + (2 * G * wave + prow + r) * kHalo + px;
+        const u32x4 *hb = sH + kg * kPlane + (2 * G * wave + prow + r) * kHalo + px + t0;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NTAPS; ++t) {
             u32x4 A[2][NP], B[G][NP];
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) {
@@ -249,11 +267,8 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
         }
     };
 
-    issue_halo(0);
-    issue_w(0);
-    int ph = 0;
-#pragma unroll 1
-    for (int c = 0; c < nC; ++c) {
+    // start of a chunk: (f16x3) fold the chunk maximum into the running scale, then split + stage the halo
+    auto begin_chunk = [&](int c) {
         float mul = 1.f;
         if constexpr (MODE == MODE_F16X3) {
             publish_max(c & 1);
@@ -278,19 +293,40 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
             if (c > 0) __syncthreads();  // every wave is done reading the previous chunk's halo
         }
         commit_halo(mul);
+    };
+
+    issue_halo(0);
+    issue_w(0);
+    int ph = 0;
+#pragma unroll 1
+    for (int c = 0; c < nC; ++c) {
+        begin_chunk(c);
 #pragma unroll
         for (int r = 0; r < 3; ++r, ++ph) {
             commit_w(ph & 1);
             __syncthreads();
-            issue_w(ph + 1 < nPh ? ph + 1 : ph);  // unconditional (re-reads the last panel at the end)
-            if (r == 0) issue_halo(c + 1 < nC ? c + 1 : c);
+            issue_w(ph + 1 < nPhases ? ph + 1 : ph);  // unconditional (re-reads the last panel at the end)
+            if (r == 0) issue_halo(c + 1 < nChunks ? c + 1 : c);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ahead of the MFMAs that hide them
-            compute(r, ph & 1);
+            compute(r, ph & 1, std::integral_constant<int, 3>{}, 0);
+        }
+    }
+    if constexpr (SRC2) {
+#pragma unroll 1
+        for (int c = nC; c < nChunks; ++c, ++ph) {  // 1x1 source: the centre tap of each chunk
+            begin_chunk(c);
+            commit_w(ph & 1);
+            __syncthreads();
+            issue_w(ph + 1 < nPhases ? ph + 1 : ph);
+            issue_halo(c + 1 < nChunks ? c + 1 : c);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1, ph & 1, std::integral_constant<int, 1>{}, 1);
         }
     }
 
     // epilogue: C/D of 32x32: column = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (channel)
-    const float *wscale = reinterpret_cast<const float *>(reinterpret_cast<const u32x4 *>(s.w) + (size_t)nPh * a.NT * kWSlots);
+    const float *wscale =
+        reinterpret_cast<const float *>(reinterpret_cast<const u32x4 *>(s.w) + (size_t)nPh * a.NT * kWSlots + (size_t)nC2 * a.NT * kW1Slots);
     const float sx = MODE == MODE_F16X3 ? exp2_int(E - 14 < -126 ? -126 : E - 14) : 1.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -325,13 +361,13 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
 }
 
 // per output channel: exponent of max |w| (MODE_F16X3 weight scale); one workgroup per channel
-__global__ __launch_bounds__(256) void weight_exponent_k(const float *__restrict__ w, int *__restrict__ wexp, float *__restrict__ wscale,
-                                                         int per_cout) {
+__global__ __launch_bounds__(256) void weight_exponent_k(const float *__restrict__ w, const float *__restrict__ w2, int *__restrict__ wexp,
+                                                         float *__restrict__ wscale, int per_cout, int per_cout2) {
     __shared__ float sm[256];
     const int co = blockIdx.x;
     float m = 0.f;
-    for (int i = threadIdx.x; i < per_cout; i += 256) {
-        const float v = w[(size_t)co * per_cout + i];
+    for (int i = threadIdx.x; i < per_cout + per_cout2; i += 256) {
+        const float v = i < per_cout ? w[(size_t)co * per_cout + i] : w2[(size_t)co * per_cout2 + (i - per_cout)];
         m = fmaxf(m, fabsf(v));
         if ((__float_as_uint(v) & 0x7F800000u) == 0x7F800000u) m = __uint_as_float(0x7F800000u);
     }
@@ -348,28 +384,30 @@ __global__ __launch_bounds__(256) void weight_exponent_k(const float *__restrict
     }
 }
 
-// OIHW fp32 -> [chunk][tap row][co tile][tap in row][piece][kg][co 64][8 x 16 bit], zero padded
-template <int MODE>
+// OIHW fp32 -> [chunk][tap row][co tile][tap in row][piece][kg][co 64][8 x 16 bit], zero padded.
+// KS = 3: 3x3 weights; KS = 1: 1x1 weights -> [chunk][co tile][piece][kg][co 64][8] (one "tap row" of one tap)
+template <int MODE, int KS>
 __global__ __launch_bounds__(256) void pack_split_weight_k(const float *__restrict__ w, u32x4 *__restrict__ dst,
                                                            const int *__restrict__ wexp, int Cout, int Cin, int nC, int NT) {
     constexpr int NP = pieces_of(MODE);
-    constexpr int kWSlots = wslots_of(MODE);
-    const long long total = (long long)nC * 3 * NT * 3 * 2 * 64;
+    constexpr int kTapsRow = KS == 3 ? 3 : 1, kRowsK = KS == 3 ? 3 : 1;
+    constexpr int kWSlots = wslots_of(MODE) / 3 * kTapsRow;
+    const long long total = (long long)nC * kRowsK * NT * kTapsRow * 2 * 64;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
         long long rr = i;
         const int co = (int)(rr % 64); rr /= 64;
         const int kg = (int)(rr % 2); rr /= 2;
-        const int t = (int)(rr % 3); rr /= 3;
+        const int t = (int)(rr % kTapsRow); rr /= kTapsRow;
         const int nt = (int)(rr % NT); rr /= NT;
-        const int r = (int)(rr % 3);
-        const int c = (int)(rr / 3);
+        const int r = (int)(rr % kRowsK);
+        const int c = (int)(rr / kRowsK);
         const int cout = 64 * nt + co, tap = 3 * r + t;
         unsigned h[8][NP];
         float mul = 1.f;
         if constexpr (MODE == MODE_F16X3) mul = exp2_int(14 - wexp[cout]);
         for (int e = 0; e < 8; ++e) {
             const int ci = 16 * c + 8 * kg + e;
-            const float v = (ci < Cin && cout < Cout) ? w[((size_t)cout * Cin + ci) * 9 + tap] : 0.f;
+            const float v = (ci < Cin && cout < Cout) ? w[((size_t)cout * Cin + ci) * (KS * KS) + tap] : 0.f;
             if constexpr (MODE == MODE_BF16X6) {
                 split3_bf16(v, h[e][0], h[e][1], h[e][2]);
             } else {
@@ -379,7 +417,7 @@ __global__ __launch_bounds__(256) void pack_split_weight_k(const float *__restri
                 h[e][1] = __builtin_bit_cast(unsigned short, a1);
             }
         }
-        const size_t base = ((size_t)(c * 3 + r) * NT + nt) * kWSlots;
+        const size_t base = ((size_t)(c * kRowsK + r) * NT + nt) * kWSlots;
         for (int pc = 0; pc < NP; ++pc) {
             u32x4 v;
             if constexpr (MODE == MODE_BF16X6)
@@ -393,22 +431,31 @@ __global__ __launch_bounds__(256) void pack_split_weight_k(const float *__restri
 
 inline int ceil16i(int v) { return (v + 15) & ~15; }
 inline size_t panel_bytes(int mode, int Cout, int Cin) { return (size_t)(ceil16i(Cin) / 16) * 3 * (Cout / 64) * wslots_of(mode) * 16; }
+inline size_t panel1_bytes(int mode, int Cout, int Cin2) { return Cin2 > 0 ? (size_t)(ceil16i(Cin2) / 16) * (Cout / 64) * (wslots_of(mode) / 3) * 16 : 0; }
+
+template <int WAVES, int G, int MODE, bool SRC2>
+int launch_one_src(const ConvArgs &a, int N, hipStream_t st);
 
 template <int WAVES, int G, int MODE>
 int launch_one(const ConvArgs &a, int N, hipStream_t st) {
+    return a.s[1].in ? launch_one_src<WAVES, G, MODE, true>(a, N, st) : launch_one_src<WAVES, G, MODE, false>(a, N, st);
+}
+
+template <int WAVES, int G, int MODE, bool SRC2>
+int launch_one_src(const ConvArgs &a, int N, hipStream_t st) {
     constexpr int kRows = 2 * G * WAVES;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_k<WAVES, G, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes_of(MODE, kRows)) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_k<WAVES, G, MODE, SRC2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_of(MODE, kRows)) != hipSuccess)
             return IDH_ELAUNCH;
         attr_done = true;
     }
     const int tiles_x = (a.Wo + kSplitTile - 1) / kSplitTile, tiles_y = (a.Ho + kRows - 1) / kRows;
     const long long blocks = (long long)N * tiles_x * tiles_y * a.NT;
     if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3x3_split_k<WAVES, G, MODE>), dim3((unsigned)blocks), dim3(64 * WAVES), lds_bytes_of(MODE, kRows), st, a,
-                       tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv3x3_split_k<WAVES, G, MODE, SRC2>), dim3((unsigned)blocks), dim3(64 * WAVES), lds_bytes_of(MODE, kRows), st,
+                       a, tiles_x, tiles_y);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }
@@ -434,29 +481,37 @@ int launch_conv_split(const ConvArgs &a, int N, int mode, int rows, hipStream_t 
 
 }  // namespace idh_conv
 
-extern "C" size_t idh_packed_split_weight_bytes(int Cout, int Cin, int mode) {
-    if (Cout <= 0 || Cin <= 0 || Cout % 64 || (mode != IDH_SPLIT_BF16X6 && mode != IDH_SPLIT_F16X3)) return 0;
+extern "C" size_t idh_packed_split_weight_bytes(int Cout, int Cin, int Cin_1x1, int mode) {
+    if (Cout <= 0 || Cin <= 0 || Cin_1x1 < 0 || Cout % 64 || (mode != IDH_SPLIT_BF16X6 && mode != IDH_SPLIT_F16X3)) return 0;
     const int m = mode == IDH_SPLIT_BF16X6 ? MODE_BF16X6 : MODE_F16X3;
-    return panel_bytes(m, Cout, Cin) + (size_t)Cout * 8;  // + per-channel scale floats + exponents
+    return panel_bytes(m, Cout, Cin) + panel1_bytes(m, Cout, Cin_1x1) + (size_t)Cout * 8;  // + per-channel scale floats + exponents
 }
 
-extern "C" int idh_pack_conv_weight_split(const float *w, void *dst, int Cout, int Cin, int mode, void *stream) {
-    if (!w || !dst || Cout <= 0 || Cin <= 0 || (mode != IDH_SPLIT_BF16X6 && mode != IDH_SPLIT_F16X3)) return IDH_EINVAL;
+extern "C" int idh_pack_conv_weight_split(const float *w, const float *w_1x1, void *dst, int Cout, int Cin, int Cin_1x1, int mode,
+                                          void *stream) {
+    if (!w || !dst || Cout <= 0 || Cin <= 0 || Cin_1x1 < 0 || (Cin_1x1 > 0) != (w_1x1 != nullptr) ||
+        (mode != IDH_SPLIT_BF16X6 && mode != IDH_SPLIT_F16X3))
+        return IDH_EINVAL;
     if (Cout % 64) return IDH_EUNSUPPORTED;
     const int m = mode == IDH_SPLIT_BF16X6 ? MODE_BF16X6 : MODE_F16X3;
-    const int nC = ceil16i(Cin) / 16, NT = Cout / 64;
-    float *wscale = reinterpret_cast<float *>(static_cast<char *>(dst) + panel_bytes(m, Cout, Cin));
+    const int nC = ceil16i(Cin) / 16, NT = Cout / 64, nC2 = Cin_1x1 > 0 ? ceil16i(Cin_1x1) / 16 : 0;
+    char *d8 = static_cast<char *>(dst);
+    u32x4 *d3 = reinterpret_cast<u32x4 *>(d8), *d1 = reinterpret_cast<u32x4 *>(d8 + panel_bytes(m, Cout, Cin));
+    float *wscale = reinterpret_cast<float *>(d8 + panel_bytes(m, Cout, Cin) + panel1_bytes(m, Cout, Cin_1x1));
     int *wexp = reinterpret_cast<int *>(wscale + Cout);
     hipStream_t st = idh_stream(stream);
-    hipLaunchKernelGGL(weight_exponent_k, dim3(Cout), dim3(256), 0, st, w, wexp, wscale, Cin * 9);
+    hipLaunchKernelGGL(weight_exponent_k, dim3(Cout), dim3(256), 0, st, w, w_1x1, wexp, wscale, Cin * 9, Cin_1x1);
     IDH_CHECK_LAUNCH();
-    const long long total = (long long)nC * 3 * NT * 3 * 2 * 64;
-    int grid = idh_cdiv(total, 256);
-    if (grid > 4096) grid = 4096;
-    if (m == MODE_BF16X6)
-        hipLaunchKernelGGL(pack_split_weight_k<MODE_BF16X6>, dim3(grid), dim3(256), 0, st, w, reinterpret_cast<u32x4 *>(dst), wexp, Cout, Cin, nC, NT);
-    else
-        hipLaunchKernelGGL(pack_split_weight_k<MODE_F16X3>, dim3(grid), dim3(256), 0, st, w, reinterpret_cast<u32x4 *>(dst), wexp, Cout, Cin, nC, NT);
+    auto grid_of = [](long long total) { int g = idh_cdiv(total, 256); return g > 4096 ? 4096 : g; };
+    const int g3 = grid_of((long long)nC * 3 * NT * 3 * 2 * 64);
+    if (m == MODE_BF16X6) hipLaunchKernelGGL((pack_split_weight_k<MODE_BF16X6, 3>), dim3(g3), dim3(256), 0, st, w, d3, wexp, Cout, Cin, nC, NT);
+    else hipLaunchKernelGGL((pack_split_weight_k<MODE_F16X3, 3>), dim3(g3), dim3(256), 0, st, w, d3, wexp, Cout, Cin, nC, NT);
     IDH_CHECK_LAUNCH();
+    if (nC2 > 0) {
+        const int g1 = grid_of((long long)nC2 * NT * 2 * 64);
+        if (m == MODE_BF16X6) hipLaunchKernelGGL((pack_split_weight_k<MODE_BF16X6, 1>), dim3(g1), dim3(256), 0, st, w_1x1, d1, wexp, Cout, Cin_1x1, nC2, NT);
+        else hipLaunchKernelGGL((pack_split_weight_k<MODE_F16X3, 1>), dim3(g1), dim3(256), 0, st, w_1x1, d1, wexp, Cout, Cin_1x1, nC2, NT);
+        IDH_CHECK_LAUNCH();
+    }
     return IDH_OK;
 }

@@ -124,23 +124,33 @@ def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
 SPLIT_CODE = {"bf16x6": 10, "f16x3": 11}  # IDH_SPLIT_* of include/idh_ops.h == the op's tile_m
 
 
-def split_packed_weight(conv: nn.Conv2d, math: str) -> torch.Tensor:
-    """16-bit-piece copy of a 3x3 Conv2d weight in the LDS image order of csrc/conv_split.hip
-    (idh_pack_conv_weight_split); cached like ``packed_weight``."""
+def split_packed_weight(conv: nn.Conv2d, math: str, proj: Optional[nn.Conv2d] = None) -> torch.Tensor:
+    """16-bit-piece copy of a 3x3 Conv2d weight (and, fused behind it, of the 1x1 projection that shares
+    its accumulator) in the LDS image order of csrc/conv_split.hip (idh_pack_conv_weight_split);
+    cached like ``packed_weight``."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(w.device), math)
+    w1 = proj.weight if proj is not None else None
+    key = (w.data_ptr(), w._version, str(w.device), math) + ((w1.data_ptr(), w1._version) if w1 is not None else ())
     cached = getattr(conv, "_idh_packed_split", None)
     if cached is not None and cached[0] == key:
         return cached[1]
     _lib.require_cuda_f32(w)
     L = _bind()
     co, ci, kh, kw = w.shape
-    n = L.idh_packed_split_weight_bytes(co, ci, SPLIT_CODE[math])
+    ci1 = 0
+    w1c = None
+    if w1 is not None:
+        _lib.require_cuda_f32(w1)
+        if tuple(w1.shape[2:]) != (1, 1) or w1.shape[0] != co:
+            raise _lib.IdhError("the fused second source of a split-precision conv must be a 1x1 conv with the same Cout")
+        ci1 = w1.shape[1]
+        w1c = w1.detach().reshape(co, ci1).contiguous()
+    n = L.idh_packed_split_weight_bytes(co, ci, ci1, SPLIT_CODE[math])
     if kh != 3 or kw != 3 or n == 0:
         raise _lib.IdhError("split-precision conv covers 3x3 kernels with Cout % 64 == 0")
     dst = torch.empty(n // 4, device=w.device, dtype=torch.int32)
     wc = w.detach().contiguous()
-    _lib.check(L.idh_pack_conv_weight_split(wc.data_ptr(), dst.data_ptr(), co, ci, SPLIT_CODE[math], _lib.stream_ptr()),
+    _lib.check(L.idh_pack_conv_weight_split(wc.data_ptr(), _lib.ptr(w1c), dst.data_ptr(), co, ci, ci1, SPLIT_CODE[math], _lib.stream_ptr()),
                "idh_pack_conv_weight_split")
     conv._idh_packed_split = (key, dst)
     return dst
@@ -158,8 +168,10 @@ SPLIT_MIN_BLOCKS = 256  # fewer 8x16x64 tiles than CUs: the fp32 kernels' finer 
 
 def split_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> bool:
     (v0, c0) = srcs[0]
-    if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64:
+    if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64:
         return False
+    if len(srcs) > 1 and (srcs[1][1].kernel_size[0] != 1 or srcs[1][1].stride[0] != 1):
+        return False  # the fused second source is a 1x1 projection (BasicBlock downsample at stride 1)
     if Wo < 16 or Ho < 8:
         return False
     return N * (-(-Ho // 8)) * (-(-Wo // 16)) * (cout // 64) >= SPLIT_MIN_BLOCKS
@@ -259,7 +271,10 @@ class Plan:
                 raise _lib.IdhError(f"conv expects {cv.in_channels} input channels, view has {v.C}")
             if v.C % 16 and (v.c0 != 0 or v.cs != ceil16(v.C)):
                 raise _lib.IdhError("a conv input whose channel count is not a multiple of 16 must be a whole zero-padded buffer")
-            w = split_packed_weight(cv, self.math) if use_split else packed_weight(cv)
+            if use_split:  # one blob: [3x3 panels][1x1 panels of the second source][scales]
+                w = split_packed_weight(conv, self.math, conv2)
+            else:
+                w = packed_weight(cv)
             self.keep.append(w)
             s = op.src[i]
             s.in_, s.w, s.cs, s.H, s.W, s.Cin = v.ptr, w.data_ptr(), v.cs, v.H, v.W, v.C
@@ -397,13 +412,6 @@ class Plan:
             out = self.buffer(x.N, Ho, Wo, planes)
         if blk.downsample is None:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=x)
-        elif (self.math != "fp32" and blk.downsample[0].kernel_size[0] == 1 and st == 1
-              and split_eligible([(h, blk.conv2)], planes, x.N, Ho, Wo, PAD_ZEROS)):
-            # the split-precision kernel takes one source: the 1x1 projection runs on its own (fp32 MFMA)
-            # and enters conv2's epilogue as the residual
-            proj = self.buffer(x.N, Ho, Wo, planes)
-            self.conv(x, blk.downsample[0], proj)
-            self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=proj)
         else:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, x2=x, conv2=blk.downsample[0])
         return out

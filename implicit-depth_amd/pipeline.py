@@ -259,7 +259,7 @@ class HotPathWorkload:
         dom = [op for op in convs if op.tile_m == 8]
         if self.conv_math != "fp32":
             dom = [op for op in convs if op.tile_m in (10, 11)]
-            self.dominant_kernel = "conv3x3_split_k<8, 1, 0>" if self.conv_math == "bf16x6" else "conv3x3_split_k<4, 2, 1>"
+            self.dominant_kernel = "conv3x3_split_k<8, 1, 0, *>" if self.conv_math == "bf16x6" else "conv3x3_split_k<4, 2, 1, *>"
         if not dom:  # small batches: every layer runs on the 4-row tile variant
             dom = [op for op in convs if op.tile_m == 9]
             self.dominant_kernel = "conv3x3_lds_k<1> + conv3x3_lds_group_k<1>"

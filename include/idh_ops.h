@@ -81,11 +81,15 @@ int idh_pack_conv_weight(const float *w_oihw, float *dst, int Cout, int Cin, int
  *                     weights and per halo chunk for the activations), 3 products.
  * Packed weights: [Cin_pad/16][tap row 3][Cout/64][tap in row 3][piece][ci half 2][co 64][8] 16-bit,
  * followed by Cout per-channel scale floats and Cout exponents.  3x3 kernels, Cout % 64 == 0
- * (IDH_EUNSUPPORTED otherwise). */
+ * (IDH_EUNSUPPORTED otherwise).
+ * A fused 1x1 second source (src[1]: BasicBlock's downsample(x)) is packed into the same blob
+ * (w_1x1 = (Cout, Cin_1x1) row-major or NULL / 0): [3x3 panels][1x1 panels: Cin_1x1_pad/16 x Cout/64 x
+ * piece x half x 64 x 8][scales]; src[1].w is then ignored by the kernel. */
 #define IDH_SPLIT_BF16X6 10
 #define IDH_SPLIT_F16X3 11
-size_t idh_packed_split_weight_bytes(int Cout, int Cin, int mode);
-int idh_pack_conv_weight_split(const float *w_oihw, void *dst, int Cout, int Cin, int mode, void *stream);
+size_t idh_packed_split_weight_bytes(int Cout, int Cin, int Cin_1x1, int mode);
+int idh_pack_conv_weight_split(const float *w_oihw, const float *w_1x1, void *dst, int Cout, int Cin, int Cin_1x1, int mode,
+                               void *stream);
 
 /* sizeof(idh_op) as compiled into the library (bindings assert their mirror matches). */
 size_t idh_sizeof_op(void);
