@@ -354,9 +354,14 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 // register index is a compile-time constant.  C/D layout of 16x16x32 equals 16x16x4's, so the
 // layer-1 accumulators are again exactly the layer-2 B operand (after scale + split).
 // LDS: ceil((K+4)/2) x 16 KiB + 64 KiB = 160 KiB for K = 7, 8.
+// KT = compile-time source-view count (7: every BDModel config, 8), 0 = run-time count: with KT > 0 the
+// 8 unrolled view iterations lose their `k < K` guards and become ONE basic block the scheduler can
+// software-pipeline across views.
+template <int KT>
 __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float *__restrict__ sw1g, const float *__restrict__ sw2g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int nb32 = (a.K + 5) / 2;                               // 32-wide K blocks of layer 1
+    const int K = KT > 0 ? KT : a.K;
+    const int nb32 = (K + 5) / 2;                                 // 32-wide K blocks of layer 1
     u32x4 *sW1 = reinterpret_cast<u32x4 *>(smem_raw);             // nb32 * 8 * 2 * 64
     u32x4 *sW2 = sW1 + nb32 * kNS * 2 * 64;                       // 4 * 8 * 2 * 64
     {
@@ -374,7 +379,6 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ln = lane & 15, q = lane >> 4;
     const int N = a.H * a.W;
-    const int K = a.K;
     const float Wf = (float)a.W, Hf = (float)a.H;
     const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
 
@@ -458,17 +462,21 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
                 const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
                 const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
                 const float *sb = a.src + (size_t)(b * K + k) * N * kC + 4 * q;
+#ifdef IDH_ABL_NOGATHER
+                t.t00 = t.t01 = t.t10 = t.t11 = (f32x4){(float)xa0, (float)ya0, (float)xa1, (float)ya1 + sb[0]};
+#else
                 t.t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kC);
                 t.t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kC);
                 t.t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kC);
                 t.t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kC);
+#endif
                 t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
                 return t;
             };
             Tap cur = issue(0);
 #pragma unroll
             for (int k = 0; k < kMaxK; ++k) {
-                if (k < K) {  // wave-uniform
+                if (KT > 0 ? k < KT : k < K) {  // compile-time when KT > 0, else wave-uniform
                     const Tap nxt = issue(min(k + 1, K - 1));
                     any_inb |= (cur.u > 2.f) & (cur.u < Wf - 2.f) & (cur.v > 2.f) & (cur.v < Hf - 2.f);
                     const float z = cur.z;
@@ -725,7 +733,11 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k<7>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return IDH_ELAUNCH;
         attr_set = true;
@@ -735,7 +747,9 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
         const size_t lds = ((size_t)nb32 * kNS * 2 * 64 + 4 * kNS * 2 * 64) * 16;
         const float *sw1 = reinterpret_cast<const float *>(static_cast<const char *>(w1_voxel_packed) + (size_t)nb32 * kNS * 2 * 64 * 16);
         const float *sw2 = reinterpret_cast<const float *>(static_cast<const char *>(w2_packed) + (size_t)4 * kNS * 2 * 64 * 16);
-        hipLaunchKernelGGL(fv_mlp_f16_k, dim3(grid), dim3(512), lds, st, a, sw1, sw2);
+        if (K == 7) hipLaunchKernelGGL(fv_mlp_f16_k<7>, dim3(grid), dim3(512), lds, st, a, sw1, sw2);
+        else if (K == 8) hipLaunchKernelGGL(fv_mlp_f16_k<8>, dim3(grid), dim3(512), lds, st, a, sw1, sw2);
+        else hipLaunchKernelGGL(fv_mlp_f16_k<0>, dim3(grid), dim3(512), lds, st, a, sw1, sw2);
     } else {
         const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4);
         hipLaunchKernelGGL(fv_mlp_k, dim3(grid), dim3(512), lds, st, a);

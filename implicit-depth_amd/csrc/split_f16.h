@@ -52,6 +52,9 @@ __device__ __forceinline__ int column_exponent(const f32x4 (&x)[NV]) {
     return exponent_of(__float_as_uint(m));
 }
 __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &A, const u32x4 &B, const f32x4 &C) {
+#ifdef IDH_ABL_NOMFMA
+    return C + __builtin_bit_cast(f32x4, A) * __builtin_bit_cast(f32x4, B)[0];
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0);
 }
 
