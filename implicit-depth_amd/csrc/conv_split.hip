@@ -161,7 +161,13 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
             const int iy = y0 + hy - 1, ix = x0 + hx - 1;
             const bool ok = (pix < kHaloPix) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
             const float *src = ok ? base + ((size_t)(n * s.H + iy) * s.W + ix) * cs + ch + 4 * q : g_zero16;
+#ifdef IDH_ABL_NOLOAD  // pseudo-random operands made in registers (keeps the MFMA toggle rate realistic)
+            const unsigned hsh = (unsigned)tid * 2654435761u + (unsigned)k * 40503u + (unsigned)cc * 9176u + (unsigned)(size_t)src;
+            ph_[k] = (f32x4){__uint_as_float(0x3f800000u | (hsh & 0x7fffffu)) - 1.5f, __uint_as_float(0x3f800000u | ((hsh >> 3) & 0x7fffffu)) - 1.5f,
+                             __uint_as_float(0x3f800000u | ((hsh >> 6) & 0x7fffffu)) - 1.5f, __uint_as_float(0x3f800000u | ((hsh >> 9) & 0x7fffffu)) - 1.5f};
+#else
             ph_[k] = *reinterpret_cast<const f32x4 *>(src);
+#endif
         }
     };
     // max |x| of this thread's prefetched halo values -> per-wave slot of parity `par`
@@ -181,6 +187,9 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
         if (lane == 0) sMax[par * 8 + wave] = m;
     };
     auto commit_halo = [&](float mul) {
+#ifdef IDH_ABL_NOCOMMIT
+        return;
+#endif
         u32x2 *sH2 = reinterpret_cast<u32x2 *>(sH);
 #pragma unroll
         for (int k = 0; k < kHaloLoads; ++k) {
@@ -224,10 +233,37 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
 #pragma unroll
         for (int k = 0; k < kWLoads; ++k) {
             const int slot = tid + NT_ * k;
+#ifdef IDH_ABL_NOLOAD
+            const unsigned hsh = (unsigned)tid * 2246822519u + (unsigned)k * 3266489917u + (unsigned)ph * 668265263u + (unsigned)last;
+            pw_[k] = (u32x4){0x3c003c00u ^ (hsh & 0x03ff03ffu), 0x3c003c00u ^ ((hsh >> 2) & 0x03ff03ffu), 0x3c003c00u ^ ((hsh >> 4) & 0x03ff03ffu),
+                             0x3c003c00u ^ ((hsh >> 6) & 0x03ff03ffu)};
+#else
             pw_[k] = src[slot < last ? slot : last];
+#endif
         }
     };
+#ifdef IDH_SPLIT_GLDS
+    // weight panel of phase `ph` straight into LDS buffer `buf` (global_load_lds_dwordx4: no VGPRs, no ds_write);
+    // 1 KiB pieces, piece i goes to wave i % WAVES
+    auto dma_w = [&](int ph, int buf) {
+        const u32x4 *w0 = reinterpret_cast<const u32x4 *>(s.w);
+        const bool second = SRC2 && ph >= nPh;
+        const u32x4 *src = second ? w0 + (size_t)nPh * a.NT * kWSlots + ((size_t)(ph - nPh) * a.NT + nt) * kW1Slots
+                                  : w0 + ((size_t)ph * a.NT + nt) * kWSlots;
+        const int pieces = (second ? kW1Slots : kWSlots) / 64;
+#pragma unroll
+        for (int i = 0; i < (kWSlots / 64 + WAVES - 1) / WAVES; ++i) {
+            const int pc = wave + WAVES * i;
+            if (pc < pieces)
+                __builtin_amdgcn_global_load_lds(src + pc * 64 + lane,
+                                                 (__attribute__((address_space(3))) void *)(sW + buf * kWSlots + pc * 64), 16, 0, 0);
+        }
+    };
+#endif
     auto commit_w = [&](int buf) {
+#if defined(IDH_ABL_NOCOMMIT) || defined(IDH_SPLIT_GLDS)
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < kWLoads; ++k)
             if (k < kWLoads - 1 || wave < kWFullWaves) sW[buf * kWSlots + tid + NT_ * k] = pw_[k];
@@ -271,8 +307,12 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
     auto begin_chunk = [&](int c) {
         float mul = 1.f;
         if constexpr (MODE == MODE_F16X3) {
+#ifndef IDH_ABL_NOCOMMIT
             publish_max(c & 1);
+#endif
+#ifndef IDH_ABL_NOBARRIER
             __syncthreads();  // every wave is done reading the previous chunk's halo; chunk maxima visible
+#endif
             float bm = sMax[(c & 1) * 8];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) bm = fmaxf(bm, sMax[(c & 1) * 8 + w]);
@@ -296,7 +336,13 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
     };
 
     issue_halo(0);
+#ifdef IDH_SPLIT_GLDS
+    dma_w(0, 0);
+#define IDH_NEXT_W(phn) dma_w((phn), (phn) & 1)
+#else
     issue_w(0);
+#define IDH_NEXT_W(phn) issue_w(phn)
+#endif
     int ph = 0;
 #pragma unroll 1
     for (int c = 0; c < nC; ++c) {
@@ -304,8 +350,10 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
 #pragma unroll
         for (int r = 0; r < 3; ++r, ++ph) {
             commit_w(ph & 1);
+#ifndef IDH_ABL_NOBARRIER
             __syncthreads();
-            issue_w(ph + 1 < nPhases ? ph + 1 : ph);  // unconditional (re-reads the last panel at the end)
+#endif
+            if (ph + 1 < nPhases || true) IDH_NEXT_W(ph + 1 < nPhases ? ph + 1 : ph);  // unconditional (re-reads the last panel at the end)
             if (r == 0) issue_halo(c + 1 < nChunks ? c + 1 : c);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads ahead of the MFMAs that hide them
             compute(r, ph & 1, std::integral_constant<int, 3>{}, 0);
@@ -317,7 +365,7 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
             begin_chunk(c);
             commit_w(ph & 1);
             __syncthreads();
-            issue_w(ph + 1 < nPhases ? ph + 1 : ph);
+            IDH_NEXT_W(ph + 1 < nPhases ? ph + 1 : ph);
             issue_halo(c + 1 < nChunks ? c + 1 : c);
             __builtin_amdgcn_sched_barrier(0);
             compute(1, ph & 1, std::integral_constant<int, 1>{}, 1);

@@ -461,14 +461,16 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
                 const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
                 const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
                 const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
-                const float *sb = a.src + (size_t)(b * K + k) * N * kC + 4 * q;
+                const float *sb = a.src + (size_t)(b * K + k) * N * kC;  // wave-uniform
 #ifdef IDH_ABL_NOGATHER
                 t.t00 = t.t01 = t.t10 = t.t11 = (f32x4){(float)xa0, (float)ya0, (float)xa1, (float)ya1 + sb[0]};
 #else
-                t.t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kC);
-                t.t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kC);
-                t.t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kC);
-                t.t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kC);
+                // 32-bit offsets from a wave-uniform base: the loads take the SGPR-base + VGPR-offset form
+                const int r0 = ya0 * a.W, r1 = ya1 * a.W;
+                t.t00 = *reinterpret_cast<const f32x4 *>(sb + (r0 + xa0) * kC + 4 * q);
+                t.t01 = *reinterpret_cast<const f32x4 *>(sb + (r0 + xa1) * kC + 4 * q);
+                t.t10 = *reinterpret_cast<const f32x4 *>(sb + (r1 + xa0) * kC + 4 * q);
+                t.t11 = *reinterpret_cast<const f32x4 *>(sb + (r1 + xa1) * kC + 4 * q);
 #endif
                 t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
                 return t;

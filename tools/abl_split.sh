@@ -1,7 +1,7 @@
 #!/bin/bash
 # ablation builds of the split-bf16 conv kernel: tools/abl_split.sh build   (here)  /  run (on the GPU box)
 cd "$(dirname "$0")/.."
-VARS="${VARS:-NOSTORE NOLOAD NOCOMMIT NOBARRIER NOMFMA}"
+VARS="${VARS:-NORES,NOSTORE NOLOAD NOLOAD,NORES,NOSTORE}"
 if [ "$1" = build ]; then
   for v in $VARS; do
     flags=""; for f in ${v//,/ }; do flags="$flags -DIDH_ABL_$f"; done
