@@ -72,6 +72,9 @@ struct BinArgs {
     int search_iters;
     float search_lo, search_hi, thr_logit;
     float *search_out;    // B,1,HW final search depths
+    const float *thr_bins;    // per-depth Thresholder (binary_metrics_utils.py:42-52): n_thr ascending bin edges ...
+    const float *thr_logits;  // ... and logit(threshold) per bin; null -> the constant thr_logit
+    int n_thr;
     const float *sw2;     // F16 kernel: per-row scale of the f16-packed W2 (w2 then points to idh_pack_mlp_weight_f16 output)
 };
 
@@ -241,7 +244,13 @@ __global__ __launch_bounds__(kBinThreads) void binary_mlp_k(const BinArgs a) {
                     if (q == 0 && mok[t]) a.out[poff[t] + (size_t)p * a.HW] = logit;
                 } else {
                     // sigmoid(logit) < threshold  <=>  logit < logit(threshold): "visible" -> move the far bound
-                    if (logit < a.thr_logit) hi[t] = sd[t]; else lo[t] = sd[t];
+                    float thr = a.thr_logit;
+                    if (a.n_thr > 0) {  // torch.bucketize(depth, bins): number of edges strictly below the query depth
+                        int idx = 0;
+                        for (int e = 0; e < a.n_thr; ++e) idx += a.thr_bins[e] < sd[t] ? 1 : 0;
+                        thr = a.thr_logits[idx < a.n_thr ? idx : a.n_thr - 1];
+                    }
+                    if (logit < thr) hi[t] = sd[t]; else lo[t] = sd[t];
                     if (p == n_eval - 1 && q == 0 && mok[t]) a.out[poff[t]] = logit;  // pred_0 of the last evaluation
                     sd[t] = (hi[t] + lo[t]) * 0.5f;
                 }
@@ -419,7 +428,7 @@ extern "C" int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, c
     const long long M = (long long)B * HW;
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
     BinArgs a{feat_nhwc, depth_bphw, prior_bphw, w1f_packed, w2_packed, vecs6x128, out_bphw,
-              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr};
+              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0, nullptr};
     return binary_mlp_launch(a, B, stream);
 }
 
@@ -433,7 +442,7 @@ extern "C" int idh_binary_mlp_f16x3_fwd(const float *feat_nhwc, int feat_cs, int
     const long long M = (long long)B * HW;
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
     BinArgs a{feat_nhwc, depth_bphw, prior_bphw, w1f_packed, static_cast<const float *>(w2_f16), vecs6x128, out_bphw,
-              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr};
+              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0, nullptr};
     return binary_mlp_launch(a, B, stream, true);
 }
 
@@ -455,7 +464,28 @@ extern "C" int idh_binary_mlp_search_fwd(const float *feat_nhwc, int feat_cs, in
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
     BinArgs a{feat_nhwc, nullptr, prior_b1hw, w1f_packed, w2_packed, vecs6x128, last_logits_b1hw,
               (int)M, HW, 1, feat_cs, Cf, has_prior, prior_const, iters, lo, hi, logf(threshold / (1.f - threshold)),
-              search_depths_b1hw, nullptr};
+              search_depths_b1hw, nullptr, nullptr, 0, nullptr};
+    return binary_mlp_launch(a, B, stream);
+}
+
+// Same search with the reference's per-depth Thresholder (utils/binary_metrics_utils.py:42-52, used by
+// bd_model.py:282-283): threshold = thresholds[bucketize(query depth, bins)].  `thr_logits` holds
+// logit(threshold) per bin (host-side transform, so the kernel compares logits like above).
+extern "C" int idh_binary_mlp_search_thr_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *prior_b1hw,
+                                             int has_prior, float prior_const, const float *w1f_packed,
+                                             const float *w2_packed, const float *vecs6x128, int B, int HW, int iters,
+                                             float lo, float hi, const float *bins, const float *thr_logits, int n_bins,
+                                             float *search_depths_b1hw, float *last_logits_b1hw, void *stream) {
+    if (B < 0 || HW <= 0 || iters <= 0 || Cf <= 0 || (Cf & 3) || (feat_cs & 3) || feat_cs < Cf || n_bins <= 0 || !(hi > lo))
+        return IDH_EINVAL;
+    if (B == 0) return IDH_OK;
+    if (!feat_nhwc || !w1f_packed || !w2_packed || !vecs6x128 || !search_depths_b1hw || !last_logits_b1hw || !bins || !thr_logits)
+        return IDH_EINVAL;
+    const long long M = (long long)B * HW;
+    if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    BinArgs a{feat_nhwc, nullptr, prior_b1hw, w1f_packed, w2_packed, vecs6x128, last_logits_b1hw,
+              (int)M, HW, 1, feat_cs, Cf, has_prior, prior_const, iters, lo, hi, 0.f,
+              search_depths_b1hw, bins, thr_logits, n_bins, nullptr};
     return binary_mlp_launch(a, B, stream);
 }
 

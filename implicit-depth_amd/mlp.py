@@ -93,15 +93,31 @@ def occlusion_logits(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, de
 
 
 def infer_depth(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, prior_b1hw: Optional[torch.Tensor] = None,
-                iters: int = 12, lo: float = 0.5, hi: float = 8.0, threshold: float = 0.5):
+                iters: int = 12, lo: float = 0.5, hi: float = 8.0, threshold: float = 0.5, thresholder=None):
     """Fused form of the reference's ``infer_depth`` loop (bd_model.py:273-292): returns
-    (search_depths (B,1,H,W), logits of the last evaluation (B,1,H,W))."""
+    (search_depths (B,1,H,W), logits of the last evaluation (B,1,H,W)).  ``thresholder``: an object
+    with ``bins`` / ``thresholds`` tensors (metrics.Thresholder, reference binary_metrics_utils.py:42-52)
+    -> per-depth thresholds as in bd_model.py:282-283; None -> the constant ``threshold``."""
     _lib.require_cuda_f32(feat_nhwc, prior_b1hw)
     B, H, W, CS = feat_nhwc.shape
     w1p, w2p, vecs = _prepared(net.mlps["s0"], n_feat, net.use_prior)
     prior = prior_b1hw.contiguous() if prior_b1hw is not None else None
     sd = torch.empty(B, 1, H, W, device=feat_nhwc.device)
     logits = torch.empty(B, 1, H, W, device=feat_nhwc.device)
+    if thresholder is not None:
+        dev = feat_nhwc.device
+        bins = thresholder.bins.to(device=dev, dtype=torch.float32).contiguous()
+        thr = thresholder.thresholds.to(device=dev, dtype=torch.float32)
+        if bins.dim() != 1 or thr.shape != bins.shape or not bool(((thr > 0) & (thr < 1)).all()):
+            raise _lib.IdhError("thresholder needs 1-D bins / thresholds of equal length with thresholds in (0, 1)")
+        thr_logits = torch.log(thr / (1 - thr)).contiguous()
+        _lib.check(
+            _lib.lib().idh_binary_mlp_search_thr_fwd(feat_nhwc.data_ptr() + 4 * feat_c0, CS, n_feat, _lib.ptr(prior), int(net.use_prior), -1.0,
+                                                     w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(), B, H * W, iters, lo, hi,
+                                                     bins.data_ptr(), thr_logits.data_ptr(), bins.numel(), sd.data_ptr(), logits.data_ptr(),
+                                                     _lib.stream_ptr()),
+            "idh_binary_mlp_search_thr_fwd")
+        return sd, logits
     _lib.check(
         _lib.lib().idh_binary_mlp_search_fwd(feat_nhwc.data_ptr() + 4 * feat_c0, CS, n_feat, _lib.ptr(prior), int(net.use_prior), -1.0,
                                              w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(), B, H * W, iters, lo, hi, threshold,

@@ -41,6 +41,7 @@ class HotPath(nn.Module):
         self.depth_decoder = depth_decoder
         self.binary_mlp = binary_mlp
         self.min_depth, self.max_depth = float(min_depth), float(max_depth)
+        self.thresholder = None  # like BDModel.thresholder (bd_model.py:141): per-depth thresholds of the infer_depth search
         self._plans: Dict = {}
 
     # ------------------------------------------------------------------------------------
@@ -141,7 +142,8 @@ class HotPath(nn.Module):
             if infer_depth:  # bd_model.py:273-292: 12-step per-pixel binary search, one launch
                 from .mlp import infer_depth as _search
 
-                out["search_depths"], out["pred_0"] = _search(self.binary_mlp, f0.buf, f0.c0, f0.C, prior[:, :1] if prior is not None else None)
+                out["search_depths"], out["pred_0"] = _search(self.binary_mlp, f0.buf, f0.c0, f0.C, prior[:, :1] if prior is not None else None,
+                                                              thresholder=self.thresholder)
             else:
                 out["pred_0"] = occlusion_logits(self.binary_mlp, f0.buf, f0.c0, f0.C, rendered_depth, prior)
         if return_features:

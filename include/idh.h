@@ -146,12 +146,19 @@ int idh_binary_mlp_f16x3_fwd(const float *feat_nhwc, int feat_cs, int Cf, const 
  * dependent evaluations of the same MLP at each pixel's current query depth, bounds [lo,hi], first
  * query (hi-lo)/2, a pixel is "visible" when sigmoid(logit) < threshold.  Outputs the final query
  * depths and the logits of the last evaluation (the reference's outputs["search_depths"] / ["pred_0"]).
- * The per-depth Thresholder (binary_metrics_utils.py:42-52) is not covered: constant threshold only. */
+ * Constant threshold; idh_binary_mlp_search_thr_fwd takes the per-depth Thresholder. */
 int idh_binary_mlp_search_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *prior_b1hw,
                               int has_prior, float prior_const, const float *w1f_packed,
                               const float *w2_packed, const float *vecs6x128, int B, int HW, int iters,
                               float lo, float hi, float threshold, float *search_depths_b1hw,
                               float *last_logits_b1hw, void *stream);
+/* The same search with the per-depth Thresholder (binary_metrics_utils.py:42-52; bd_model.py:282-283):
+ * threshold = thresholds[bucketize(query depth, bins)]; pass thr_logits[i] = logit(thresholds[i]). */
+int idh_binary_mlp_search_thr_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *prior_b1hw,
+                                  int has_prior, float prior_const, const float *w1f_packed,
+                                  const float *w2_packed, const float *vecs6x128, int B, int HW, int iters,
+                                  float lo, float hi, const float *bins, const float *thr_logits, int n_bins,
+                                  float *search_depths_b1hw, float *last_logits_b1hw, void *stream);
 
 /* ---- temporal prior ------------------------------------------------------------------ */
 /* Replaces BDModel.sample_prior (reference experiment_modules/bd_model.py:395-410): back-project

@@ -135,3 +135,42 @@ def test_fused_binary_depth_search_matches_reference_loop():
     assert bool((agree | knife_edge).all())
     assert rel_err(got_logit.cpu()[agree], logit[agree]) < TOL
     assert got_sd.min().item() >= 0.5 and got_sd.max().item() <= 8.0
+
+
+def test_fused_search_with_per_depth_thresholder():
+    """bd_model.py:282-283 with a Thresholder (binary_metrics_utils.py:42-52): the threshold of each step
+    is looked up from the step's query depth."""
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd.metrics import Thresholder
+    from implicit_depth_amd.mlp import infer_depth
+
+    B, H, W = 2, 12, 20
+    feat = syn.randn((B, 64, H, W), 61, "f")
+    m = net.BinaryMLPNetwork([64, 64, 128, 256], use_prior=False)
+    syn.fill_state_dict(m, seed=62, gain=1.2)
+    with torch.no_grad():
+        m.mlps["s0"][0].weight[:, 0] *= 3.0
+    planes = torch.tensor([1.5 + 0.5 * i for i in range(8)])
+    th = Thresholder(planes, torch.tensor([0.3, 0.35, 0.45, 0.5, 0.55, 0.6, 0.65, 0.7]))
+    w = {k: v.double() for k, v in m.state_dict().items()}
+    f64 = feat.double()
+    lo = torch.full((B, 1, H, W), 0.5, dtype=torch.float64)
+    hi = torch.full((B, 1, H, W), 8.0, dtype=torch.float64)
+    sd = torch.full((B, 1, H, W), 7.5 / 2.0, dtype=torch.float64)
+    margins = []
+    for _ in range(12):
+        logit = onet.occlusion_logits(f64, sd, w)
+        thr = th.thresholds.double()[torch.bucketize(sd, th.bins.double())]   # the reference's get_thresholds
+        margins.append((torch.sigmoid(logit) - thr).abs())
+        vis = torch.sigmoid(logit) < thr
+        hi = torch.where(vis, sd, hi)
+        lo = torch.where(~vis, sd, lo)
+        sd = (hi + lo) / 2
+    got_sd, got_logit = infer_depth(m.cuda(), feat.permute(0, 2, 3, 1).contiguous().cuda(), 0, 64, thresholder=th)
+    agree = (got_sd.cpu().double() - sd).abs() < 1e-6
+    assert agree.float().mean().item() > 0.99
+    knife_edge = torch.stack(margins).min(0).values < 1e-4
+    assert bool((agree | knife_edge).all())
+    # and it differs from the constant-0.5 search (the table is doing something)
+    const_sd, _ = infer_depth(m, feat.permute(0, 2, 3, 1).contiguous().cuda(), 0, 64)
+    assert (const_sd.cpu().double() - sd).abs().max().item() > 1e-3
