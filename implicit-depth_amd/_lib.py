@@ -55,6 +55,8 @@ _SIGS = {
                                             C.c_float, C.c_float, C.c_float, f32p, f32p, C.c_void_p]),
     "idh_binary_mlp_search_thr_fwd": (C.c_int, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int,
                                                 C.c_float, C.c_float, f32p, f32p, C.c_int, f32p, f32p, C.c_void_p]),
+    "idh_binary_mlp_search_f16x3_fwd": (C.c_int, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_float, f32p, C.c_void_p, f32p, C.c_int, C.c_int, C.c_int,
+                                                  C.c_float, C.c_float, C.c_float, f32p, f32p, C.c_int, f32p, f32p, C.c_void_p]),
     "idh_metrics_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "idh_plane_iou_fwd": (C.c_int, [f32p, f32p, f32p, f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "idh_depth_metrics_fwd": (C.c_int, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -489,6 +489,27 @@ extern "C" int idh_binary_mlp_search_thr_fwd(const float *feat_nhwc, int feat_cs
     return binary_mlp_launch(a, B, stream);
 }
 
+// f16x3 variants of the two search entry points (w2_f16 from idh_pack_mlp_weight_f16): the same kernel
+// template with the per-plane layer in split precision
+extern "C" int idh_binary_mlp_search_f16x3_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *prior_b1hw,
+                                               int has_prior, float prior_const, const float *w1f_packed,
+                                               const void *w2_f16, const float *vecs6x128, int B, int HW, int iters,
+                                               float lo, float hi, float threshold, const float *bins,
+                                               const float *thr_logits, int n_bins, float *search_depths_b1hw,
+                                               float *last_logits_b1hw, void *stream) {
+    if (B < 0 || HW <= 0 || iters <= 0 || Cf <= 0 || (Cf & 3) || (feat_cs & 3) || feat_cs < Cf || !(hi > lo) || n_bins < 0) return IDH_EINVAL;
+    if (n_bins == 0 && (!(threshold > 0.f) || !(threshold < 1.f))) return IDH_EINVAL;
+    if (n_bins > 0 && (!bins || !thr_logits)) return IDH_EINVAL;
+    if (B == 0) return IDH_OK;
+    if (!feat_nhwc || !w1f_packed || !w2_f16 || !vecs6x128 || !search_depths_b1hw || !last_logits_b1hw) return IDH_EINVAL;
+    const long long M = (long long)B * HW;
+    if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    BinArgs a{feat_nhwc, nullptr, prior_b1hw, w1f_packed, static_cast<const float *>(w2_f16), vecs6x128, last_logits_b1hw,
+              (int)M, HW, 1, feat_cs, Cf, has_prior, prior_const, iters, lo, hi,
+              n_bins == 0 ? logf(threshold / (1.f - threshold)) : 0.f, search_depths_b1hw, bins, thr_logits, n_bins, nullptr};
+    return binary_mlp_launch(a, B, stream, true);
+}
+
 static int binary_mlp_launch(BinArgs a, int B, void *stream, bool f16) {
     const long long M = a.M;
     constexpr int TM = 1;

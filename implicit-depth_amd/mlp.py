@@ -100,10 +100,12 @@ def infer_depth(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, prior_b
     -> per-depth thresholds as in bd_model.py:282-283; None -> the constant ``threshold``."""
     _lib.require_cuda_f32(feat_nhwc, prior_b1hw)
     B, H, W, CS = feat_nhwc.shape
-    w1p, w2p, vecs = _prepared(net.mlps["s0"], n_feat, net.use_prior)
+    math = mlp_math_of(net)
+    w1p, w2p, vecs = _prepared(net.mlps["s0"], n_feat, net.use_prior, math)
     prior = prior_b1hw.contiguous() if prior_b1hw is not None else None
     sd = torch.empty(B, 1, H, W, device=feat_nhwc.device)
     logits = torch.empty(B, 1, H, W, device=feat_nhwc.device)
+    bins = thr_logits = None
     if thresholder is not None:
         dev = feat_nhwc.device
         bins = thresholder.bins.to(device=dev, dtype=torch.float32).contiguous()
@@ -111,6 +113,15 @@ def infer_depth(net, feat_nhwc: torch.Tensor, feat_c0: int, n_feat: int, prior_b
         if bins.dim() != 1 or thr.shape != bins.shape or not bool(((thr > 0) & (thr < 1)).all()):
             raise _lib.IdhError("thresholder needs 1-D bins / thresholds of equal length with thresholds in (0, 1)")
         thr_logits = torch.log(thr / (1 - thr)).contiguous()
+    if math == "f16x3":
+        _lib.check(
+            _lib.lib().idh_binary_mlp_search_f16x3_fwd(feat_nhwc.data_ptr() + 4 * feat_c0, CS, n_feat, _lib.ptr(prior), int(net.use_prior), -1.0,
+                                                       w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(), B, H * W, iters, lo, hi, threshold,
+                                                       _lib.ptr(bins), _lib.ptr(thr_logits), 0 if bins is None else bins.numel(),
+                                                       sd.data_ptr(), logits.data_ptr(), _lib.stream_ptr()),
+            "idh_binary_mlp_search_f16x3_fwd")
+        return sd, logits
+    if thresholder is not None:
         _lib.check(
             _lib.lib().idh_binary_mlp_search_thr_fwd(feat_nhwc.data_ptr() + 4 * feat_c0, CS, n_feat, _lib.ptr(prior), int(net.use_prior), -1.0,
                                                      w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(), B, H * W, iters, lo, hi,

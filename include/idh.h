@@ -159,6 +159,14 @@ int idh_binary_mlp_search_thr_fwd(const float *feat_nhwc, int feat_cs, int Cf, c
                                   const float *w2_packed, const float *vecs6x128, int B, int HW, int iters,
                                   float lo, float hi, const float *bins, const float *thr_logits, int n_bins,
                                   float *search_depths_b1hw, float *last_logits_b1hw, void *stream);
+/* f16x3 variant of both searches (w2_f16 from idh_pack_mlp_weight_f16): n_bins == 0 -> constant
+ * `threshold`, else the per-depth table. */
+int idh_binary_mlp_search_f16x3_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float *prior_b1hw,
+                                    int has_prior, float prior_const, const float *w1f_packed,
+                                    const void *w2_f16, const float *vecs6x128, int B, int HW, int iters,
+                                    float lo, float hi, float threshold, const float *bins,
+                                    const float *thr_logits, int n_bins, float *search_depths_b1hw,
+                                    float *last_logits_b1hw, void *stream);
 
 /* ---- temporal prior ------------------------------------------------------------------ */
 /* Replaces BDModel.sample_prior (reference experiment_modules/bd_model.py:395-410): back-project

@@ -72,3 +72,8 @@ def test_binary_mlp_module_interface_f16x3(use_prior, f16_mlp):
 def test_binary_mlp_odd_sizes_and_scales_f16x3(f16_mlp):
     mlp_base.test_prior_absent_is_minus_one_and_odd_sizes()
     mlp_base.test_all_scales_interface()
+
+
+def test_binary_depth_search_f16x3(f16_mlp):
+    mlp_base.test_fused_binary_depth_search_matches_reference_loop()
+    mlp_base.test_fused_search_with_per_depth_thresholder()
