@@ -48,3 +48,46 @@ def test_split_hot_path_matches_fp32_hot_path_at_bench_shape(math):
         outs[m] = wl.out["pred_0"].clone()
     a, b = outs["fp32"], outs[math]
     assert float((a - b).abs().max() / a.abs().max()) < 2e-5
+
+
+# ---- every conv-stage golden / oracle case of tests/test_conv_gpu.py and the pipeline cases of
+# ---- tests/test_pipeline_gpu.py, re-run with the split-precision kernels selected wherever eligible
+import test_conv_gpu as conv_base
+import test_pipeline_gpu as pipe_base
+
+
+@pytest.fixture(params=["bf16x6", "f16x3"])
+def split_everything(request):
+    from implicit_depth_amd import cost_volume as cvmod
+
+    old = nhwc.DEFAULT_MATH, nhwc.SPLIT_MIN_BLOCKS, cvmod.DEFAULT_MLP_MATH
+    nhwc.DEFAULT_MATH, nhwc.SPLIT_MIN_BLOCKS = request.param, 1
+    cvmod.DEFAULT_MLP_MATH = "f16x3" if request.param == "f16x3" else "fp32"
+    yield request.param
+    nhwc.DEFAULT_MATH, nhwc.SPLIT_MIN_BLOCKS, cvmod.DEFAULT_MLP_MATH = old
+
+
+@pytest.mark.parametrize("tag", ["id", "proj", "down"])
+def test_basic_block_golden_split(tag, split_everything):
+    conv_base.test_basic_block_golden(tag)
+
+
+def test_encoder_decoder_goldens_split(split_everything):
+    conv_base.test_cvencoder_golden()
+    conv_base.test_decoders_golden("bd")
+    conv_base.test_decoders_golden("depth")
+    conv_base.test_cvencoder_decoder_batched_vs_oracle()
+
+
+@pytest.mark.parametrize("reg", [False, True])
+def test_skip_decoder_and_matching_head_goldens_split(reg, split_everything):
+    conv_base.test_skip_decoder_golden(reg)
+    conv_base.test_matching_head_golden_and_layouts()
+
+
+def test_pipeline_cases_split(split_everything):
+    pipe_base.test_bd_hot_path_matches_oracle((1, 2, 24, 32, 16, 3))
+    pipe_base.test_bd_hot_path_matches_oracle((2, 7, 16, 24, 64, 2))
+    pipe_base.test_depth_model_hot_path_matches_oracle()
+    pipe_base.test_prior_channel_path()
+    pipe_base.test_temporal_sequence_with_prior_d96()
