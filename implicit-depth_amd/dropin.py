@@ -76,9 +76,11 @@ def convert_binary_mlp(ref: nn.Module) -> nn.Module:
     return new.to(_device(ref))
 
 
-def convert(model: nn.Module) -> nn.Module:
+def convert(model: nn.Module, math: str = None) -> nn.Module:
     """In-place: replace ``cost_volume``, ``cost_volume_net``, ``depth_decoder`` and (BDModel)
-    ``binary_mlp`` of a reference model.  Idempotent."""
+    ``binary_mlp`` of a reference model.  Idempotent.  ``math``: None keeps the defaults (fp32 MFMA
+    unless IDH_CONV_MATH / IDH_MLP_MATH say otherwise); "f16x3" / "bf16x6" select the split-precision
+    kernels for this model's convs (and, for "f16x3", its MLP feature volume and BinaryMLP)."""
     if not isinstance(model.cost_volume, cv.CostVolumeManager):
         model.cost_volume = convert_cost_volume(model.cost_volume)
     if not isinstance(model.cost_volume_net, net.CVEncoder):
@@ -87,13 +89,25 @@ def convert(model: nn.Module) -> nn.Module:
         model.depth_decoder = convert_decoder(model.depth_decoder)
     if hasattr(model, "binary_mlp") and not isinstance(model.binary_mlp, net.BinaryMLPNetwork):
         model.binary_mlp = convert_binary_mlp(model.binary_mlp)
+    if math is not None:
+        from . import nhwc
+
+        if math not in nhwc.MATH_MODES:
+            raise ValueError(f"math must be one of {nhwc.MATH_MODES}")
+        mlp_math = "f16x3" if math == "f16x3" else "fp32"
+        model.cost_volume_net.conv_math = model.depth_decoder.conv_math = math
+        if isinstance(model.cost_volume, cv.FeatureVolumeManager):
+            model.cost_volume.mlp_math = mlp_math
+        if hasattr(model, "binary_mlp"):
+            model.binary_mlp.mlp_math = mlp_math
     return model
 
 
-def hot_path_of(model: nn.Module, min_depth: float = 0.25, max_depth: float = 5.0) -> HotPath:
+def hot_path_of(model: nn.Module, min_depth: float = 0.25, max_depth: float = 5.0, math: str = None) -> HotPath:
     """Fused pipeline sharing the (converted) modules of ``model``."""
-    convert(model)
+    convert(model, math)
     o = getattr(model, "run_opts", None)
     if o is not None:
         min_depth, max_depth = o.min_matching_depth, o.max_matching_depth
-    return HotPath(model.cost_volume, model.cost_volume_net, model.depth_decoder, getattr(model, "binary_mlp", None), min_depth, max_depth)
+    return HotPath(model.cost_volume, model.cost_volume_net, model.depth_decoder, getattr(model, "binary_mlp", None), min_depth, max_depth,
+                   conv_math=getattr(model.cost_volume_net, "conv_math", None))

@@ -466,6 +466,12 @@ class Plan:
         self._array()[self._idx(idx)].out = t.data_ptr()
 
 
+def math_of(module: nn.Module) -> str:
+    """Conv arithmetic of a drop-in module: its ``conv_math`` attribute (set by ``dropin.convert(model,
+    math=...)``) or the process-wide DEFAULT_MATH."""
+    return getattr(module, "conv_math", None) or DEFAULT_MATH
+
+
 def _plan_cache(module: nn.Module) -> Dict:
     c = module.__dict__.get("_idh_plans")
     if c is None:
@@ -475,7 +481,7 @@ def _plan_cache(module: nn.Module) -> Dict:
 
 
 def _param_key(module: nn.Module):
-    return (DEFAULT_MATH,) + tuple((p.data_ptr(), p._version) for p in module.parameters())
+    return (math_of(module),) + tuple((p.data_ptr(), p._version) for p in module.parameters())
 
 
 def _check_in(*ts):
@@ -494,7 +500,7 @@ def block_forward_nchw(blk, x: torch.Tensor) -> torch.Tensor:
     ent = cache.get(key)
     if ent is None:
         cache.clear()
-        p = Plan(x.device)
+        p = Plan(x.device, math=math_of(blk))
         N, Cc, H, W = x.shape
         xin = p.buffer(N, H, W, Cc)
         i_in = p.import_nchw(x.shape, xin)
@@ -545,7 +551,7 @@ def cv_encoder_forward_nchw(enc, x: torch.Tensor, img_feats: List[torch.Tensor])
     ent = cache.get(key)
     if ent is None:
         cache.clear()
-        p = Plan(x.device)
+        p = Plan(x.device, math=math_of(enc))
         N, D, H, W = x.shape
         xin = p.buffer(N, H, W, D)
         i_x = p.import_nchw(x.shape, xin)
@@ -607,7 +613,7 @@ def decoder_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dict[str, t
     ent = cache.get(key)
     if ent is None:
         cache.clear()
-        p = Plan(feats[0].device)
+        p = Plan(feats[0].device, math=math_of(dec))
         views, i_in = [], []
         for f in feats:
             v = p.buffer(f.shape[0], f.shape[2], f.shape[3], f.shape[1])
@@ -664,7 +670,7 @@ def matching_head_forward(enc, feat_nchw: torch.Tensor, channels_last: bool = Fa
     ent = cache.get(key)
     if ent is None:
         cache.clear()
-        p = Plan(x.device)
+        p = Plan(x.device, math=math_of(enc))
         N, Cc, H, W = x.shape
         xin = p.buffer(N, H, W, Cc)
         i_in = p.import_nchw(x.shape, xin)
@@ -743,7 +749,7 @@ def skip_regression_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dic
     ent = cache.get(key)
     if ent is None:
         cache.clear()
-        p = Plan(feats[0].device)
+        p = Plan(feats[0].device, math=math_of(dec))
         views, i_in = [], []
         for f in feats:
             v = p.buffer(f.shape[0], f.shape[2], f.shape[3], f.shape[1])

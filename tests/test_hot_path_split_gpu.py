@@ -91,3 +91,32 @@ def test_pipeline_cases_split(split_everything):
     pipe_base.test_depth_model_hot_path_matches_oracle()
     pipe_base.test_prior_channel_path()
     pipe_base.test_temporal_sequence_with_prior_d96()
+
+
+def test_dropin_convert_with_math_selects_split_kernels_per_model():
+    """dropin.hot_path_of(model, math="f16x3") on the reference-shaped holder of the G5 golden."""
+    from implicit_depth_amd import cost_volume as cvmod
+    from implicit_depth_amd.dropin import hot_path_of
+
+    g = base.load_golden("g5_bdmodel_mlp")
+    K = int(g["K"])
+    h = base._holder(K, "mlp")
+    h.cuda()
+    old = nhwc.SPLIT_MIN_BLOCKS
+    nhwc.SPLIT_MIN_BLOCKS = 1
+    try:
+        hot = hot_path_of(h, math="f16x3")
+        assert hot.conv_math == "f16x3" and h.cost_volume.mlp_math == "f16x3" and h.binary_mlp.mlp_math == "f16x3"
+        assert nhwc.DEFAULT_MATH == "fp32" and cvmod.DEFAULT_MLP_MATH == "fp32"  # per-model, not process-wide
+        cur, src = base.syn.frame_tuple(1, K, 96, 128, seed=31, P=3)
+        cur = {k: v.cuda() for k, v in cur.items()}
+        src = {k: v.cuda() for k, v in src.items()}
+        t = lambda name: torch.as_tensor(g[name]).cuda()
+        out = hot(t("matching_cur"), t("matching_src"), [t(f"enc{i}") for i in range(5)],
+                  src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1), cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"],
+                  src["K_s1_b44"], cur["invK_s1_b44"], rendered_depth=cur["rendered_depth"], return_mask=True)
+        plan = next(iter(hot._plans.values()))["plan"]
+        assert any(op.kind == nhwc.OP_CONV and op.tile_m == nhwc.SPLIT_CODE["f16x3"] for op in plan.ops)
+        assert base.rel_err(out["pred_0"].cpu(), g["pred_0"]) < base.TOL
+    finally:
+        nhwc.SPLIT_MIN_BLOCKS = old
