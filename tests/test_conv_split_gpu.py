@@ -153,3 +153,30 @@ def test_split_basic_block_matches_oracle(split_math):
 
 def test_zz_both_tile_heights_were_exercised():
     assert rows_used >= {8, 16}, rows_used
+
+
+def test_split_abi_rejects_unsupported_shapes():
+    """Loud failures, no silent fallback: Cout % 64 != 0 at pack time, a strided conv flagged as split."""
+    import ctypes as C
+
+    from implicit_depth_amd import _lib
+
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    assert L.idh_packed_split_weight_bytes(48, 32, 0, 11) == 0
+    w = torch.randn(48, 32, 3, 3, device=dev)
+    dst = torch.empty(1 << 16, device=dev, dtype=torch.int32)
+    rc = L.idh_pack_conv_weight_split(w.data_ptr(), None, dst.data_ptr(), 48, 32, 0, 11, _lib.stream_ptr())
+    assert rc == -2 and b"not covered" in L.idh_error_string(rc)  # IDH_EUNSUPPORTED
+    assert L.idh_pack_conv_weight_split(w.data_ptr(), None, dst.data_ptr(), 64, 32, 0, 7, _lib.stream_ptr()) != 0  # unknown mode
+    # a stride-2 conv may not be tagged for the split kernel
+    conv = torch.nn.Conv2d(32, 64, 3, stride=2, padding=1).to(dev)
+    p = nhwc.Plan(dev, math="f16x3")
+    x = p.buffer(2, 32, 32, 32)
+    out = p.buffer(2, 16, 16, 64)
+    p.conv(x, conv, out)
+    assert p.ops[-1].tile_m not in (10, 11)      # the planner never does it ...
+    p.ops[-1].tile_m = 11                        # ... and the library refuses it
+    p._arr = None
+    with pytest.raises(_lib.IdhError):
+        p.run()
