@@ -22,6 +22,8 @@
 //     MFMA fragment order (152 KiB for K = 7, all 160 KiB for K = 8) and are shared by the 8 waves of a persistent
 //     workgroup; per plane a wave issues (K+4+8)*32 MFMAs.
 // Roofline: fp32 MFMA (2*D*N*(16K+64+128)*128 + ... ~ 66.6 GFLOP per 96x128x64 frame).
+#include <stdlib.h>
+
 #include "idh_common.h"
 #include "split_f16.h"
 
@@ -115,6 +117,9 @@ struct FvArgs {
     float dmin, dmax;
 };
 
+// KT = compile-time view count (7, 8) or 0 = run-time: with KT > 0 the view loop is fully unrolled so the
+// scheduler can slot view k+1's projection / blend VALU work between view k's 32 MFMAs.
+template <int KT>
 __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4 *sW1 = reinterpret_cast<f32x4 *>(smem_raw);            // (K+4)*8*64
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ln = lane & 15, q = lane >> 4;
     const int N = a.H * a.W;
-    const int K = a.K;
+    const int K = KT > 0 ? KT : a.K;
     const float Wf = (float)a.W, Hf = (float)a.H;
     const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
 
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 return t;
             };
             Tap cur = issue(0);
-#pragma unroll 1
+#pragma clang loop unroll_count(KT > 0 ? KT : 1)
             for (int k = 0; k < K; ++k) {
                 const Tap nxt = issue(min(k + 1, K - 1));  // unconditional: counted vmcnt waits
                 any_inb |= (cur.u > 2.f) & (cur.u < Wf - 2.f) & (cur.v > 2.f) & (cur.v < Hf - 2.f);
@@ -733,7 +738,9 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     if (grid > 256) grid = 256;  // persistent: one 512-thread workgroup per CU (LDS-resident weights)
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k<7>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
@@ -754,7 +761,8 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
         else hipLaunchKernelGGL(fv_mlp_f16_k<0>, dim3(grid), dim3(512), lds, st, a, sw1, sw2);
     } else {
         const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4);
-        hipLaunchKernelGGL(fv_mlp_k, dim3(grid), dim3(512), lds, st, a);
+        if (K == 7 && getenv("IDH_FV_GENERIC") == nullptr) hipLaunchKernelGGL(fv_mlp_k<7>, dim3(grid), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL(fv_mlp_k<0>, dim3(grid), dim3(512), lds, st, a);
     }
     IDH_CHECK_LAUNCH();
     if (lowest_bhw) {
