@@ -70,7 +70,7 @@ class WarpMatchDot:
     map, K source views, D planes, random-init N(0,1) matching features (NHWC, resident)."""
 
     name = "warp_match_dot"
-    dominant_kernel = "cv_dot_k"
+    dominant_kernel = "cv_dot_quad_k"
     bound = "hbm"
 
     def __init__(self, args, device, rank):

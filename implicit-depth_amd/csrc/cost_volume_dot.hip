@@ -16,8 +16,11 @@
 // 4 x dwordx4.  Work decomposition: a 256-thread workgroup owns 32 consecutive pixels and ALL
 // D planes: thread (px, g) sweeps planes [g*DP, (g+1)*DP) for its pixel, g = 0..7, so the
 // arg-max over planes finishes inside the workgroup (LDS reduce, first maximum wins) and the
-// cost volume is written exactly once.  The per-(b,k) 3x4 homographies are built once per
+// cost volume is written exactly once.  (cv_dot_k below keeps this one-lane-per-tap form; the launcher
+// prefers cv_dot_quad_k, the quad-coalesced form further down, whenever 32-bit tap offsets suffice.)  The per-(b,k) 3x4 homographies are built once per
 // workgroup into LDS and read back as same-address (broadcast) LDS reads.
+#include <stdlib.h>
+
 #include "idh_common.h"
 
 namespace {
@@ -190,6 +193,155 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Quad-coalesced variant.  The kernel above issues one 64-byte tap per lane as four dwordx4 loads; the vector
+// L1 serves that pattern at ~28 B/clk/CU, but 43 B/clk/CU when the four 16-byte pieces of a tap sit in four
+// ADJACENT lanes (tools/micro/gather_bw.hip).  Here a quad of lanes owns one pixel and four consecutive planes:
+// lane q projects plane d+q (no redundant geometry), then for j = 0..3 the quad takes plane d+j's tap
+// offsets / weights from lane j (DPP quad broadcast), each lane loads ITS 16-byte quarter of the four taps
+// (one coalesced 64-byte segment per tap per quad) and accumulates a partial dot product; after the K views
+// the four partial sums of each plane are added across the quad and lane 0 stores the four planes as one
+// 16-byte NHWC vector.  A 256-thread workgroup = 4 pixels x 16 plane quads (D <= 64 per pass; larger D loops).
+template <int CTRL>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+
+__global__ __launch_bounds__(256) void cv_dot_quad_k(const float *__restrict__ cur, const float *__restrict__ src,
+                                                     const float *__restrict__ src_K, const float *__restrict__ src_E,
+                                                     const float *__restrict__ cur_invK, float dmin, float dmax, int B, int K,
+                                                     int H, int W, int D, int tiles_per_img, int cost_cs,
+                                                     float *__restrict__ cost, float *__restrict__ lowest,
+                                                     float *__restrict__ planes_out) {
+    __shared__ float s_planes[kMaxPlanes];
+    __shared__ __attribute__((aligned(16))) float s_h[IDH_MAX_SOURCE_VIEWS][12];
+    __shared__ float s_best[16][4];
+    __shared__ int s_bidx[16][4];
+
+    const int N = H * W;
+    const unsigned lin = idh_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lin / tiles_per_img;
+    const int tile = lin - b * tiles_per_img;
+    const int q = threadIdx.x & 3;           // channel quarter / plane within the quad's group of four
+    const int quad = threadIdx.x >> 2;       // 0..63
+    const int pxl = quad & 3;                // pixel of the tile
+    const int pg = quad >> 2;                // plane-quad slot 0..15
+
+    if (threadIdx.x < K)
+        build_homography(src_K + (size_t)(b * K + threadIdx.x) * 16, src_E + (size_t)(b * K + threadIdx.x) * 16,
+                         cur_invK + (size_t)b * 16, s_h[threadIdx.x]);
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float dp = depth_plane(i, D, dmin, dmax);
+        s_planes[i] = dp;
+        if (planes_out != nullptr && blockIdx.x == 0) planes_out[i] = dp;
+    }
+    __syncthreads();
+
+    const int p_raw = tile * 4 + pxl;
+    const bool live = p_raw < N;
+    const int p = live ? p_raw : N - 1;
+    const int y = p / W, x = p - y * W;
+    const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
+    const float4 cq = *reinterpret_cast<const float4 *>(cur + ((size_t)b * N + p) * kC + 4 * q);
+    const float Wf = (float)W, Hf = (float)H;
+
+    float best = -INFINITY;
+    int bidx = 0;
+    for (int dbase = 4 * pg; dbase < D; dbase += 64) {  // this quad's planes dbase .. dbase+3
+        const int dmine = min(dbase + q, D - 1);       // the plane this lane projects
+        const float depth = s_planes[dmine];
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float *hm = s_h[k];
+            const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+            const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+            const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+            const float cx = fmaf(depth, qx, hm[9]);
+            const float cy = fmaf(depth, qy, hm[10]);
+            const float cz = fmaf(depth, qz, hm[11]);
+            const float z = fmaxf(cz, 1e-5f);
+            float r = __builtin_amdgcn_rcpf(z);
+            r = r * fmaf(-z, r, 2.0f);
+            const float sx = fminf(fmaxf(fmaf(cx, r, -0.5f), -1.0f), Wf);
+            const float sy = fminf(fmaxf(fmaf(cy, r, -0.5f), -1.0f), Hf);
+            const float x0f = floorf(sx), y0f = floorf(sy);
+            const float fx = sx - x0f, fy = sy - y0f;
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const float wx0 = (x0 >= 0 && x0 < W) ? 1.0f - fx : 0.f;
+            const float wx1 = (x0 + 1 < W) ? fx : 0.f;
+            const float wy0 = (y0 >= 0 && y0 < H) ? 1.0f - fy : 0.f;
+            const float wy1 = (y0 + 1 < H) ? fy : 0.f;
+            const int xa0 = min(max(x0, 0), W - 1), xa1 = min(x0 + 1, W - 1);
+            const int ya0 = min(max(y0, 0), H - 1), ya1 = min(y0 + 1, H - 1);
+            // own sample: four tap weights and four element offsets (32-bit: B*K*N*16 < 2^31 is checked on the host)
+            const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+            const int o00 = (ya0 * W + xa0) * kC, o01 = (ya0 * W + xa1) * kC, o10 = (ya1 * W + xa0) * kC, o11 = (ya1 * W + xa1) * kC;
+            const float *sb = src + (size_t)(b * K + k) * N * kC + 4 * q;
+            // round j: every lane of the quad works on plane dbase + j with lane j's geometry
+#define IDH_QUAD_ROUND(CTRL, ACC)                                                                                      \
+    {                                                                                                                  \
+        const float4 t00 = *reinterpret_cast<const float4 *>(sb + quad_bcast_i<CTRL>(o00));                            \
+        const float4 t01 = *reinterpret_cast<const float4 *>(sb + quad_bcast_i<CTRL>(o01));                            \
+        const float4 t10 = *reinterpret_cast<const float4 *>(sb + quad_bcast_i<CTRL>(o10));                            \
+        const float4 t11 = *reinterpret_cast<const float4 *>(sb + quad_bcast_i<CTRL>(o11));                            \
+        const float d00 = fmaf(cq.w, t00.w, fmaf(cq.z, t00.z, fmaf(cq.y, t00.y, cq.x * t00.x)));                       \
+        const float d01 = fmaf(cq.w, t01.w, fmaf(cq.z, t01.z, fmaf(cq.y, t01.y, cq.x * t01.x)));                       \
+        const float d10 = fmaf(cq.w, t10.w, fmaf(cq.z, t10.z, fmaf(cq.y, t10.y, cq.x * t10.x)));                       \
+        const float d11 = fmaf(cq.w, t11.w, fmaf(cq.z, t11.z, fmaf(cq.y, t11.y, cq.x * t11.x)));                       \
+        ACC += fmaf(quad_bcast<CTRL>(w11), d11, fmaf(quad_bcast<CTRL>(w10), d10, fmaf(quad_bcast<CTRL>(w01), d01, quad_bcast<CTRL>(w00) * d00))); \
+    }
+            IDH_QUAD_ROUND(0x00, acc0)  // quad_perm [0,0,0,0]
+            IDH_QUAD_ROUND(0x55, acc1)  // [1,1,1,1]
+            IDH_QUAD_ROUND(0xAA, acc2)  // [2,2,2,2]
+            IDH_QUAD_ROUND(0xFF, acc3)  // [3,3,3,3]
+#undef IDH_QUAD_ROUND
+        }
+        // add the four channel-quarter partials of every plane across the quad (xor 1, xor 2 within the quad)
+#define IDH_QUAD_SUM(v)                                                                                                 \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)); /* [1,0,3,2] */      \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)); /* [2,3,0,1] */
+        IDH_QUAD_SUM(acc0) IDH_QUAD_SUM(acc1) IDH_QUAD_SUM(acc2) IDH_QUAD_SUM(acc3)
+#undef IDH_QUAD_SUM
+        if (q == 0) {
+            const float a4[4] = {acc0, acc1, acc2, acc3};
+            const int nd = min(4, D - dbase);
+            if (live) {
+                if (cost_cs > 0) {
+                    float *o = cost + ((size_t)b * N + p) * cost_cs + dbase;
+                    if (nd == 4 && (cost_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(cost) & 15) == 0)
+                        *reinterpret_cast<float4 *>(o) = make_float4(acc0, acc1, acc2, acc3);
+                    else
+                        for (int j = 0; j < nd; ++j) o[j] = a4[j];
+                } else {
+                    for (int j = 0; j < nd; ++j) cost[((size_t)b * D + dbase + j) * N + p] = a4[j];
+                }
+            }
+            for (int j = 0; j < nd; ++j)
+                if (a4[j] > best) { best = a4[j]; bidx = dbase + j; }
+        }
+    }
+    if (lowest == nullptr) return;
+    if (q == 0) { s_best[pg][pxl] = best; s_bidx[pg][pxl] = bidx; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int px2 = threadIdx.x;
+        const int pp = tile * 4 + px2;
+        if (pp < N) {
+            // first maximum wins: candidates are compared in plane order (slot pg covers planes 4pg + 64m)
+            float bv = -INFINITY;
+            int bi = 0;
+            for (int j = 0; j < 16; ++j) {
+                const float v = s_best[j][px2];
+                const int i = s_bidx[j][px2];
+                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+            }
+            lowest[(size_t)b * N + pp] = s_planes[bi];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
@@ -203,6 +355,15 @@ extern "C" int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_n
     if (cost_nhwc_cs != 0 && cost_nhwc_cs < D) return IDH_EINVAL;
     if (!cur_nhwc || !cost || !cur_invK_44 || (K > 0 && (!src_nhwc || !src_K_44 || !src_E_44)))
         return IDH_EINVAL;
+    static const int force = getenv("IDH_CV_DOT_KERNEL") ? atoi(getenv("IDH_CV_DOT_KERNEL")) : 0;  // 1 = one lane per tap, 2 = quad
+    const bool quad_ok = (long long)B * K * H * W * kC < (1ll << 31) && K > 0;
+    if (quad_ok && force != 1) {  // default: 1.4-1.7x faster than the one-lane-per-tap kernel at every batch size measured
+        const int tiles4 = idh_cdiv((long long)H * W, 4);
+        hipLaunchKernelGGL(cv_dot_quad_k, dim3((unsigned)(B * tiles4)), dim3(256), 0, idh_stream(stream), cur_nhwc, src_nhwc, src_K_44,
+                           src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles4, cost_nhwc_cs, cost, lowest_bhw, planes_d);
+        IDH_CHECK_LAUNCH();
+        return IDH_OK;
+    }
     const int tiles = idh_cdiv((long long)H * W, kTilePx);
     hipLaunchKernelGGL(cv_dot_k, dim3((unsigned)(B * tiles)), dim3(256), 0, idh_stream(stream), cur_nhwc,
                        src_nhwc, src_K_44, src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles, cost_nhwc_cs,
