@@ -120,3 +120,8 @@ def test_dropin_convert_with_math_selects_split_kernels_per_model():
         assert base.rel_err(out["pred_0"].cpu(), g["pred_0"]) < base.TOL
     finally:
         nhwc.SPLIT_MIN_BLOCKS = old
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 16, 9, 7, 1), (3, 64, 64, 33, 47, 1), (2, 112, 64, 24, 32, 1), (1, 64, 128, 31, 45, 2)])
+def test_basic_block_ragged_shapes_split(shape, split_everything):
+    conv_base.test_basic_block_vs_oracle(shape)
