@@ -634,6 +634,30 @@ __global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__
     const long long total = (long long)B * N;
     if (planes_out && blockIdx.x == 0)
         for (int i = threadIdx.x; i < D; i += 256) planes_out[i] = fv_depth_plane(i, D, dmin, dmax);
+    if (vol_cs > 0 && (vol_cs & 3) == 0 && (D & 3) == 0 && (reinterpret_cast<uintptr_t>(vol) & 15) == 0) {
+        // NHWC: 16 lanes share a pixel and read its D planes as coalesced 16-byte pieces (a lane per pixel would
+        // stride 4*cs bytes between lanes: 2.5x read amplification at the HBM counters)
+        const int sub = threadIdx.x & 15;
+        for (long long t = blockIdx.x * 16ll + (threadIdx.x >> 4); t < total; t += gridDim.x * 16ll) {
+            float best = -INFINITY;
+            int bi = 0;
+            for (int d0 = 4 * sub; d0 < D; d0 += 64) {
+                const float4 v = *reinterpret_cast<const float4 *>(vol + t * vol_cs + d0);
+                if (v.x > best) { best = v.x; bi = d0; }
+                if (v.y > best) { best = v.y; bi = d0 + 1; }
+                if (v.z > best) { best = v.z; bi = d0 + 2; }
+                if (v.w > best) { best = v.w; bi = d0 + 3; }
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {  // first maximum wins: on ties keep the lower plane index
+                const float ov = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (sub == 0) lowest[t] = fv_depth_plane(bi, D, dmin, dmax);
+        }
+        return;
+    }
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
         const long long b = t / N, p = t - b * N;
         float best = -INFINITY;
@@ -766,8 +790,8 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     }
     IDH_CHECK_LAUNCH();
     if (lowest_bhw) {
-        int g2 = idh_cdiv((long long)B * N, 256);
-        if (g2 > 4096) g2 = 4096;
+        int g2 = idh_cdiv((long long)B * N, vol_nhwc_cs > 0 ? 16 : 256);
+        if (g2 > 8192) g2 = 8192;
         hipLaunchKernelGGL(argmax_planes_k, dim3(g2), dim3(256), 0, st, vol, vol_nhwc_cs, B, N, D, dmin, dmax, lowest_bhw,
                            planes_d);
         IDH_CHECK_LAUNCH();
