@@ -412,6 +412,13 @@ class Plan:
             out = self.buffer(x.N, Ho, Wo, planes)
         if blk.downsample is None:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=x)
+        elif (self.math != "fp32" and blk.downsample[0].kernel_size[0] == 3
+              and split_eligible([(h, blk.conv2)], planes, x.N, Ho, Wo, PAD_ZEROS)):
+            # stride-2 block: the strided 3x3 projection (1/3 of the block's conv2-stage flops) runs on its own with
+            # the fp32 direct kernel and enters the split-precision conv2 as the residual
+            proj = self.buffer(x.N, Ho, Wo, planes)
+            self.conv(x, blk.downsample[0], proj)
+            self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=proj)
         else:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, x2=x, conv2=blk.downsample[0])
         return out
