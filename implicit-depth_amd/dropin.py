@@ -109,5 +109,7 @@ def hot_path_of(model: nn.Module, min_depth: float = 0.25, max_depth: float = 5.
     o = getattr(model, "run_opts", None)
     if o is not None:
         min_depth, max_depth = o.min_matching_depth, o.max_matching_depth
-    return HotPath(model.cost_volume, model.cost_volume_net, model.depth_decoder, getattr(model, "binary_mlp", None), min_depth, max_depth,
-                   conv_math=getattr(model.cost_volume_net, "conv_math", None))
+    hot = HotPath(model.cost_volume, model.cost_volume_net, model.depth_decoder, getattr(model, "binary_mlp", None), min_depth, max_depth,
+                  conv_math=getattr(model.cost_volume_net, "conv_math", None))
+    hot.thresholder = getattr(model, "thresholder", None)  # test_bd.py:103 sets it on the model for the infer_depth search
+    return hot
