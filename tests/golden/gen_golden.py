@@ -385,5 +385,43 @@ def gen_skip_decoder(syn):
         save(nm, **{k: v for k, v in out.items()}, keys=np.array(sorted(dec.state_dict())))
 
 
+def gen_full_feature_volume():
+    """G2 at BASELINE.json's full size (96x128 matching map, K=7, D=64, the reference-native BDModel volume):
+    checksums + strided slices of the reference FeatureVolumeManager's outputs.
+        python tests/golden/gen_golden.py g2_full
+    """
+    import contextlib, io
+
+    import_reference()
+    import implicit_depth_amd.synthetic as syn
+    from modules.cost_volume import FeatureVolumeManager
+
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(8)
+    print("G2 feature volume (MLP), full size")
+    B, K, C, H, W, D, seed = 1, 7, 16, 96, 128, 64, 0
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = FeatureVolumeManager(H, W, D, mlp_channels=[202, 128, 128, 1], num_source_views=K)
+    syn.fill_state_dict(m.mlp, seed=100 + seed, gain=1.4)
+    fv, low, planes, mask = m(**inp, return_mask=True)
+    save(
+        "g2_full_k7d64",
+        dims=np.array([B, K, C, H, W, D, seed, -1, -1]),
+        mlp_seed=np.array(100 + seed),
+        fv_chk=chk(fv),
+        fv_slice=fv[:, ::4, ::6, ::8],
+        lowest_chk=chk(low),
+        lowest_slice=low[:, ::3, ::4],
+        mask_count=np.array(int(mask.sum().item())),
+        mask_slice=mask[:, ::3, ::4],
+        mlp_chk=np.stack([chk(v) for v in m.mlp.state_dict().values()]),
+    )
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g2_full":
+        gen_full_feature_volume()
+    else:
+        main()
+        gen_full_feature_volume()

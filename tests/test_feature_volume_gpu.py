@@ -52,6 +52,21 @@ def test_matches_oracle_fp64(shape):
     assert ((low.cpu().double() - rlow).abs() > 1e-5).float().mean().item() < 5e-3
 
 
+def test_full_size_golden():
+    """BASELINE.json's size (96x128 matching map, K=7, D=64): reference checksums + strided slices."""
+    g = load_golden("g2_full_k7d64")
+    B, K, C, H, W, D, seed = [int(v) for v in g["dims"][:7]]
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed)
+    m = _manager(K, H, W, D, int(g["mlp_seed"])).cuda()
+    fv, low, planes, mask = m(**{k: v.cuda() for k, v in inp.items()}, return_mask=True)
+    fv, low, mask = fv.cpu(), low.cpu(), mask.cpu()
+    assert rel_err(fv[:, ::4, ::6, ::8], g["fv_slice"]) < TOL
+    s = fv.double()
+    np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["fv_chk"][1:], rtol=1e-4)
+    assert ((low[:, ::3, ::4] - torch.as_tensor(g["lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3
+    assert (mask[:, ::3, ::4] != torch.as_tensor(g["mask_slice"])).float().mean().item() < 2e-3
+
+
 def test_wrong_view_count_is_an_error():
     from implicit_depth_amd import _lib
 

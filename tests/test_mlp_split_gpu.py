@@ -30,6 +30,10 @@ def test_matches_oracle_fp64_f16x3(shape, f16_mlp):
     base.test_matches_oracle_fp64(shape)
 
 
+def test_full_size_golden_f16x3(f16_mlp):
+    base.test_full_size_golden()
+
+
 def test_pipeline_with_feature_volume_f16x3(f16_mlp):
     base.test_pipeline_with_feature_volume()
 

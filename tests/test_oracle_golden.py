@@ -75,6 +75,23 @@ def test_feature_volume_matches_reference(name):
     assert mism.float().mean().item() < 5e-3
 
 
+def test_feature_volume_full_size_checksums():
+    """BASELINE.json's size (96x128 map, K=7, D=64): the oracle against the reference's checksums / slices."""
+    g = load_golden("g2_full_k7d64")
+    inp, D = _inputs(g)
+    K = int(g["dims"][1])
+    w = _mlp_weights(K, int(g["mlp_seed"]))
+    np.testing.assert_allclose(np.stack([chk(v) for v in w.values()]), g["mlp_chk"], rtol=1e-12)
+    fv, low, planes, mask = ocv.feature_volume(
+        inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"],
+        inp["cur_invK"], 0.25, 5.0, D, w, return_mask=True)
+    assert rel_err(fv[:, ::4, ::6, ::8], g["fv_slice"]) < 5e-5
+    np.testing.assert_allclose(chk(fv)[1:], g["fv_chk"][1:], rtol=1e-5)
+    assert ((torch.as_tensor(g["lowest_slice"]) - low[:, ::3, ::4]).abs() > 1e-5).float().mean().item() < 5e-3
+    assert (mask[:, ::3, ::4] != torch.as_tensor(g["mask_slice"])).float().mean().item() < 2e-3
+    assert abs(int(mask.sum()) - int(g["mask_count"])) <= 0.002 * mask.numel()
+
+
 def _sd(module_ctor, seed, gain=1.0):
     m = module_ctor()
     syn.fill_state_dict(m, seed=seed, gain=gain)
