@@ -24,6 +24,10 @@ def test_bdmodel_golden_with_split_convs(volume, split_default):
     base.test_hot_path_reproduces_reference_bdmodel_forward(volume)
 
 
+def test_full_size_bdmodel_golden_with_split_kernels(split_everything):
+    base.test_full_size_bdmodel_forward_golden()
+
+
 def test_depthmodel_golden_with_split_convs(split_default):
     base.test_hot_path_reproduces_reference_depthmodel_forward()
 
