@@ -419,6 +419,68 @@ def gen_full_feature_volume():
     )
 
 
+def gen_full_temporal():
+    """BASELINE.json config 5 at full size: the reference's BDModel.forward with the temporal prior —
+    512x384 8-frame tuple, mlp_feature_volume K=7, **96** depth planes, prior-enabled occlusion MLP, the previous
+    frame's prediction warped by sample_prior (bd_model.py:395-449).  Synthetic backbone features as in g5_full.
+        python tests/golden/gen_golden.py g5_temporal
+    """
+    import contextlib, io
+
+    import_reference()
+    import implicit_depth_amd.synthetic as syn
+    import timm, antialiased_cnns
+    from options import Options
+
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(8)
+    print("G5 BDModel.forward with temporal prior, full size, D=96")
+    for name in ("pytorch_lightning", "moviepy", "moviepy.editor"):
+        _stub(name)
+    sys.modules["pytorch_lightning"].LightningModule = torch.nn.Module
+    sys.modules["moviepy"].editor = sys.modules["moviepy.editor"]
+    sys.modules["kornia"].filters.sobel = None
+    timm.create_model = lambda *a, **k: syn.StubImageEncoder()
+    for nm in ("resnet18", "resnet34", "resnet50", "resnet101", "resnet152"):
+        setattr(antialiased_cnns, nm, lambda *a, **k: syn.StubResnetStem())
+    from experiment_modules.bd_model import BDModel
+
+    torch.nn.Module.cuda = lambda self, *a, **k: self  # the ctor / run_mlp_val call .cuda() on the geometry helpers
+    K, Hi, Wi, D, P = 7, 384, 512, 96, 1
+    o = Options()
+    o.image_width, o.image_height = Wi, Hi
+    o.matching_num_depth_bins = D
+    o.feature_volume_type = "mlp_feature_volume"
+    o.model_num_views = K + 1
+    o.binary_loss_positive_weight = 1.0
+    o.bd_edge_regularision = False
+    o.use_prior = True
+    torch.nn.Module.save_hyperparameters = lambda self, *a, **k: None
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = BDModel(o)
+    model.eval()
+    syn.fill_state_dict(model, seed=30, gain=1.0)
+    cur, src = syn.frame_tuple(1, K, Hi, Wi, seed=31, P=P)
+    cur["prior_prediction"] = torch.sigmoid(syn.randn((1, 1, Hi // 2, Wi // 2), 74, "prior"))
+    cur["prior_cam_T_world"] = torch.linalg.inv(syn.source_pose(1).float())[None]
+    mc = syn.randn((1, 16, Hi // 4, Wi // 4), 71, "mc")
+    ms = syn.randn((1, K, 16, Hi // 4, Wi // 4), 72, "ms")
+    pyr = list(syn.encoder_pyramid(1, Hi, Wi, seed=73))
+    model.compute_matching_feats = lambda *a, **k: (mc, ms)
+    model.encoder.forward = lambda x: pyr
+    out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+    save(
+        "g5_full_temporal_d96",
+        dims=np.array([K, Hi, Wi, D, P]),
+        pred_chk=chk(out["pred_0"]),
+        pred_slice=out["pred_0"][:, :, ::6, ::8],
+        prior_mask_chk=chk(cur["prior_mask"]),
+        prior_mask_slice=cur["prior_mask"][:, :, ::6, ::8],
+        lowest_slice=out["lowest_cost_bhw"][:, ::3, ::4],
+        keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))),
+    )
+
+
 def gen_full_bdmodel():
     """G5 at BASELINE.json's full size: the reference's BDModel.forward on a 512x384 8-frame tuple
     (mlp_feature_volume, K=7, D=64, 8 query planes).  The third-party backbones are replaced by seeded synthetic
@@ -485,7 +547,10 @@ if __name__ == "__main__":
         gen_full_feature_volume()
     elif len(sys.argv) > 1 and sys.argv[1] == "g5_full":
         gen_full_bdmodel()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g5_temporal":
+        gen_full_temporal()
     else:
         main()
         gen_full_feature_volume()
         gen_full_bdmodel()
+        gen_full_temporal()

@@ -122,3 +122,46 @@ def test_full_size_bdmodel_forward_golden():
     np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["pred_chk"][1:], rtol=2e-4)
     assert ((low[:, ::3, ::4] - torch.as_tensor(g["lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3
     assert (mask[:, ::3, ::4] != torch.as_tensor(g["mask_slice"])).float().mean().item() < 2e-3
+
+
+def test_full_size_temporal_prior_golden():
+    """BASELINE.json config 5 at full size: 512x384 8-frame tuple, 96 depth planes, prior-enabled occlusion MLP with
+    the previous prediction warped by sample_prior — against the reference's BDModel.forward (golden g5_full_temporal)."""
+    import numpy as np
+
+    from implicit_depth_amd import cost_volume as cv
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd.dropin import hot_path_of
+
+    g = load_golden("g5_full_temporal_d96")
+    K, Hi, Wi, D, P = [int(v) for v in g["dims"]]
+    h = nn.Module()
+    h.cost_volume = cv.FeatureVolumeManager(Hi // 4, Wi // 4, D, num_source_views=K)
+    h.cost_volume_net = net.CVEncoder(D, [48, 64, 160, 256], [64, 128, 256, 384])
+    h.depth_decoder = net.BDDecoderPP([24] + h.cost_volume_net.num_ch_enc)
+    h.binary_mlp = net.BinaryMLPNetwork(h.depth_decoder.num_ch_dec, mlp_size=128, use_prior=True)
+    syn.fill_state_dict(h, seed=30)
+    assert sorted(h.state_dict()) == list(g["keys"])
+    h.cuda()
+    cur, src = syn.frame_tuple(1, K, Hi, Wi, seed=31, P=P)
+    cur = {k: v.cuda() for k, v in cur.items()}
+    src = {k: v.cuda() for k, v in src.items()}
+    prior_inputs = {"prior_prediction": torch.sigmoid(syn.randn((1, 1, Hi // 2, Wi // 2), 74, "prior")).cuda(),
+                    "prior_cam_T_world": torch.linalg.inv(syn.source_pose(1).float())[None].cuda(),
+                    "world_T_cam_b44": cur["world_T_cam_b44"], "K_s0_b44": cur["K_s0_b44"], "invK_s0_b44": cur["invK_s0_b44"]}
+    mc = syn.randn((1, 16, Hi // 4, Wi // 4), 71, "mc").cuda()
+    ms = syn.randn((1, K, 16, Hi // 4, Wi // 4), 72, "ms").cuda()
+    pyr = [t.cuda() for t in syn.encoder_pyramid(1, Hi, Wi, seed=73)]
+    hot = hot_path_of(h)
+    out = hot(mc, ms, pyr, src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1),
+              cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"], src["K_s1_b44"], cur["invK_s1_b44"],
+              rendered_depth=cur["rendered_depth"], prior_inputs=prior_inputs, return_mask=True)
+    pm = out["prior_mask"].cpu()
+    assert ((pm[:, :, ::6, ::8] - torch.as_tensor(g["prior_mask_slice"])).abs() > 1e-6).float().mean().item() < 2e-3  # nearest sampling
+    pred = out["pred_0"].cpu()
+    # a flipped nearest-neighbour prior sample changes one pixel's logit: compare the bulk tightly, allow rare outliers
+    d = (pred[:, :, ::6, ::8] - torch.as_tensor(g["pred_slice"])).abs() / torch.as_tensor(g["pred_slice"]).abs().max()
+    assert (d > TOL).float().mean().item() < 2e-3
+    s = pred.double()
+    np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["pred_chk"][1:], rtol=5e-4)
+    assert ((out["lowest_cost_bhw"].cpu()[:, ::3, ::4] - torch.as_tensor(g["lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3
