@@ -419,6 +419,62 @@ def gen_full_feature_volume():
     )
 
 
+def gen_full_depthmodel():
+    """G9 at full size: the reference's DepthModel.forward (depth_model.py:280-440) on a 512x384 8-frame tuple
+    (mlp_feature_volume K=7, D=64, DepthDecoderPP heads); synthetic backbone features as in g5_full.
+        python tests/golden/gen_golden.py g9_full
+    """
+    import contextlib, io
+
+    import_reference()
+    import implicit_depth_amd.synthetic as syn
+    import timm, antialiased_cnns
+
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(8)
+    print("G9 DepthModel.forward, full size (synthetic backbone features)")
+    for name in ("pytorch_lightning", "moviepy", "moviepy.editor"):
+        _stub(name)
+    sys.modules["pytorch_lightning"].LightningModule = torch.nn.Module
+    sys.modules["moviepy"].editor = sys.modules["moviepy.editor"]
+    k = sys.modules["kornia"]
+    k.filters.sobel = None
+    for name in ("losses", "geometry", "utils"):
+        setattr(k, name, _stub("kornia." + name))
+    timm.create_model = lambda *a, **kw: syn.StubImageEncoder()
+    for nm in ("resnet18", "resnet34", "resnet50", "resnet101", "resnet152"):
+        setattr(antialiased_cnns, nm, lambda *a, **kw: syn.StubResnetStem())
+    from options import Options
+    from experiment_modules.depth_model import DepthModel
+
+    K, Hi, Wi, D = 7, 384, 512, 64
+    o = Options()
+    o.image_width, o.image_height = Wi, Hi
+    o.matching_num_depth_bins = D
+    o.feature_volume_type = "mlp_feature_volume"
+    o.model_num_views = K + 1
+    torch.nn.Module.save_hyperparameters = lambda self, *a, **kw: None
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DepthModel(o)
+    model.eval()
+    syn.fill_state_dict(model, seed=33, gain=1.0)
+    cur, src = syn.frame_tuple(1, K, Hi, Wi, seed=34, P=1)
+    mc = syn.randn((1, 16, Hi // 4, Wi // 4), 75, "mc")
+    ms = syn.randn((1, K, 16, Hi // 4, Wi // 4), 76, "ms")
+    pyr = list(syn.encoder_pyramid(1, Hi, Wi, seed=77))
+    model.compute_matching_feats = lambda *a, **kw: (mc, ms)
+    model.encoder.forward = lambda x: pyr
+    out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+    arrs = {}
+    for i in range(4):
+        for nm in (f"log_depth_pred_s{i}_b1hw", f"depth_pred_s{i}_b1hw"):
+            arrs[nm + "_chk"] = chk(out[nm])
+            arrs[nm + "_slice"] = out[nm][:, :, ::3, ::4] if i >= 2 else out[nm][:, :, ::6, ::8]
+    save("g9_full_depthmodel", dims=np.array([K, Hi, Wi, D]), lowest_slice=out["lowest_cost_bhw"][:, ::3, ::4],
+         mask_slice=out["overall_mask_bhw"][:, ::3, ::4], **arrs,
+         keys=np.array(sorted(kk for kk in model.state_dict() if kk.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder"))))
+
+
 def gen_full_temporal():
     """BASELINE.json config 5 at full size: the reference's BDModel.forward with the temporal prior —
     512x384 8-frame tuple, mlp_feature_volume K=7, **96** depth planes, prior-enabled occlusion MLP, the previous
@@ -549,8 +605,11 @@ if __name__ == "__main__":
         gen_full_bdmodel()
     elif len(sys.argv) > 1 and sys.argv[1] == "g5_temporal":
         gen_full_temporal()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g9_full":
+        gen_full_depthmodel()
     else:
         main()
         gen_full_feature_volume()
         gen_full_bdmodel()
         gen_full_temporal()
+        gen_full_depthmodel()

@@ -165,3 +165,40 @@ def test_full_size_temporal_prior_golden():
     s = pred.double()
     np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["pred_chk"][1:], rtol=5e-4)
     assert ((out["lowest_cost_bhw"].cpu()[:, ::3, ::4] - torch.as_tensor(g["lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3
+
+
+def test_full_size_depthmodel_forward_golden():
+    """The reference's DepthModel.forward at 512x384 (mlp_feature_volume K=7, D=64, DepthDecoderPP heads + exp)."""
+    import numpy as np
+
+    from implicit_depth_amd import cost_volume as cv
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd.dropin import hot_path_of
+
+    g = load_golden("g9_full_depthmodel")
+    K, Hi, Wi, D = [int(v) for v in g["dims"]]
+    h = nn.Module()
+    h.cost_volume = cv.FeatureVolumeManager(Hi // 4, Wi // 4, D, num_source_views=K)
+    h.cost_volume_net = net.CVEncoder(D, [48, 64, 160, 256], [64, 128, 256, 384])
+    h.depth_decoder = net.DepthDecoderPP([24] + h.cost_volume_net.num_ch_enc)
+    syn.fill_state_dict(h, seed=33)
+    assert sorted(h.state_dict()) == list(g["keys"])
+    h.cuda()
+    cur, src = syn.frame_tuple(1, K, Hi, Wi, seed=34, P=1)
+    cur = {k: v.cuda() for k, v in cur.items()}
+    src = {k: v.cuda() for k, v in src.items()}
+    mc = syn.randn((1, 16, Hi // 4, Wi // 4), 75, "mc").cuda()
+    ms = syn.randn((1, K, 16, Hi // 4, Wi // 4), 76, "ms").cuda()
+    pyr = [t.cuda() for t in syn.encoder_pyramid(1, Hi, Wi, seed=77)]
+    hot = hot_path_of(h)
+    out = hot(mc, ms, pyr, src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1),
+              cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"], src["K_s1_b44"], cur["invK_s1_b44"], return_mask=True)
+    for i in range(4):
+        sl = (slice(None), slice(None), slice(None, None, 3), slice(None, None, 4)) if i >= 2 else (slice(None), slice(None), slice(None, None, 6), slice(None, None, 8))
+        for nm, tol in ((f"log_depth_pred_s{i}_b1hw", TOL), (f"depth_pred_s{i}_b1hw", 5 * TOL)):  # exp() amplifies
+            y = out[nm].cpu()
+            assert rel_err(y[sl], g[nm + "_slice"]) < tol, nm
+            s = y.double()
+            np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g[nm + "_chk"][1:], rtol=1e-3)
+    assert ((out["lowest_cost_bhw"].cpu()[:, ::3, ::4] - torch.as_tensor(g["lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3
+    assert (out["overall_mask_bhw"].cpu()[:, ::3, ::4] != torch.as_tensor(g["mask_slice"])).float().mean().item() < 2e-3

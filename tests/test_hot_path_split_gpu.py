@@ -32,6 +32,10 @@ def test_full_size_temporal_golden_with_split_kernels(split_everything):
     base.test_full_size_temporal_prior_golden()
 
 
+def test_full_size_depthmodel_golden_with_split_kernels(split_everything):
+    base.test_full_size_depthmodel_forward_golden()
+
+
 def test_depthmodel_golden_with_split_convs(split_default):
     base.test_hot_path_reproduces_reference_depthmodel_forward()
 
