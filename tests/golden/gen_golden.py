@@ -564,38 +564,41 @@ def gen_full_bdmodel():
         setattr(antialiased_cnns, nm, lambda *a, **k: syn.StubResnetStem())
     from experiment_modules.bd_model import BDModel
 
-    K, Hi, Wi, D, P = 7, 384, 512, 64, 8
-    o = Options()
-    o.image_width, o.image_height = Wi, Hi
-    o.matching_num_depth_bins = D
-    o.feature_volume_type = "mlp_feature_volume"
-    o.model_num_views = K + 1
-    o.binary_loss_positive_weight = 1.0
-    o.bd_edge_regularision = False
-    o.use_prior = False
-    torch.nn.Module.save_hyperparameters = lambda self, *a, **k: None
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = BDModel(o)
-    model.eval()
-    syn.fill_state_dict(model, seed=30, gain=1.0)
-    cur, src = syn.frame_tuple(1, K, Hi, Wi, seed=31, P=P)
-    mc = syn.randn((1, 16, Hi // 4, Wi // 4), 71, "mc")
-    ms = syn.randn((1, K, 16, Hi // 4, Wi // 4), 72, "ms")
-    pyr = list(syn.encoder_pyramid(1, Hi, Wi, seed=73))
-    model.compute_matching_feats = lambda *a, **k: (mc, ms)
-    model.encoder.forward = lambda x: pyr
-    out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
-    save(
-        "g5_full_bdmodel_mlp",
-        dims=np.array([K, Hi, Wi, D, P]),
-        pred_chk=chk(out["pred_0"]),
-        pred_slice=out["pred_0"][:, :, ::6, ::8],
-        lowest_chk=chk(out["lowest_cost_bhw"]),
-        lowest_slice=out["lowest_cost_bhw"][:, ::3, ::4],
-        mask_count=np.array(int(out["overall_mask_bhw"].sum().item())),
-        mask_slice=out["overall_mask_bhw"][:, ::3, ::4],
-        keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))),
-    )
+    for name, fvt, K in (("g5_full_bdmodel_mlp", "mlp_feature_volume", 7), ("g5_full_bdmodel_dot", "simple_cost_volume", 8)):
+        Hi, Wi, D, P = 384, 512, 64, 8
+        o = Options()
+        o.image_width, o.image_height = Wi, Hi
+        o.matching_num_depth_bins = D
+        o.feature_volume_type = fvt
+        o.model_num_views = K + 1
+        o.binary_loss_positive_weight = 1.0
+        o.bd_edge_regularision = False
+        o.use_prior = False
+        torch.nn.Module.save_hyperparameters = lambda self, *a, **k: None
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = BDModel(o)
+        model.eval()
+        syn.fill_state_dict(model, seed=30, gain=1.0)
+        cur, src = syn.frame_tuple(1, K, Hi, Wi, seed=31, P=P)
+        mc = syn.randn((1, 16, Hi // 4, Wi // 4), 71, "mc")
+        ms = syn.randn((1, K, 16, Hi // 4, Wi // 4), 72, "ms")
+        pyr = list(syn.encoder_pyramid(1, Hi, Wi, seed=73))
+        model.compute_matching_feats = lambda *a, **k: (mc, ms)
+        model.encoder.forward = lambda x: pyr
+        out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+        extra = {}
+        if out["overall_mask_bhw"] is not None:
+            extra = {"mask_count": np.array(int(out["overall_mask_bhw"].sum().item())), "mask_slice": out["overall_mask_bhw"][:, ::3, ::4]}
+        save(
+            name,
+            dims=np.array([K, Hi, Wi, D, P]),
+            pred_chk=chk(out["pred_0"]),
+            pred_slice=out["pred_0"][:, :, ::6, ::8],
+            lowest_chk=chk(out["lowest_cost_bhw"]),
+            lowest_slice=out["lowest_cost_bhw"][:, ::3, ::4],
+            keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))),
+            **extra,
+        )
 
 
 if __name__ == "__main__":

@@ -24,8 +24,9 @@ def test_bdmodel_golden_with_split_convs(volume, split_default):
     base.test_hot_path_reproduces_reference_bdmodel_forward(volume)
 
 
-def test_full_size_bdmodel_golden_with_split_kernels(split_everything):
-    base.test_full_size_bdmodel_forward_golden()
+@pytest.mark.parametrize("volume", ["mlp", "dot"])
+def test_full_size_bdmodel_golden_with_split_kernels(volume, split_everything):
+    base.test_full_size_bdmodel_forward_golden(volume)
 
 
 def test_full_size_temporal_golden_with_split_kernels(split_everything):
