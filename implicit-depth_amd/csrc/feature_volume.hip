@@ -144,7 +144,9 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
     const float Wf = (float)a.W, Hf = (float)a.H;
     const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
 
-    for (long long task = (long long)blockIdx.x * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
+    // XCD-aware: hardware puts workgroup b on XCD b % 8; after the remap each XCD walks a contiguous run of tasks
+    // (= a band of image rows) per round, so the taps of its 32 workgroups share that XCD's 4 MB L2
+    for (long long task = (long long)idh_xcd_remap(blockIdx.x, gridDim.x) * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
         // wave-uniform task coordinates: pin to SGPRs so the per-b constants come through the scalar cache
         const int g = __builtin_amdgcn_readfirstlane((int)(task % a.G));
         const int tile = __builtin_amdgcn_readfirstlane((int)((task / a.G) % a.tiles_per_img));
@@ -387,7 +389,9 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
     const float Wf = (float)a.W, Hf = (float)a.H;
     const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
 
-    for (long long task = (long long)blockIdx.x * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
+    // XCD-aware: hardware puts workgroup b on XCD b % 8; after the remap each XCD walks a contiguous run of tasks
+    // (= a band of image rows) per round, so the taps of its 32 workgroups share that XCD's 4 MB L2
+    for (long long task = (long long)idh_xcd_remap(blockIdx.x, gridDim.x) * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
         const int g = __builtin_amdgcn_readfirstlane((int)(task % a.G));
         const int tile = __builtin_amdgcn_readfirstlane((int)((task / a.G) % a.tiles_per_img));
         const int b = __builtin_amdgcn_readfirstlane((int)(task / ((long long)a.G * a.tiles_per_img)));
