@@ -138,3 +138,31 @@ def test_dropin_convert_with_math_selects_split_kernels_per_model():
 @pytest.mark.parametrize("shape", [(1, 16, 16, 9, 7, 1), (3, 64, 64, 33, 47, 1), (2, 112, 64, 24, 32, 1), (1, 64, 128, 31, 45, 2)])
 def test_basic_block_ragged_shapes_split(shape, split_everything):
     conv_base.test_basic_block_vs_oracle(shape)
+
+
+@pytest.mark.parametrize("math", ["fp32", "f16x3"])
+def test_batch_invariance_at_bench_size(math):
+    """Size-independent property at the bench's own size: frame i of the 32-frame batch (16-row tiles, level-grouped
+    launches, one workgroup round per layer) must equal the same frame run alone (8- / 4-row tiles, split-K on the small
+    maps) up to summation order."""
+    import argparse
+
+    from implicit_depth_amd.pipeline import HotPathWorkload
+
+    mk = lambda B: argparse.Namespace(batch=B, views=7, planes=64, height=384, width=512, volume="mlp", conv_math=math,
+                                      mlp_math="f16x3" if math == "f16x3" else "fp32")
+    big = HotPathWorkload(mk(32), torch.device("cuda:0"), 0)
+    big.step()
+    torch.cuda.synchronize()
+    ref = big.out["pred_0"]
+    low = big.out["lowest_cost_bhw"]
+    one = HotPathWorkload(mk(1), torch.device("cuda:0"), 0)
+    for i in (0, 17, 31):
+        one.d = {k: (v[i:i + 1].contiguous() if v.dim() > 0 and v.shape[0] == 32 else v) for k, v in big.d.items()}
+        one.pyr = [t[i:i + 1].contiguous() for t in big.pyr]
+        one.rd = big.rd[i:i + 1].contiguous()
+        one.step()
+        torch.cuda.synchronize()
+        a, b = one.out["pred_0"][0], ref[i]
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-5, i
+        assert ((one.out["lowest_cost_bhw"][0] - low[i]).abs() > 1e-5).float().mean().item() < 5e-3
