@@ -4,20 +4,32 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
 
 One "step" = one pass of the hot path over the GLOBAL batch of 32 synthetic frames (BASELINE.json
-configs[3]), sharded by frame over the GPUs (strong scaling: total work fixed, 32/N frames per GPU).  Inputs are generated once and are resident in HBM before the
-timed region.  For N>1 launch with torch.distributed.run (one rank per GPU, RCCL); the batch
-dimension is sharded, there is no data-path collective, and the only message is an
-all-gather of per-frame metric vectors after the timed region.
+configs[3]), sharded by frame over the GPUs (strong scaling: total work fixed, 32/N frames per GPU).
+Inputs are generated once and are resident in HBM before the timed region.  For N>1 launch with
+torch.distributed.run (one rank per GPU, RCCL); the batch dimension is sharded, there is no data-path
+collective, and the only message is an all-gather of per-frame metric vectors after the timed region
+(SURVEY.md §8e).
 
-Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-  roofline     — dominant kernel, algorithmic bytes(flops)/launch ÷ HIP-event-measured
-                 average launch time vs the gfx950 peak
-  cpu_baseline — the oracle (CPU restatement) timed on this host's cores on a bounded
-                 sample of the same workload (rank 0, N=1 only)
+Workloads
+  hot_path        (default) matching backbone's layer1 map -> encoder head -> fused volume -> CVEncoder ->
+                  UNet++ decoder -> occlusion MLP x8 query planes; 512x384, D=64, 8-frame tuples
+  warp_match_dot  BASELINE.json configs[1]: the fused warp+match kernel alone (K=8, D=64)
+  temporal        BASELINE.json configs[4]: one sequence per GPU, B=1, D=96, the previous frame's prediction
+                  carried as the prior (inference/inference.py:139-157); a step = one frame
+
+Prints ONE JSON line on rank 0 (see the driver contract) with extra objects:
+  roofline     — dominant kernel, algorithmic flops (bytes) per launch ÷ HIP-event-measured average launch
+                 time vs the gfx950 peak
+  warp_match   — the north-star kernel on its own (K=8, D=64, same per-GPU batch): achieved algorithmic GB/s
+                 and its fraction of the 8 TB/s HBM roofline (rank 0)
+  temporal     — configs[4] frames/s on one GPU (rank 0, N=1 only)
+  cpu_baseline — the oracle (CPU restatement) timed on this host's cores on a bounded sample of the same
+                 workload (rank 0, N=1 only)
 """
 from __future__ import annotations
 
 import argparse
+import copy
 import json
 import os
 import sys
@@ -35,31 +47,44 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak (no xf32/TF32 on gfx9
 MFMA_16BIT_PEAK_TFLOPS = 2500.0  # bf16 / f16 MFMA dense peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="auto", help="auto | warp_match_dot | hot_path")
+    ap.add_argument("--workload", default="hot_path", choices=["hot_path", "warp_match_dot", "temporal"])
     ap.add_argument("--batch", type=int, default=32, help="GLOBAL frames per step (BASELINE.json configs[3]: batch_size=32), sharded over the GPUs")
     ap.add_argument("--views", type=int, default=0, help="source views K; 0 = 7 for --volume mlp (reference-native 8-frame tuple = 1 cur + 7 src), 8 for --volume dot (BASELINE.json literal)")
     ap.add_argument("--volume", default="mlp", choices=["mlp", "dot"], help="mlp = FeatureVolumeManager (every shipped BDModel config), dot = CostVolumeManager")
-    ap.add_argument("--planes", type=int, default=64)
+    ap.add_argument("--planes", type=int, default=0, help="depth planes D; 0 = 64 (96 for --workload temporal)")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--no-head", action="store_true", help="start at finished matching features (round-1 workload) instead of the layer1 map")
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "bf16x6", "f16x3"],
                     help="arithmetic of the 3x3 stride-1 convs: fp32 MFMA (default) or the fp32-equivalent split-precision kernels")
     ap.add_argument("--mlp-math", default="fp32", choices=["fp32", "f16x3"], help="arithmetic of the MLP kernels (feature volume)")
     ap.add_argument("--math", default=None, choices=["fp32", "bf16x6", "f16x3"],
                     help="shorthand: sets --conv-math, and --mlp-math f16x3 when f16x3")
     ap.add_argument("--no-split-line", action="store_true", help="skip the secondary split-precision measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the warp_match / temporal objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.math is not None:
         args.conv_math = args.math
         args.mlp_math = "f16x3" if args.math == "f16x3" else "fp32"
+    if args.views == 0:
+        args.views = 7 if (args.volume == "mlp" and args.workload != "warp_match_dot") else 8
+    if args.planes == 0:
+        args.planes = 96 if args.workload == "temporal" else 64
     return args
+
+
+def shard_counts(global_batch: int, world: int):
+    """Frames per rank for a global batch sharded by frame (ragged when world does not divide it)."""
+    from implicit_depth_amd.dist import shard_range
+
+    return [shard_range(global_batch, world, r)[1] - shard_range(global_batch, world, r)[0] for r in range(world)]
 
 
 # ------------------------------------------------------------------------------------------
@@ -70,8 +95,8 @@ class WarpMatchDot:
     map, K source views, D planes, random-init N(0,1) matching features (NHWC, resident)."""
 
     name = "warp_match_dot"
-    dominant_kernel = "cv_dot_quad_k"
     bound = "hbm"
+    scaling = "strong"
 
     def __init__(self, args, device, rank):
         import implicit_depth_amd.synthetic as syn
@@ -91,12 +116,15 @@ class WarpMatchDot:
         self.cost = torch.empty(self.B, self.D, self.H, self.W, device=device)
         self.lowest = torch.empty(self.B, self.H, self.W, device=device)
         self.planes = torch.empty(self.D, device=device)
-        self.kernel_ms = []
+        self.dominant_kernel = self.L.idh_cost_volume_dot_kernel_name(self.B, self.K, self.H, self.W, self.D).decode()
 
     def config(self):
         return {"workload": f"{self.name}: fused plane-sweep warp+match, {self.W * 4}x{self.H * 4} image, matching map {self.W}x{self.H}, "
                             f"K={self.K} source views, D={self.D} planes, C=16, fp32",
                 "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D}
+
+    def metric(self):
+        return f"frames/sec (fused warp+match kernel, {self.W * 4}x{self.H * 4}, {self.D} planes, {self.K} views)"
 
     def step(self, ev=None):
         p, L = self._lib.ptr, self.L
@@ -109,12 +137,38 @@ class WarpMatchDot:
             ev[1].record()
         self._lib.check(rc, "idh_cost_volume_dot_fwd")
 
+    def frames_per_step(self):
+        return self.B
+
     def algorithmic_bytes_per_launch(self):
         # compulsory traffic per frame = every input read once + every output
         # written once = 4*[C*N + K*C*N + D*N + N] + 64*(2K+1) bytes; one launch processes B frames.
         N = self.H * self.W
         per_frame = 4 * (self.C * N + self.K * self.C * N + self.D * N + N) + 64 * (2 * self.K + 1)
         return per_frame * self.B
+
+    def kernel_roofline(self, iters=30):
+        """HIP-event timing of `iters` back-to-back launches on the launch stream -> the `warp_match` object."""
+        for _ in range(5):
+            self.step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            self.step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        alg = self.algorithmic_bytes_per_launch()
+        gbs = alg / (ms * 1e-3) / 1e9
+        out = {"kernel": self.dominant_kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+               "kernel_ms": ms, "algorithmic_bytes_per_launch": alg, "frames_per_launch": self.B, "source_views": self.K, "depth_planes": self.D,
+               "frames_per_s": self.B / (ms * 1e-3), "traffic": None,
+               "note": "achieved = compulsory bytes (every input read once, every output written once) / kernel time; the kernel is bound by "
+                       "the on-chip gather + VALU work of D*K*N*4 bilinear taps, not by HBM (DESIGN.md 4.1)"}
+        pmc = _pmc_traffic(f"warp_match_dot/b{self.B}") if (self.K, self.D) == (8, 64) else None
+        if pmc is not None and pmc.get("kernel") == self.dominant_kernel:
+            out["traffic"], out["traffic_source"] = pmc["traffic_bytes_per_launch"], "profiles/pmc_traffic.json"
+        return out
 
     def metrics(self):
         # per-frame vector that is all-gathered (stand-in for the reference's per-frame
@@ -139,29 +193,266 @@ class WarpMatchDot:
                 "sample": f"{n} frames of the same workload through oracle/cost_volume.py (torch CPU fp32), {dt:.1f} s"}
 
 
-def make_workload(args, device, rank):
-    name = args.workload
-    if name == "auto":
-        try:
-            from implicit_depth_amd import pipeline  # noqa: F401
+class HotPathWorkload:
+    """The in-scope part of BDModel.forward on synthetic ScanNet-shaped tuples — 512x384 image, matching map
+    128x96, K source views, D planes, P=8 query planes — starting at the matching backbone's layer1 map
+    (B*(K+1) images, 64 channels at 1/4 resolution).  The third-party image encoder and ResNet18 stem are replaced by
+    resident synthetic feature maps of the right shape (they are outside the hot path)."""
 
-            name = "hot_path"
-        except Exception:
-            name = "warp_match_dot"
-    if name == "warp_match_dot":
-        return WarpMatchDot(args, device, rank)
-    if name == "hot_path":
-        from implicit_depth_amd.pipeline import HotPathWorkload
+    name = "hot_path"
+    bound = "mfma"
+    scaling = "strong"
+    use_prior = False
+    P = 8
 
-        return HotPathWorkload(args, device, rank)
-    raise SystemExit(f"unknown workload {name}")
+    def __init__(self, args, device, rank):
+        import implicit_depth_amd.synthetic as syn
+        from implicit_depth_amd import networks as net
+        from implicit_depth_amd.cost_volume import CostVolumeManager, FeatureVolumeManager
+        from implicit_depth_amd.pipeline import HotPath
+
+        self.args = args
+        self.B, self.K, self.D = args.batch, args.views, args.planes
+        self.Hi, self.Wi = args.height, args.width
+        self.H, self.W, self.C = args.height // 4, args.width // 4, 16
+        self.head = not getattr(args, "no_head", False)
+        enc_ch = [24, 48, 64, 160, 256]
+        self.volume = getattr(args, "volume", "dot")
+        if self.volume == "mlp":
+            cv = FeatureVolumeManager(self.H, self.W, self.D, num_source_views=self.K)
+            syn.fill_state_dict(cv.mlp, seed=99, gain=1.4)
+        else:
+            cv = CostVolumeManager(self.H, self.W, self.D)
+        cve = net.CVEncoder(self.D, enc_ch[1:], [64, 128, 256, 384])
+        dec = net.BDDecoderPP(enc_ch[:1] + cve.num_ch_enc)
+        mlp = net.BinaryMLPNetwork(dec.num_ch_dec, mlp_size=128, use_prior=self.use_prior)
+        mm = net.ResnetMatchingEncoder([torch.nn.Identity() for _ in range(5)], self.C) if self.head else None
+        for i, m in enumerate((cve, dec, mlp) + ((mm,) if mm is not None else ())):
+            syn.fill_state_dict(m, seed=100 + i)
+        self.conv_math = getattr(args, "conv_math", "fp32")
+        self.mlp_math = getattr(args, "mlp_math", "fp32")
+        if self.volume == "mlp":
+            cv.mlp_math = self.mlp_math
+        mlp.mlp_math = self.mlp_math
+        self.model = HotPath(cv, cve, dec, mlp, conv_math=self.conv_math, matching_model=mm).to(device)
+        inp = syn.cost_volume_inputs(self.B, self.K, self.C, self.H, self.W, seed=rank)
+        self.host_inputs = inp
+        self.host_pyr = syn.encoder_pyramid(self.B, self.Hi, self.Wi, seed=rank)
+        self.host_rd = syn.rendered_depth_planes(self.B, self.Hi // 2, self.Wi // 2, self.P)
+        self.d = {k: v.to(device) for k, v in inp.items()}
+        self.pyr = [t.to(device) for t in self.host_pyr]
+        self.rd = self.host_rd.to(device)
+        self.l1 = self.host_l1 = None
+        if self.head:
+            self.host_l1 = syn.layer1_maps(self.B, self.K, self.H, self.W, seed=rank)
+            self.l1 = self.host_l1.to(device)
+        self.out = None
+
+    def config(self):
+        vol = "fused MLP feature volume (FeatureVolumeManager, implicit_depth.yaml)" if self.volume == "mlp" else "fused warp+match (dot, CostVolumeManager)"
+        start = (f"layer1 map of the matching backbone ({self.K + 1} images/frame, 64ch @ {self.W}x{self.H}, NCHW) -> matching-encoder head "
+                 "(1x1 conv, InstanceNorm, LeakyReLU, 3x3 conv, InstanceNorm; NHWC hand-off)") if self.head else "matching feats"
+        return {"workload": f"{self.name}: {start} -> {vol} -> CVEncoder -> BDDecoderPP (UNet++) -> occlusion MLP x{self.P} planes; "
+                            f"{self.Wi}x{self.Hi} image, matching map {self.W}x{self.H}, K={self.K} source views, D={self.D} planes, fp32; "
+                            "image encoder / ResNet18 stem (third-party) replaced by resident synthetic feature maps",
+                "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D, "query_planes": self.P, "volume": self.volume,
+                "matching_head_in_timed_region": self.head, "conv_math": self.conv_math, "mlp_math": self.mlp_math}
+
+    def metric(self):
+        return (f"frames/sec (BDModel.forward hot path, {self.Wi}x{self.Hi}, {self.D} planes, {self.K + 1}-frame tuple = 1 current + {self.K} "
+                f"source views; third-party backbones excluded)")
+
+    def frames_per_step(self):
+        return self.B
+
+    def _forward(self, **kw):
+        d = self.d
+        if self.head:
+            return self.model(None, None, self.pyr, d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"], rendered_depth=self.rd,
+                              matching_layer1=self.l1, **kw)
+        return self.model(d["cur_feats"], d["src_feats"], self.pyr, d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
+                          rendered_depth=self.rd, **kw)
+
+    def step(self, ev=None):
+        if ev is not None:
+            ev[0].record()
+        self.out = self._forward()
+        if ev is not None:
+            ev[1].record()
+
+    # roofline of the dominant kernel -------------------------------------------------------
+    dominant_kernel = "conv3x3_lds_k<2>"
+
+    def _replay_ms(self, ops, iters=10, batches=3):
+        """ms per pass of `ops` replayed alone between HIP events on the launch stream: median of
+        `batches` batches of `iters` passes (a single batch right after the timed loop occasionally
+        catches a clock / power-state transient: 0.74 vs 0.79 of peak for the same kernel)."""
+        import ctypes as C
+
+        from implicit_depth_amd import _lib, nhwc
+
+        arr = (nhwc.Op * len(ops))(*ops)
+        L = _lib.lib()
+        for _ in range(3):
+            _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(ops), _lib.stream_ptr()), "idh_run_ops")
+        times = []
+        for _ in range(batches):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(ops), _lib.stream_ptr()), "idh_run_ops")
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / iters)
+        return sorted(times)[len(times) // 2]
+
+    @staticmethod
+    def _conv_flops(op):
+        return sum(2 * op.N * op.Ho * op.Wo * op.Cout * s.Cin * s.ks * s.ks for s in op.src if s.in_)
+
+    def conv_only_ms(self, iters=10):
+        """HIP-event timing of (a) the launches of the dominant kernel — the 8-row LDS-staged
+        3x3 conv, one launch per op with tile code 8 — and (b) every conv op of the step, each
+        set replayed alone on the launch stream.  Returns two (ms_per_step, launches, flops)."""
+        from implicit_depth_amd import nhwc
+
+        ent = next(iter(self.model._plans.values()))
+        p = ent["plan"]
+        convs = [op for op in p.ops if op.kind == nhwc.OP_CONV]
+        dom = [op for op in convs if op.tile_m == 8]
+        if self.conv_math != "fp32":
+            dom = [op for op in convs if op.tile_m in (10, 11)]
+            self.dominant_kernel = "conv3x3_split_k<8, 1, 0, *>" if self.conv_math == "bf16x6" else "conv3x3_split_k<4, 2, 1, *>"
+        if not dom:  # small batches: every layer runs on the 4-row tile variant
+            dom = [op for op in convs if op.tile_m == 9]
+            self.dominant_kernel = "conv3x3_lds_k<1> + conv3x3_lds_group_k<1>"
+        dom_res = (self._replay_ms(dom, iters), len(dom), sum(self._conv_flops(o) for o in dom))
+        all_res = (self._replay_ms(convs, iters), len(convs), sum(self._conv_flops(o) for o in convs))
+        return dom_res, all_res
+
+    def metrics(self):
+        """Per-frame metric rows (B, 120): PlaneEvaluator IoU / IoU+ / IoU- for 5 thresholds x 8 query
+        planes against a synthetic ground-truth depth — the shape of the dict test_bd.py:288-339
+        builds per frame, computed on the GPU (csrc/metrics.hip) and then all-gathered."""
+        import implicit_depth_amd.synthetic as syn
+        from implicit_depth_amd.metrics import PlaneEvaluator, metric_rows
+
+        o = self.out
+        B, P, H, W = o["pred_0"].shape
+        gt = (1.0 + 3.5 * torch.sigmoid(syn.randn((B, 1, H, W), 7, "bench_gt"))).to(o["pred_0"].device)
+        rows, self.metric_keys = metric_rows(PlaneEvaluator().compute_batch_scores(self.rd, gt, torch.sigmoid(o["pred_0"])))
+        return rows
+
+    def cpu_baseline(self, seconds):
+        """oracle (torch CPU fp32 restatement) of the same path, one frame at a time."""
+        from oracle import cost_volume as ocv
+        from oracle import networks as onet
+
+        i = self.host_inputs
+        sd = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        w_cve, w_dec, w_mlp = sd(self.model.cost_volume_net), sd(self.model.depth_decoder), sd(self.model.binary_mlp)
+        w_mm = sd(self.model.matching_model) if self.head else None
+        n, t0 = 0, time.perf_counter()
+        ocv.FAST_GATHER = True  # time the restatement with torch's own grid_sample primitive
+        with torch.inference_mode():
+            while True:
+                cur_f, src_f = i["cur_feats"][:1], i["src_feats"][:1]
+                if self.head:
+                    f = onet.matching_head(self.host_l1[0], w_mm)[None]
+                    cur_f, src_f = f[:, 0], f[:, 1:]
+                if self.volume == "mlp":
+                    w_fv = {k: v.detach().cpu() for k, v in self.model.cost_volume.mlp.state_dict().items()}
+                    cvol = ocv.feature_volume(cur_f, src_f, i["src_extrinsics"][:1], i["src_poses"][:1], i["src_Ks"][:1],
+                                              i["cur_invK"][:1], 0.25, 5.0, self.D, w_fv)[0]
+                else:
+                    cvol, _, _ = ocv.cost_volume_dot(cur_f, src_f, i["src_extrinsics"][:1], i["src_Ks"][:1], i["cur_invK"][:1], 0.25, 5.0, self.D)
+                pyr = [t[:1] for t in self.host_pyr]
+                enc = onet.cv_encoder(cvol, pyr[1:], w_cve)
+                dec = onet.unetpp_decoder([pyr[0]] + enc, w_dec, depth_head=False)
+                prior = -torch.ones_like(self.host_rd[:1]) if self.use_prior else None
+                onet.occlusion_logits(dec["feature_s0_b1hw"], self.host_rd[:1], w_mlp, prior)
+                n += 1
+                if time.perf_counter() - t0 > seconds:
+                    break
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} frame(s) of the same workload through oracle/ (torch CPU fp32 restatement, grid_sample gather), {dt:.1f} s"}
+
+
+class TemporalWorkload(HotPathWorkload):
+    """BASELINE.json configs[4] as the reference runs it (inference/inference.py:139-157): B=1, 8-frame tuple, D=96
+    planes, prior-enabled occlusion MLP, ONE query plane at 2 m (the `plane_2.0` asset), the previous frame's
+    sigmoid(pred_0) + cam_T_world carried as the prior.  Frames of a sequence are serially dependent, so a step = one
+    frame and GPUs run independent sequences (weak scaling)."""
+
+    name = "temporal"
+    scaling = "weak"
+    use_prior = True
+    P = 1
+
+    def __init__(self, args, device, rank):
+        a = copy.copy(args)
+        a.batch = 1  # one sequence per GPU
+        super().__init__(a, device, rank)
+        import implicit_depth_amd.synthetic as syn
+
+        self.rd = torch.full((1, 1, self.Hi // 2, self.Wi // 2), 2.0, device=device)
+        self.host_rd = self.rd.cpu()
+        K0 = syn.intrinsics(self.Wi // 2, self.Hi // 2).float()
+        self.K0, self.invK0 = K0[None].to(device), torch.linalg.inv(K0)[None].to(device)
+        # camera drifts 5 cm / frame along x: the prior is re-projected with a real motion every frame
+        self.poses = []
+        for t in range(64):
+            T = torch.eye(4)
+            T[0, 3] = 0.05 * t
+            self.poses.append((T[None].to(device), torch.linalg.inv(T)[None].to(device)))  # world_T_cam, cam_T_world
+        self.t = 0
+        self.prev = None
+
+    def metric(self):
+        return (f"frames/sec (temporal BDModel.forward hot path, {self.Wi}x{self.Hi}, {self.D} planes, {self.K + 1}-frame tuple, "
+                "prior carried frame to frame, B=1 per GPU)")
+
+    def step(self, ev=None):
+        if ev is not None:
+            ev[0].record()
+        wTc, cTw = self.poses[self.t % len(self.poses)]
+        prior_inputs = None
+        if self.prev is not None:
+            prior_inputs = {"prior_prediction": self.prev[0], "prior_cam_T_world": self.prev[1], "world_T_cam_b44": wTc,
+                            "K_s0_b44": self.K0, "invK_s0_b44": self.invK0}
+        self.out = self._forward(prior_inputs=prior_inputs)
+        self.prev = (torch.sigmoid(self.out["pred_0"]), cTw)  # sigmoid_custom(x, 1.0), inference.py:154
+        self.t += 1
+        if ev is not None:
+            ev[1].record()
+
+    def metrics(self):
+        o = self.out["pred_0"]
+        return torch.stack([o.mean((1, 2, 3)), torch.sigmoid(o).mean((1, 2, 3))], 1)
+
+
+WORKLOADS = {"warp_match_dot": WarpMatchDot, "hot_path": HotPathWorkload, "temporal": TemporalWorkload}
+
+
+def _pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, tools/pmc_bench.sh):
+    PMC counters cannot be read from inside the process."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
+def _median(xs):
+    s = sorted(xs)
+    n = len(s)
+    return 0.0 if n == 0 else (s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2]))
 
 
 # ------------------------------------------------------------------------------------------
 def main():
     args = parse()
-    if args.views == 0:
-        args.views = 7 if (args.volume == "mlp" and args.workload != "warp_match_dot") else 8
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -174,18 +465,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # strong scaling: the global batch is fixed (32 ScanNet-shaped tuples) and sharded by frame
-    from implicit_depth_amd.dist import shard_range
-
     global_batch = args.batch
-    lo, hi = shard_range(global_batch, world, rank)
-    args.batch = hi - lo  # frames of THIS rank
-    counts = [shard_range(global_batch, world, r)[1] - shard_range(global_batch, world, r)[0] for r in range(world)]
+    counts = shard_counts(global_batch, world)
+    args.batch = counts[rank]  # frames of THIS rank
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun: exercise RCCL even at N=1
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
-    wl = make_workload(args, device, rank)
+    wl = WORKLOADS[args.workload](args, device, rank)
+    if wl.scaling == "weak":  # temporal: one sequence per GPU
+        counts = [wl.frames_per_step()] * world
 
     def barrier():
         if use_dist:
@@ -207,29 +497,30 @@ def main():
             barrier()
             el = time.perf_counter() - t0
             torch.cuda.synchronize()
-        k_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
+        per_step = [a.elapsed_time(b) for a, b in evs]
         t = torch.tensor([el], device=device, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.item(), k_ms
+        return t.item(), per_step
 
-    elapsed, kernel_ms = timed(wl)
+    elapsed, per_step = timed(wl)
+    kernel_ms = sum(per_step) / max(len(per_step), 1)
+    frames_per_step_total = sum(counts)
 
     # Secondary line (same run, same inputs and weights): the hot path with the fp32-equivalent
     # split-precision kernels (f16x3 convs + MLPs).  `value` above stays the fp32-MFMA path.
     split = None
     if wl.name == "hot_path" and args.conv_math == "fp32" and args.mlp_math == "fp32" and not args.no_split_line:
-        import copy
-
         a2 = copy.copy(args)
         a2.conv_math, a2.mlp_math = "f16x3", "f16x3"
-        wl2 = make_workload(a2, device, rank)
+        wl2 = HotPathWorkload(a2, device, rank)
         el2, _ = timed(wl2)
         ref_o, got_o = wl.out["pred_0"], wl2.out["pred_0"]
-        split = {"math": "f16x3", "value": global_batch * args.steps / el2, "unit": "frames/s", "ms_per_step": el2 / args.steps * 1e3,
+        split = {"math": "f16x3", "value": frames_per_step_total * args.steps / el2, "unit": "frames/s", "ms_per_step": el2 / args.steps * 1e3,
                  "max_abs_diff_vs_fp32_path_over_max_abs": float((ref_o - got_o).abs().max() / ref_o.abs().max()),
-                 "note": "3x3 convs, feature-volume MLP and BinaryMLP on the f16 matrix cores: fp32 operands split into two power-of-two-scaled "
-                         "f16 pieces, 3 products, fp32 accumulate; same goldens / tolerances as the fp32-MFMA path (tests/test_*split*_gpu.py)"}
+                 "note": "NOT the headline: 3x3 convs, feature-volume MLP and BinaryMLP on the f16 matrix cores with fp32 operands split into two "
+                         "power-of-two-scaled f16 pieces, 3 products, fp32 accumulate (narrower operand arithmetic than the reference's fp32); same "
+                         "goldens / tolerances as the fp32-MFMA path (tests/test_*split*_gpu.py)"}
         del wl2
         torch.cuda.empty_cache()
 
@@ -237,7 +528,7 @@ def main():
     from implicit_depth_amd.dist import all_gather_metrics
 
     m = all_gather_metrics(wl.metrics().float().contiguous(), counts=counts)
-    frames_total = global_batch * args.steps
+    frames_total = frames_per_step_total * args.steps
 
     if rank == 0:
         if wl.bound == "hbm":
@@ -246,7 +537,7 @@ def main():
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None, "kernel": wl.dominant_kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": rl_alg}
         else:
-            # dominant kernel = conv3x3_lds_k<2> (8-row LDS-staged 3x3 conv, ~1/3 of a step): replay
+            # dominant kernel = conv3x3_lds_k<2> (8-row LDS-staged 3x3 conv, ~2/3 of a step): replay
             # ONLY its launches between two HIP events on the launch stream; the same for all conv
             # launches of the step as a secondary figure
             (dom_ms, dom_n, dom_fl), (all_ms, all_n, all_fl) = wl.conv_only_ms()
@@ -264,39 +555,61 @@ def main():
             if math != "fp32":
                 roof["peak_note"] = (f"fp32-equivalent flops; peak = {MFMA_16BIT_PEAK_TFLOPS:.0f} TFLOP/s dense 16-bit MFMA / "
                                      f"{6 if math == 'bf16x6' else 3} products per MAC; the fp32-MFMA peak is 157.3")
-        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the
-        # process, so the figure comes from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/pmc_traffic.json, tools/pmc_bench.sh) when the configuration matches, else null.
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = f"{wl.name}/{getattr(wl, 'volume', 'dot')}/b{wl.B}" if wl.name == "hot_path" else f"{wl.name}/b{wl.B}"
-            if getattr(wl, "conv_math", "fp32") != "fp32":
-                key += "/" + wl.conv_math
-            if key in pmc and (wl.name != "warp_match_dot" or (wl.K, wl.D) == (8, 64)):
-                roof["traffic"] = pmc[key]["traffic_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/pmc_traffic.json"
-        except Exception:
-            pass
+        key = f"{wl.name}/{getattr(wl, 'volume', 'dot')}/b{wl.B}" if wl.name != "warp_match_dot" else f"{wl.name}/b{wl.B}"
+        if getattr(wl, "conv_math", "fp32") != "fp32":
+            key += "/" + wl.conv_math
+        pmc = _pmc_traffic(key)
+        if pmc is not None and pmc.get("kernel") == wl.dominant_kernel and (wl.name != "warp_match_dot" or (wl.K, wl.D) == (8, 64)):
+            roof["traffic"] = pmc["traffic_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/pmc_traffic.json"
         out = {
-            "metric": "frames/sec (BDModel.forward, 512x384, 64 planes, 8 views)",
+            "metric": wl.metric(),
             "value": frames_total / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median_hip_events": _median(per_step),
+            "ms_per_step_min_hip_events": min(per_step) if per_step else 0.0,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": wl.scaling,
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x6": "f32 (3x3 convs: bf16x3-split operands, 6 products, f32 accumulate)",
                       "f16x3": "f32 (3x3 convs: scaled f16x2-split operands, 3 products, f32 accumulate)"}[getattr(wl, "conv_math", "fp32")],
             "data": "synthetic",
-            "config": dict(wl.config(), global_batch=global_batch),
+            "config": dict(wl.config(), global_batch=frames_per_step_total),
             "roofline": roof,
             "gathered_metric_rows": int(m.shape[0]),
         }
         if split is not None:
             out["split_precision"] = split
+        if wl.name == "hot_path" and not args.no_extras:
+            # the north-star kernel on its own, same per-GPU batch (BASELINE.json configs[1]: K=8, D=64)
+            a3 = copy.copy(args)
+            a3.views, a3.planes = 8, 64
+            with torch.inference_mode():
+                out["warp_match"] = WarpMatchDot(a3, device, rank).kernel_roofline()
+            torch.cuda.empty_cache()
+            if world == 1:  # BASELINE.json configs[4]: the temporal loop, B=1, D=96, prior carried over 48 frames
+                a4 = copy.copy(args)
+                a4.planes, a4.views, a4.volume = 96, 7, "mlp"
+                tw = TemporalWorkload(a4, device, rank)
+                with torch.inference_mode():
+                    for _ in range(8):
+                        tw.step()
+                    torch.cuda.synchronize()
+                    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(48)]
+                    t0 = time.perf_counter()
+                    for e in evs:
+                        tw.step(e)
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t0
+                ts = [a.elapsed_time(b) for a, b in evs]
+                out["temporal"] = {"value": len(evs) / el, "unit": "frames/s", "frames": len(evs), "ms_per_frame_median_hip_events": _median(ts),
+                                   "config": tw.config()["workload"]}
+                del tw
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -25,6 +25,14 @@ class IdhError(RuntimeError):
     pass
 
 
+class VolumeOpts(C.Structure):
+    """ctypes mirror of ``idh_volume_opts`` (include/idh.h)."""
+
+    _fields_ = [("cur_batch_stride", C.c_int64), ("src_batch_stride", C.c_int64), ("planes", C.c_void_p),
+                ("planes_batch_stride", C.c_int64), ("planes_plane_stride", C.c_int64), ("planes_pixel_stride", C.c_int32),
+                ("_reserved", C.c_int32)]
+
+
 _SIGS = {
     "idh_version": (C.c_int, []),
     "idh_error_string": (C.c_char_p, [C.c_int]),
@@ -49,6 +57,16 @@ _SIGS = {
         C.c_int,
         [f32p] * 6 + [C.c_float, C.c_float] + [C.c_int] * 6 + [f32p] * 6 + [f32p, C.c_int, f32p, C.c_void_p, f32p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "idh_feature_volume_ex_fwd": (
+        C.c_int,
+        [f32p] * 6 + [C.c_float, C.c_float] + [C.c_int] * 6 + [f32p] * 6 + [f32p, C.c_int, f32p, C.c_void_p, f32p, C.c_void_p, C.c_size_t,
+                                                                  C.c_int, C.POINTER(VolumeOpts), C.c_void_p],
+    ),
+    "idh_cost_volume_dot_ex_fwd": (
+        C.c_int,
+        [f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_float] + [C.c_int] * 6 + [f32p, C.c_int, f32p, f32p, C.POINTER(VolumeOpts), C.c_void_p],
+    ),
+    "idh_cost_volume_dot_kernel_name": (C.c_char_p, [C.c_int] * 5),
     "idh_packed_mlp_weight_f16_bytes": (C.c_size_t, [C.c_int]),
     "idh_pack_mlp_weight_f16": (C.c_int, [f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idh_binary_mlp_search_fwd": (C.c_int, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int,

@@ -9,7 +9,6 @@ torch is only used to own device memory and the stream.
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
@@ -46,6 +45,36 @@ def to_nchw(x_nhwc: Tensor) -> Tensor:
     return out
 
 
+def _is_device_scalar(v) -> bool:
+    return torch.is_tensor(v) and v.is_cuda
+
+
+def volume_opts(B, K, C, H, W, D, planes_bdhw: Optional[Tensor] = None, cur_batch_stride: int = 0, src_batch_stride: int = 0):
+    """``idh_volume_opts`` for one launch -> (ctypes struct or None, keep-alive list).  ``planes_bdhw`` is the
+    reference's ``depth_planes_bdhw`` (modules/cost_volume.py:324-347): any (B,D,H,W) fp32 device tensor; views
+    that are constant over the image (``expand()``ed (B,D,1,1) / (1,D,1,1), what generate_depth_planes returns)
+    are passed by stride, anything else as a dense per-pixel map."""
+    if planes_bdhw is None and not cur_batch_stride and not src_batch_stride:
+        return None, []
+    o = _lib.VolumeOpts()
+    o.cur_batch_stride, o.src_batch_stride = int(cur_batch_stride), int(src_batch_stride)
+    keep = []
+    if planes_bdhw is not None:
+        pl = planes_bdhw
+        _lib.require_cuda_f32(pl)
+        if pl.dim() != 4 or pl.shape[1] != D or pl.shape[0] not in (1, B) or tuple(pl.shape[2:]) not in ((H, W), (1, 1)):
+            raise ValueError(f"depth_planes_bdhw has shape {tuple(pl.shape)}, expected ({B},{D},{H},{W})")
+        const_over_image = tuple(pl.shape[2:]) == (1, 1) or (pl.stride(2) == 0 and pl.stride(3) == 0)
+        if const_over_image:
+            sb = pl.stride(0) if pl.shape[0] == B and B > 1 else 0
+            o.planes, o.planes_batch_stride, o.planes_plane_stride, o.planes_pixel_stride = pl.data_ptr(), sb, pl.stride(1), 0
+        else:
+            pl = pl.expand(B, D, H, W).contiguous()
+            o.planes, o.planes_batch_stride, o.planes_plane_stride, o.planes_pixel_stride = pl.data_ptr(), D * H * W, H * W, 1
+        keep.append(pl)
+    return o, keep
+
+
 class CostVolumeManager(nn.Module):
     """Dot-product plane-sweep cost volume (reference modules/cost_volume.py:17-366)."""
 
@@ -74,13 +103,24 @@ class CostVolumeManager(nn.Module):
         planes = torch.exp(torch.log(min_depth) + torch.log(max_depth / min_depth) * ramp)
         return planes.expand(batch_size, self.num_depth_bins, self.matching_height, self.matching_width)
 
+    def _planes_arg(self, B, min_depth, max_depth, depth_planes_bdhw):
+        """How the planes reach the kernel: caller-supplied planes and device-resident min/max depth
+        tensors (what BDModel.forward passes, bd_model.py:226-229) go in as a device array — computed with the
+        reference's own formula, no device->host read; plain numbers are expanded in the kernel.
+        Returns (planes tensor or None, dmin, dmax)."""
+        if depth_planes_bdhw is not None:
+            return depth_planes_bdhw, 1.0, 1.0
+        if _is_device_scalar(min_depth) or _is_device_scalar(max_depth):
+            dev = self.linear_ramp_1d11.device
+            as_t = lambda v: (v if torch.is_tensor(v) else torch.tensor(float(v))).to(device=dev, dtype=torch.float32)
+            return self.generate_depth_planes(B, as_t(min_depth), as_t(max_depth)), 1.0, 1.0
+        return None, float(min_depth), float(max_depth)
+
     def build_cost_volume(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
                           depth_planes_bdhw=None, return_mask=False, cur_feats_nhwc=None, src_feats_nhwc=None):
         """Returns (cost_volume B,D,H,W ; depth_planes view ; None) like reference :221-317,
         plus the arg-max depth as a 4th element (the kernel produces it in the same pass)."""
         del src_poses, return_mask  # unused by the dot-product volume, as in the reference (:270)
-        if depth_planes_bdhw is not None:
-            raise _lib.IdhError("caller-supplied depth_planes_bdhw is not supported by the fused kernel (planes are log-spaced from min/max depth)")
         B, K, C, H, W = self._check(cur_feats, src_feats)
         D = self.num_depth_bins
         _lib.require_cuda_f32(cur_feats, src_feats, src_extrinsics, src_Ks, cur_invK)
@@ -90,19 +130,21 @@ class CostVolumeManager(nn.Module):
         cost = torch.empty(B, D, H, W, device=dev, dtype=torch.float32)
         lowest = torch.empty(B, H, W, device=dev, dtype=torch.float32)
         L = _lib.lib()
-        planes_d = torch.empty(D, device=dev, dtype=torch.float32)
-        dmin, dmax = float(min_depth), float(max_depth)
+        planes_t, dmin, dmax = self._planes_arg(B, min_depth, max_depth, depth_planes_bdhw)
+        opts, keep = volume_opts(B, K, C, H, W, D, planes_t)
+        planes_d = torch.empty(D, device=dev, dtype=torch.float32) if planes_t is None else None
         # keep the contiguous copies alive until the launch is enqueued (a temporary's block may be
         # recycled by the next .contiguous() before the kernel runs)
         Ks_c, E_c, iK_c = src_Ks.contiguous(), src_extrinsics.contiguous(), cur_invK.contiguous()
         _lib.check(
-            L.idh_cost_volume_dot_fwd(
+            L.idh_cost_volume_dot_ex_fwd(
                 _lib.ptr(cur_n), _lib.ptr(src_n), _lib.ptr(Ks_c), _lib.ptr(E_c),
                 _lib.ptr(iK_c), dmin, dmax, B, K, C, H, W, D, _lib.ptr(cost), 0, _lib.ptr(lowest),
-                _lib.ptr(planes_d), _lib.stream_ptr()),
-            "idh_cost_volume_dot_fwd",
+                _lib.ptr(planes_d), opts, _lib.stream_ptr()),
+            "idh_cost_volume_dot_ex_fwd",
         )
-        planes = planes_d.view(1, D, 1, 1).expand(B, D, H, W)
+        del keep
+        planes = planes_t.expand(B, D, H, W) if planes_t is not None else planes_d.view(1, D, 1, 1).expand(B, D, H, W)
         return cost, planes, None, lowest
 
     def forward(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
@@ -164,7 +206,7 @@ def feature_mlp_column_maps(K: int, C: int = 16):
 # Arithmetic of the MLP kernels (feature volume, BinaryMLP): "fp32" = v_mfma_f32_16x16x4_f32 (default),
 # "f16x3" = split precision on the f16 matrix cores (csrc/feature_volume.hip, fp32-equivalent results).
 MLP_MATH_MODES = ("fp32", "f16x3")
-DEFAULT_MLP_MATH = os.environ.get("IDH_MLP_MATH", "fp32")
+DEFAULT_MLP_MATH = "fp32"  # process-wide default; per-module: the ``mlp_math`` attribute (dropin.convert(model, math=...))
 
 
 class FeatureVolumeManager(CostVolumeManager):
@@ -230,53 +272,57 @@ class FeatureVolumeManager(CostVolumeManager):
         self.__dict__["_idh_fv"] = (key, out)
         return out
 
-    def _run(self, cur_n, src_n, src_extrinsics, src_poses, src_Ks, cur_invK, dmin, dmax, vol, vol_cs, want_mask):
-        B, K, H, W, C = src_n.shape
+    def _run(self, cur_ptr, src_ptr, dims, src_extrinsics, src_poses, src_Ks, cur_invK, dmin, dmax, vol_ptr, vol_cs, want_mask, dev,
+             planes_t=None, cur_batch_stride=0, src_batch_stride=0, scratch=None):
+        """One launch of the fused kernel.  ``scratch``: a dict the caller keeps between calls (HotPath's plan
+        state) so the outputs / workspace are allocated once per shape instead of once per step."""
+        B, K, C, H, W = dims
         if K != self.num_source_views:
             raise _lib.IdhError(f"FeatureVolumeManager was built for {self.num_source_views} source views, got {K} (the MLP input width is fixed)")
-        dev = cur_n.device
         pk = self._packed()
         L = _lib.lib()
         D = self.num_depth_bins
+        sc = scratch if scratch is not None else {}
+        key = ("fv", B, H, W, D, str(dev))
+        if sc.get("fv_key") != key:
+            wsb = L.idh_feature_volume_workspace_bytes(B)
+            sc.update(fv_key=key, fv_wsb=wsb, fv_ws=torch.empty(max(wsb // 4, 1), device=dev), fv_planes=torch.empty(D, device=dev))
         lowest = torch.empty(B, H, W, device=dev)
-        planes = torch.empty(D, device=dev)
-        mask = torch.empty(B, H, W, device=dev, dtype=torch.uint8) if want_mask else None
-        wsb = L.idh_feature_volume_workspace_bytes(B)
-        ws = torch.empty(max(wsb // 4, 1), device=dev)
-        Ks_c, E_c, P_c, iK_c = src_Ks.contiguous(), src_extrinsics.contiguous(), src_poses.contiguous(), cur_invK.contiguous()
-        fwd = L.idh_feature_volume_f16x3_fwd if pk["math"] == "f16x3" else L.idh_feature_volume_fwd
+        mask = torch.empty(B, H, W, device=dev, dtype=torch.bool) if want_mask else None  # the kernel writes 0/1 bytes
+        planes = sc["fv_planes"] if planes_t is None else None
+        opts, keep = volume_opts(B, K, C, H, W, D, planes_t, cur_batch_stride, src_batch_stride)
+        mats = [t if t.is_contiguous() else t.contiguous() for t in (src_Ks, src_extrinsics, src_poses, cur_invK)]  # alive until enqueued
         _lib.check(
-            fwd(cur_n.data_ptr(), src_n.data_ptr(), Ks_c.data_ptr(), E_c.data_ptr(),
-                                     P_c.data_ptr(), iK_c.data_ptr(), dmin, dmax, B, K, C, H, W, D,
-                                     pk["w1v"].data_ptr(), pk["w1p"].data_ptr(), pk["pose"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(),
-                                     pk["vecs"].data_ptr(), vol.data_ptr() if torch.is_tensor(vol) else vol, vol_cs, lowest.data_ptr(),
-                                     _lib.ptr(mask), planes.data_ptr(), ws.data_ptr(), wsb, _lib.stream_ptr()),
-            "idh_feature_volume_fwd")
-        return lowest, planes, (mask.bool() if mask is not None else None)
+            L.idh_feature_volume_ex_fwd(cur_ptr, src_ptr, mats[0].data_ptr(), mats[1].data_ptr(), mats[2].data_ptr(), mats[3].data_ptr(),
+                                        dmin, dmax, B, K, C, H, W, D,
+                                        pk["w1v"].data_ptr(), pk["w1p"].data_ptr(), pk["pose"].data_ptr(), pk["b1"].data_ptr(), pk["w2"].data_ptr(),
+                                        pk["vecs"].data_ptr(), vol_ptr, vol_cs, lowest.data_ptr(),
+                                        _lib.ptr(mask), _lib.ptr(planes), sc["fv_ws"].data_ptr(), sc["fv_wsb"], int(pk["math"] == "f16x3"), opts,
+                                        _lib.stream_ptr()),
+            "idh_feature_volume_ex_fwd")
+        del keep
+        return lowest, planes, mask
 
     def build_cost_volume(self, cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, min_depth, max_depth,
                           depth_planes_bdhw=None, return_mask=False, cur_feats_nhwc=None, src_feats_nhwc=None):
-        if depth_planes_bdhw is not None:
-            raise _lib.IdhError("caller-supplied depth_planes_bdhw is not supported by the fused kernel")
         B, K, C, H, W = self._check(cur_feats, src_feats)
         _lib.require_cuda_f32(cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK)
         cur_n = cur_feats_nhwc if cur_feats_nhwc is not None else to_nhwc(cur_feats)
         src_n = src_feats_nhwc if src_feats_nhwc is not None else to_nhwc(src_feats)
         D = self.num_depth_bins
         vol = torch.empty(B, D, H, W, device=cur_feats.device)
-        lowest, planes, mask = self._run(cur_n, src_n, src_extrinsics, src_poses, src_Ks, cur_invK, float(min_depth), float(max_depth), vol, 0, return_mask)
-        return vol, planes.view(1, D, 1, 1).expand(B, D, H, W), mask, lowest
+        planes_t, dmin, dmax = self._planes_arg(B, min_depth, max_depth, depth_planes_bdhw)
+        lowest, planes, mask = self._run(cur_n.data_ptr(), src_n.data_ptr(), (B, K, C, H, W), src_extrinsics, src_poses, src_Ks, cur_invK,
+                                         dmin, dmax, vol.data_ptr(), 0, return_mask, cur_feats.device, planes_t=planes_t)
+        planes_v = planes_t.expand(B, D, H, W) if planes_t is not None else planes.clone().view(1, D, 1, 1).expand(B, D, H, W)
+        return vol, planes_v, mask, lowest
 
-    def fused_into(self, cv_in, state, matching_cur_feats, matching_src_feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK,
-                   dmin, dmax, return_mask):
-        """Pipeline entry: writes the volume NHWC into the CVEncoder's input buffer."""
-        B, K, C, H, W = matching_src_feats.shape
-        L, sp = _lib.lib(), _lib.stream_ptr()
-        mc, ms = matching_cur_feats.contiguous(), matching_src_feats.contiguous()
-        _lib.check(L.idh_nchw_to_nhwc_f32(mc.data_ptr(), state["cur_n"].data_ptr(), B, C, H * W, sp), "idh_nchw_to_nhwc_f32")
-        _lib.check(L.idh_nchw_to_nhwc_f32(ms.data_ptr(), state["src_n"].data_ptr(), B * K, C, H * W, sp), "idh_nchw_to_nhwc_f32")
-        lowest, planes, mask = self._run(state["cur_n"], state["src_n"], src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK, dmin, dmax,
-                                         cv_in.ptr, cv_in.cs, return_mask)
+    def fused_into(self, cv_in, state, feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK, dmin, dmax, return_mask):
+        """Pipeline entry: writes the volume NHWC into the CVEncoder's input buffer.  ``feats`` =
+        (cur pointer, src pointer, (B,K,C,H,W), cur batch stride, src batch stride) of NHWC matching features."""
+        cur_ptr, src_ptr, dims, cbs, sbs = feats
+        lowest, _, mask = self._run(cur_ptr, src_ptr, dims, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK, dmin, dmax,
+                                    cv_in.ptr, cv_in.cs, return_mask, cv_in.buf.device, cur_batch_stride=cbs, src_batch_stride=sbs, scratch=state)
         return lowest, mask
 
 

@@ -492,12 +492,12 @@ int launch_one(const ConvArgs &a, int N, hipStream_t st) {
 template <int WAVES, int G, int MODE, bool SRC2>
 int launch_one_src(const ConvArgs &a, int N, hipStream_t st) {
     constexpr int kRows = 2 * G * WAVES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static IdhDeviceOnce attr_done;
+    if (attr_done.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_k<WAVES, G, MODE, SRC2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_of(MODE, kRows)) != hipSuccess)
             return IDH_ELAUNCH;
-        attr_done = true;
+        attr_done.mark();
     }
     const int tiles_x = (a.Wo + kSplitTile - 1) / kSplitTile, tiles_y = (a.Ho + kRows - 1) / kRows;
     const long long blocks = (long long)N * tiles_x * tiles_y * a.NT;

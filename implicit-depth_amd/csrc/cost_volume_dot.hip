@@ -30,6 +30,14 @@ constexpr int kTilePx = 32;
 constexpr int kGroups = 8;
 constexpr int kMaxPlanes = 512;
 
+// strides / caller-supplied planes (idh_volume_opts resolved to concrete values by the launcher)
+struct CvExt {
+    const float *planes;          // null: log-spaced planes from dmin/dmax (s_planes)
+    long long planes_sb, planes_sd;
+    int planes_sp;                // 0: planes constant over the image, 1: per-pixel (B,D,H,W)
+    long long cur_bs, src_bs;     // floats between consecutive batch elements
+};
+
 // ---- per-workgroup prologue: homographies + depth planes into LDS ------------------------
 // One thread per source view builds the 3x4 map  [M | t] = [P[:3,:3] invK[:3,:3] | P[:3,3]],
 // P = K_src E (geometry_utils.py:82); ~100 flops per view, redundant per workgroup but it
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
                                                 int cost_cs,                     // 0: (B,D,N) planes; >0: NHWC, floats per pixel
                                                 float *__restrict__ cost,
                                                 float *__restrict__ lowest,      // B,N or null
-                                                float *__restrict__ planes_out) {  // D or null
+                                                float *__restrict__ planes_out,  // D or null
+                                                const CvExt ext) {
     __shared__ float s_planes[kMaxPlanes];
     __shared__ __attribute__((aligned(16))) float s_h[IDH_MAX_SOURCE_VIEWS][12];
     __shared__ float s_best[kGroups][kTilePx];
@@ -115,7 +124,8 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
     const int y = p / W, x = p - y * W;
     const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
 
-    const float4 *cp = reinterpret_cast<const float4 *>(cur + ((size_t)b * N + p) * kC);
+    const float4 *cp = reinterpret_cast<const float4 *>(cur + (size_t)b * ext.cur_bs + (size_t)p * kC);
+    const float *pl = ext.planes ? ext.planes + (size_t)b * ext.planes_sb + (size_t)p * ext.planes_sp : nullptr;
     const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
 
     const int DP = (D + kGroups - 1) / kGroups;
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
     float ob0 = 0.f, ob1 = 0.f, ob2 = 0.f, ob3 = 0.f;
     const bool vec_ok = cost_cs > 0 && ((d0 & 3) == 0) && ((cost_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(cost) & 15) == 0);
     for (int d = d0; d < d1; ++d) {
-        const float depth = s_planes[d];
+        const float depth = pl ? pl[(size_t)d * ext.planes_sd] : s_planes[d];
         float acc = 0.f;
         for (int k = 0; k < K; ++k) {
             const float *hm = s_h[k];  // same address in every lane: LDS broadcast read
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
             const float wy1 = (y0 + 1 < H) ? fy : 0.f;
             const int xa0 = min(max(x0, 0), W - 1), xa1 = min(x0 + 1, W - 1);
             const int ya0 = min(max(y0, 0), H - 1), ya1 = min(y0 + 1, H - 1);
-            const float *sb = src + (size_t)(b * K + k) * N * kC;
+            const float *sb = src + (size_t)b * ext.src_bs + (size_t)k * N * kC;
             const float t00 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya0 * W + xa0) * kC));
             const float t01 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya0 * W + xa1) * kC));
             const float t10 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya1 * W + xa0) * kC));
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
             const float v = s_best[j][px];
             if (v > bv) { bv = v; bi = s_bidx[j][px]; }  // strict: first maximum wins
         }
-        lowest[(size_t)b * N + p] = s_planes[bi];
+        lowest[(size_t)b * N + p] = pl ? pl[(size_t)bi * ext.planes_sd] : s_planes[bi];
     }
 }
 
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void cv_dot_quad_k(const float *__restrict__ c
                                                      const float *__restrict__ cur_invK, float dmin, float dmax, int B, int K,
                                                      int H, int W, int D, int tiles_per_img, int cost_cs,
                                                      float *__restrict__ cost, float *__restrict__ lowest,
-                                                     float *__restrict__ planes_out) {
+                                                     float *__restrict__ planes_out, const CvExt ext) {
     __shared__ float s_planes[kMaxPlanes];
     __shared__ __attribute__((aligned(16))) float s_h[IDH_MAX_SOURCE_VIEWS][12];
     __shared__ float s_best[16][4];
@@ -244,14 +254,15 @@ __global__ __launch_bounds__(256) void cv_dot_quad_k(const float *__restrict__ c
     const int p = live ? p_raw : N - 1;
     const int y = p / W, x = p - y * W;
     const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
-    const float4 cq = *reinterpret_cast<const float4 *>(cur + ((size_t)b * N + p) * kC + 4 * q);
+    const float4 cq = *reinterpret_cast<const float4 *>(cur + (size_t)b * ext.cur_bs + (size_t)p * kC + 4 * q);
+    const float *pl = ext.planes ? ext.planes + (size_t)b * ext.planes_sb + (size_t)p * ext.planes_sp : nullptr;
     const float Wf = (float)W, Hf = (float)H;
 
     float best = -INFINITY;
     int bidx = 0;
     for (int dbase = 4 * pg; dbase < D; dbase += 64) {  // this quad's planes dbase .. dbase+3
         const int dmine = min(dbase + q, D - 1);       // the plane this lane projects
-        const float depth = s_planes[dmine];
+        const float depth = pl ? pl[(size_t)dmine * ext.planes_sd] : s_planes[dmine];
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
         for (int k = 0; k < K; ++k) {
             const float *hm = s_h[k];
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(256) void cv_dot_quad_k(const float *__restrict__ c
             // own sample: four tap weights and four element offsets (32-bit: B*K*N*16 < 2^31 is checked on the host)
             const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
             const int o00 = (ya0 * W + xa0) * kC, o01 = (ya0 * W + xa1) * kC, o10 = (ya1 * W + xa0) * kC, o11 = (ya1 * W + xa1) * kC;
-            const float *sb = src + (size_t)(b * K + k) * N * kC + 4 * q;
+            const float *sb = src + (size_t)b * ext.src_bs + (size_t)k * N * kC + 4 * q;
             // round j: every lane of the quad works on plane dbase + j with lane j's geometry
 #define IDH_QUAD_ROUND(CTRL, ACC)                                                                                      \
     {                                                                                                                  \
@@ -337,37 +348,73 @@ __global__ __launch_bounds__(256) void cv_dot_quad_k(const float *__restrict__ c
                 const int i = s_bidx[j][px2];
                 if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
             }
-            lowest[(size_t)b * N + pp] = s_planes[bi];
+            lowest[(size_t)b * N + pp] = ext.planes ? ext.planes[(size_t)b * ext.planes_sb + (size_t)pp * ext.planes_sp + (size_t)bi * ext.planes_sd]
+                                                    : s_planes[bi];
         }
     }
 }
 
 }  // namespace
 
-extern "C" int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
-                                       const float *src_E_44, const float *cur_invK_44, float dmin,
-                                       float dmax, int B, int K, int C, int H, int W, int D,
-                                       float *cost, int cost_nhwc_cs, float *lowest_bhw, float *planes_d,
-                                       void *stream) {
-    if (B < 0 || K < 0 || H <= 0 || W <= 0 || D <= 0 || !(dmin > 0.f) || !(dmax > 0.f)) return IDH_EINVAL;
+static int cv_resolve_ext(const idh_volume_opts *o, int K, int H, int W, CvExt *e) {
+    const long long N = (long long)H * W;
+    e->planes = nullptr; e->planes_sb = e->planes_sd = 0; e->planes_sp = 0;
+    e->cur_bs = N * kC; e->src_bs = (long long)K * N * kC;
+    if (!o) return IDH_OK;
+    if (o->cur_batch_stride) e->cur_bs = o->cur_batch_stride;
+    if (o->src_batch_stride) e->src_bs = o->src_batch_stride;
+    if (e->cur_bs < N * kC || e->src_bs < (long long)K * N * kC || (e->cur_bs & 3) || (e->src_bs & 3)) return IDH_EINVAL;
+    if (o->planes) {
+        if (o->planes_pixel_stride != 0 && o->planes_pixel_stride != 1) return IDH_EINVAL;
+        e->planes = o->planes; e->planes_sb = o->planes_batch_stride; e->planes_sd = o->planes_plane_stride;
+        e->planes_sp = o->planes_pixel_stride;
+    }
+    return IDH_OK;
+}
+
+extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                                          const float *src_E_44, const float *cur_invK_44, float dmin,
+                                          float dmax, int B, int K, int C, int H, int W, int D,
+                                          float *cost, int cost_nhwc_cs, float *lowest_bhw, float *planes_d,
+                                          const idh_volume_opts *opts, void *stream) {
+    const bool own_planes = opts && opts->planes;
+    if (B < 0 || K < 0 || H <= 0 || W <= 0 || D <= 0) return IDH_EINVAL;
+    if (!own_planes && (!(dmin > 0.f) || !(dmax > 0.f))) return IDH_EINVAL;
     if (C != kC || D > kMaxPlanes || K > IDH_MAX_SOURCE_VIEWS) return IDH_EUNSUPPORTED;
     if (B == 0) return IDH_OK;
     if (cost_nhwc_cs != 0 && cost_nhwc_cs < D) return IDH_EINVAL;
     if (!cur_nhwc || !cost || !cur_invK_44 || (K > 0 && (!src_nhwc || !src_K_44 || !src_E_44)))
         return IDH_EINVAL;
-    static const int force = getenv("IDH_CV_DOT_KERNEL") ? atoi(getenv("IDH_CV_DOT_KERNEL")) : 0;  // 1 = one lane per tap, 2 = quad
-    const bool quad_ok = (long long)B * K * H * W * kC < (1ll << 31) && K > 0;
-    if (quad_ok && force != 1) {  // default: 1.4-1.7x faster than the one-lane-per-tap kernel at every batch size measured
+    CvExt ext;
+    if (int rc = cv_resolve_ext(opts, K, H, W, &ext)) return rc;
+    if (own_planes) { planes_d = nullptr; dmin = dmax = 1.f; }
+    const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;  // 32-bit tap offsets within one (b,k) image
+    if (quad_ok) {  // default: 1.4-1.7x faster than the one-lane-per-tap kernel at every batch size measured
         const int tiles4 = idh_cdiv((long long)H * W, 4);
         hipLaunchKernelGGL(cv_dot_quad_k, dim3((unsigned)(B * tiles4)), dim3(256), 0, idh_stream(stream), cur_nhwc, src_nhwc, src_K_44,
-                           src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles4, cost_nhwc_cs, cost, lowest_bhw, planes_d);
+                           src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles4, cost_nhwc_cs, cost, lowest_bhw, planes_d, ext);
         IDH_CHECK_LAUNCH();
         return IDH_OK;
     }
     const int tiles = idh_cdiv((long long)H * W, kTilePx);
     hipLaunchKernelGGL(cv_dot_k, dim3((unsigned)(B * tiles)), dim3(256), 0, idh_stream(stream), cur_nhwc,
                        src_nhwc, src_K_44, src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles, cost_nhwc_cs,
-                       cost, lowest_bhw, planes_d);
+                       cost, lowest_bhw, planes_d, ext);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
+}
+
+extern "C" const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D) {
+    (void)B; (void)D;
+    const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;
+    return quad_ok ? "cv_dot_quad_k" : "cv_dot_k";
+}
+
+extern "C" int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                                       const float *src_E_44, const float *cur_invK_44, float dmin,
+                                       float dmax, int B, int K, int C, int H, int W, int D,
+                                       float *cost, int cost_nhwc_cs, float *lowest_bhw, float *planes_d,
+                                       void *stream) {
+    return idh_cost_volume_dot_ex_fwd(cur_nhwc, src_nhwc, src_K_44, src_E_44, cur_invK_44, dmin, dmax, B, K, C, H, W, D, cost,
+                                      cost_nhwc_cs, lowest_bhw, planes_d, nullptr, stream);
 }

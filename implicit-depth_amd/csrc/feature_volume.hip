@@ -115,7 +115,17 @@ struct FvArgs {
     int tiles_per_img;     // ceil(N/16)
     int DP, G;             // planes per task, plane groups
     float dmin, dmax;
+    // idh_volume_opts, resolved: batch strides (floats) and caller-supplied planes (null = log-spaced)
+    long long cur_bs, src_bs;
+    const float *planes;
+    long long planes_sb, planes_sd;
+    int planes_sp;
 };
+
+__device__ __forceinline__ float fv_plane(const FvArgs &a, int b, int p, int d) {
+    return a.planes ? a.planes[(size_t)b * a.planes_sb + (size_t)d * a.planes_sd + (size_t)p * a.planes_sp]
+                    : fv_depth_plane(d, a.D, a.dmin, a.dmax);
+}
 
 // KT = compile-time view count (7, 8) or 0 = run-time: with KT > 0 the view loop is fully unrolled so the
 // scheduler can slot view k+1's projection / blend VALU work between view k's 32 MFMAs.
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
         const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
         const float *pb = a.ws + (size_t)b * kWsStrideReal;
 
-        const f32x4 cur4 = *reinterpret_cast<const f32x4 *>(a.cur + ((size_t)b * N + p) * kC + 4 * q);
+        const f32x4 cur4 = *reinterpret_cast<const f32x4 *>(a.cur + (size_t)b * a.cur_bs + (size_t)p * kC + 4 * q);
         // back-projected ray of the pixel (geometry_utils.py:60) and its direction (cost_volume.py:618)
         const float *iK = pb + kWsInvK;
         const float rx = fmaf(iK[0], pxf, fmaf(iK[1], pyf, iK[2]));
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
         const bool vec_ok = ((d0 & 3) == 0) && ((a.vol_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.vol) & 15) == 0);
 #pragma unroll 1
         for (int d = d0; d < d1; ++d) {
-            const float depth = fv_depth_plane(d, a.D, a.dmin, a.dmax);
+            const float depth = fv_plane(a, b, p, d);
             const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
             f32x4 acc1[kNS];
 #pragma unroll
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
                 const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
                 const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
-                const float *sb = a.src + (size_t)(b * K + k) * N * kC + 4 * q;
+                const float *sb = a.src + (size_t)b * a.src_bs + (size_t)k * N * kC + 4 * q;
                 t.t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kC);
                 t.t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kC);
                 t.t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kC);
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
         const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
         const float *pb = a.ws + (size_t)b * kWsStrideReal;
 
-        const f32x4 cur4 = *reinterpret_cast<const f32x4 *>(a.cur + ((size_t)b * N + p) * kC + 4 * q);
+        const f32x4 cur4 = *reinterpret_cast<const f32x4 *>(a.cur + (size_t)b * a.cur_bs + (size_t)p * kC + 4 * q);
         const float *iK = pb + kWsInvK;
         const float rx = fmaf(iK[0], pxf, fmaf(iK[1], pyf, iK[2]));
         const float ry = fmaf(iK[3], pxf, fmaf(iK[4], pyf, iK[5]));
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
         const bool vec_ok = ((d0 & 3) == 0) && ((a.vol_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.vol) & 15) == 0);
 #pragma unroll 1
         for (int d = d0; d < d1; ++d) {
-            const float depth = fv_depth_plane(d, a.D, a.dmin, a.dmax);
+            const float depth = fv_plane(a, b, p, d);
             const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
             f32x4 X[12];  // [0..3] metadata blocks, [4 + k] warped features of view k
 #pragma unroll
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
                 const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
                 const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
                 const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
-                const float *sb = a.src + (size_t)(b * K + k) * N * kC;  // wave-uniform
+                const float *sb = a.src + (size_t)b * a.src_bs + (size_t)k * N * kC;  // wave-uniform
 #ifdef IDH_ABL_NOGATHER
                 t.t00 = t.t01 = t.t10 = t.t11 = (f32x4){(float)xa0, (float)ya0, (float)xa1, (float)ya1 + sb[0]};
 #else
@@ -634,9 +644,15 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
 // lowest[b,p] = plane_{argmax_d vol[b,d,p]} (first maximum wins), reference cost_volume.py:352-356
 __global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__ vol, int vol_cs, int B, int N, int D,
                                                        float dmin, float dmax, float *__restrict__ lowest,
-                                                       float *__restrict__ planes_out) {
+                                                       float *__restrict__ planes_out, const float *__restrict__ planes,
+                                                       long long planes_sb, long long planes_sd, int planes_sp) {
+    auto plane_of = [&](long long t, int bi) {
+        if (planes == nullptr) return fv_depth_plane(bi, D, dmin, dmax);
+        const long long b = t / N, p = t - b * N;
+        return planes[b * planes_sb + (long long)bi * planes_sd + p * planes_sp];
+    };
     const long long total = (long long)B * N;
-    if (planes_out && blockIdx.x == 0)
+    if (planes_out && planes == nullptr && blockIdx.x == 0)
         for (int i = threadIdx.x; i < D; i += 256) planes_out[i] = fv_depth_plane(i, D, dmin, dmax);
     if (vol_cs > 0 && (vol_cs & 3) == 0 && (D & 3) == 0 && (reinterpret_cast<uintptr_t>(vol) & 15) == 0) {
         // NHWC: 16 lanes share a pixel and read its D planes as coalesced 16-byte pieces (a lane per pixel would
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__
                 const int oi = __shfl_xor(bi, off, 64);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
-            if (sub == 0) lowest[t] = fv_depth_plane(bi, D, dmin, dmax);
+            if (sub == 0) lowest[t] = plane_of(t, bi);
         }
         return;
     }
@@ -670,7 +686,7 @@ __global__ __launch_bounds__(256) void argmax_planes_k(const float *__restrict__
             const float v = vol_cs > 0 ? vol[t * vol_cs + d] : vol[(b * D + d) * N + p];
             if (v > best) { best = v; bi = d; }
         }
-        lowest[t] = fv_depth_plane(bi, D, dmin, dmax);
+        lowest[t] = plane_of(t, bi);
     }
 }
 
@@ -685,7 +701,7 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
                                const float *w1_pose_rowmajor, const float *b1, const void *w2_packed,
                                const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
                                unsigned char *mask_bhw, float *planes_d, void *workspace,
-                               size_t workspace_bytes, void *stream, bool f16x3);
+                               size_t workspace_bytes, void *stream, bool f16x3, const idh_volume_opts *opts);
 
 extern "C" int idh_feature_volume_f16x3_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
                                             const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
@@ -697,7 +713,7 @@ extern "C" int idh_feature_volume_f16x3_fwd(const float *cur_nhwc, const float *
                                             size_t workspace_bytes, void *stream) {
     return feature_volume_impl(cur_nhwc, src_nhwc, src_K_44, src_E_44, src_poses_44, cur_invK_44, dmin, dmax, B, K, C, H, W, D,
                                w1_voxel_f16, w1_pixel_packed, w1_pose_rowmajor, b1, w2_f16, vecs_b2_w3_b3, vol, vol_nhwc_cs,
-                               lowest_bhw, mask_bhw, planes_d, workspace, workspace_bytes, stream, true);
+                               lowest_bhw, mask_bhw, planes_d, workspace, workspace_bytes, stream, true, nullptr);
 }
 
 extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
@@ -710,7 +726,20 @@ extern "C" int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nh
                                       size_t workspace_bytes, void *stream) {
     return feature_volume_impl(cur_nhwc, src_nhwc, src_K_44, src_E_44, src_poses_44, cur_invK_44, dmin, dmax, B, K, C, H, W, D,
                                w1_voxel_packed, w1_pixel_packed, w1_pose_rowmajor, b1, w2_packed, vecs_b2_w3_b3, vol, vol_nhwc_cs,
-                               lowest_bhw, mask_bhw, planes_d, workspace, workspace_bytes, stream, false);
+                               lowest_bhw, mask_bhw, planes_d, workspace, workspace_bytes, stream, false, nullptr);
+}
+
+extern "C" int idh_feature_volume_ex_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                                         const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
+                                         float dmin, float dmax, int B, int K, int C, int H, int W, int D,
+                                         const void *w1_voxel, const float *w1_pixel_packed,
+                                         const float *w1_pose_rowmajor, const float *b1, const void *w2,
+                                         const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
+                                         unsigned char *mask_bhw, float *planes_d, void *workspace,
+                                         size_t workspace_bytes, int f16x3, const idh_volume_opts *opts, void *stream) {
+    return feature_volume_impl(cur_nhwc, src_nhwc, src_K_44, src_E_44, src_poses_44, cur_invK_44, dmin, dmax, B, K, C, H, W, D,
+                               w1_voxel, w1_pixel_packed, w1_pose_rowmajor, b1, w2, vecs_b2_w3_b3, vol, vol_nhwc_cs,
+                               lowest_bhw, mask_bhw, planes_d, workspace, workspace_bytes, stream, f16x3 != 0, opts);
 }
 
 static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
@@ -720,7 +749,9 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
                                const float *w1_pose_rowmajor, const float *b1, const void *w2_packed,
                                const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
                                unsigned char *mask_bhw, float *planes_d, void *workspace,
-                               size_t workspace_bytes, void *stream, bool f16x3) {
+                               size_t workspace_bytes, void *stream, bool f16x3, const idh_volume_opts *opts) {
+    const bool own_planes = opts && opts->planes;
+    if (own_planes) { dmin = dmax = 1.f; planes_d = nullptr; }
     if (B < 0 || K <= 0 || H <= 0 || W <= 0 || D <= 0 || !(dmin > 0.f) || !(dmax > 0.f)) return IDH_EINVAL;
     if (C != kC || K > kMaxK || D > 4096) return IDH_EUNSUPPORTED;
     if (B == 0) return IDH_OK;
@@ -741,6 +772,17 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     a.vecs = vecs_b2_w3_b3; a.vol = vol; a.mask = mask_bhw; a.vol_cs = vol_nhwc_cs;
     a.B = B; a.K = K; a.H = H; a.W = W; a.D = D; a.dmin = dmin; a.dmax = dmax;
     const int N = H * W;
+    a.cur_bs = (long long)N * kC; a.src_bs = (long long)K * N * kC;
+    if (opts) {
+        if (opts->cur_batch_stride) a.cur_bs = opts->cur_batch_stride;
+        if (opts->src_batch_stride) a.src_bs = opts->src_batch_stride;
+        if (a.cur_bs < (long long)N * kC || a.src_bs < (long long)K * N * kC || (a.cur_bs & 3) || (a.src_bs & 3)) return IDH_EINVAL;
+        if (opts->planes) {
+            if (opts->planes_pixel_stride != 0 && opts->planes_pixel_stride != 1) return IDH_EINVAL;
+            a.planes = opts->planes; a.planes_sb = opts->planes_batch_stride; a.planes_sd = opts->planes_plane_stride;
+            a.planes_sp = opts->planes_pixel_stride;
+        }
+    }
     a.tiles_per_img = (N + 15) / 16;
     // plane groups: tasks are uniform in cost and run on 256 CUs x 8 persistent waves, so pick the
     // number of groups G (>= 4 planes per task, so the per-pixel pre-activation stays amortised) that
@@ -764,8 +806,8 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     const long long ntasks = pix_tasks * a.G;
     int grid = (int)((ntasks + 7) / 8);
     if (grid > 256) grid = 256;  // persistent: one 512-thread workgroup per CU (LDS-resident weights)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static IdhDeviceOnce attr_set;
+    if (attr_set.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k<7>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -777,7 +819,7 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return IDH_ELAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     if (f16x3) {
         const int nb32 = (K + 5) / 2;
@@ -789,7 +831,7 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
         else hipLaunchKernelGGL(fv_mlp_f16_k<0>, dim3(grid), dim3(512), lds, st, a, sw1, sw2);
     } else {
         const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4);
-        if (K == 7 && getenv("IDH_FV_GENERIC") == nullptr) hipLaunchKernelGGL(fv_mlp_k<7>, dim3(grid), dim3(512), lds, st, a);
+        if (K == 7) hipLaunchKernelGGL(fv_mlp_k<7>, dim3(grid), dim3(512), lds, st, a);
         else hipLaunchKernelGGL(fv_mlp_k<0>, dim3(grid), dim3(512), lds, st, a);
     }
     IDH_CHECK_LAUNCH();
@@ -797,7 +839,7 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
         int g2 = idh_cdiv((long long)B * N, vol_nhwc_cs > 0 ? 16 : 256);
         if (g2 > 8192) g2 = 8192;
         hipLaunchKernelGGL(argmax_planes_k, dim3(g2), dim3(256), 0, st, vol, vol_nhwc_cs, B, N, D, dmin, dmax, lowest_bhw,
-                           planes_d);
+                           planes_d, a.planes, a.planes_sb, a.planes_sd, a.planes_sp);
         IDH_CHECK_LAUNCH();
     }
     return IDH_OK;

@@ -15,6 +15,23 @@
         if (e__ != hipSuccess) return IDH_ELAUNCH; \
     } while (0)
 
+// Per-device "already configured" flag for per-function attributes (hipFuncSetAttribute is a
+// per-device setting).  True exactly once per (flag set, device); devices beyond the table are
+// configured on every call.  Relaxed atomics: a race only repeats an idempotent call.
+struct IdhDeviceOnce {
+    unsigned char done[64] = {};
+    bool first() {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) return false;
+        return true;
+    }
+    void mark() {
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) __atomic_store_n(&done[dev], 1, __ATOMIC_RELEASE);
+    }
+};
+
 static inline hipStream_t idh_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int idh_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

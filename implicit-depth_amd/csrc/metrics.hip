@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void iou_count_k(const IouArgs a) {
         if (a.bins) {  // per-depth threshold: thresholds[bucketize(query, bins)] (:49-51), right=False
             int lo = 0, hi = a.nb;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.bins[mid] < qd) lo = mid + 1; else hi = mid; }
+            if (lo >= a.nb) lo = a.nb - 1;  // query beyond the last bin edge (the reference would raise): last threshold, as csrc/mlp.hip
             const bool pr = pv > a.thr[lo];
             np[0] += pr; ni[0] += pr && tgt;
         } else {

@@ -520,14 +520,14 @@ static int binary_mlp_launch(BinArgs a, int B, void *stream, bool f16) {
     const int cblocks = (a.Cf + 15) >> 4;
     const size_t lds = ((size_t)kNS * kNS * 64 + (cblocks <= kW1LdsMaxBlocks ? (size_t)cblocks * kNS * 64 : 0)) * sizeof(f32x4) +
                        6 * kHidden * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static IdhDeviceOnce attr_set;
+    if (attr_set.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(binary_mlp_k<TM, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(binary_mlp_k<TM, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return IDH_ELAUNCH;
-        attr_set = true;
+        attr_set.mark();
     }
     if (f16) {
         a.sw2 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.w2) + (size_t)4 * kNS * 2 * 64 * 16);

@@ -41,8 +41,8 @@ def shard_batch(batch: Dict[str, torch.Tensor], world: int, rank: int, batch_siz
 def all_gather_metrics(local: torch.Tensor, counts: Sequence[int] | None = None) -> torch.Tensor:
     """All-gather per-frame metric rows (B_local, M) -> (B_global, M), rank order = frame order.
     Ragged shards (B % G != 0) are padded to the largest shard for the collective and trimmed."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local
+    if not (dist.is_available() and dist.is_initialized()):
+        return local  # single process without a process group; a 1-rank group still runs the collective
     world = dist.get_world_size()
     n_local = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
     if counts is None:

@@ -78,8 +78,7 @@ def convert_binary_mlp(ref: nn.Module) -> nn.Module:
 
 def convert(model: nn.Module, math: str = None) -> nn.Module:
     """In-place: replace ``cost_volume``, ``cost_volume_net``, ``depth_decoder`` and (BDModel)
-    ``binary_mlp`` of a reference model.  Idempotent.  ``math``: None keeps the defaults (fp32 MFMA
-    unless IDH_CONV_MATH / IDH_MLP_MATH say otherwise); "f16x3" / "bf16x6" select the split-precision
+    ``binary_mlp`` of a reference model.  Idempotent.  ``math``: None keeps the default (fp32 MFMA); "f16x3" / "bf16x6" select the split-precision
     kernels for this model's convs (and, for "f16x3", its MLP feature volume and BinaryMLP)."""
     if not isinstance(model.cost_volume, cv.CostVolumeManager):
         model.cost_volume = convert_cost_volume(model.cost_volume)
@@ -109,7 +108,10 @@ def hot_path_of(model: nn.Module, min_depth: float = 0.25, max_depth: float = 5.
     o = getattr(model, "run_opts", None)
     if o is not None:
         min_depth, max_depth = o.min_matching_depth, o.max_matching_depth
+    mm = getattr(model, "matching_model", None)
+    if mm is not None and not (hasattr(mm, "net") and len(mm.net) == 10 and isinstance(mm.net[5], nn.Conv2d) and isinstance(mm.net[8], nn.Conv2d)):
+        mm = None  # FPNMatchingEncoder etc.: the caller keeps running it and passes finished matching features
     hot = HotPath(model.cost_volume, model.cost_volume_net, model.depth_decoder, getattr(model, "binary_mlp", None), min_depth, max_depth,
-                  conv_math=getattr(model.cost_volume_net, "conv_math", None))
+                  conv_math=getattr(model.cost_volume_net, "conv_math", None), matching_model=mm)
     hot.thresholder = getattr(model, "thresholder", None)  # test_bd.py:103 sets it on the model for the infer_depth search
     return hot

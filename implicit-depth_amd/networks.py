@@ -111,6 +111,11 @@ class MLP(nn.Module):
             layers = layers[:-1]
         self.net = nn.Sequential(*layers)
 
+    def forward(self, x):
+        """reference networks.py:232-233.  Not on the hot path (the fused feature-volume kernel reads the
+        weights directly); kept so the attribute behaves like the reference's module."""
+        return self.net(x)
+
 
 class BinaryMLPNetwork(nn.Module):
     """reference modules/networks.py:87-115 (only scale 0 is evaluated at test time)."""

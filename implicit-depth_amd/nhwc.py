@@ -16,7 +16,6 @@ What the plans encode (reference modules/networks.py + modules/layers.py):
 from __future__ import annotations
 
 import ctypes as C
-import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -162,7 +161,7 @@ def split_packed_weight(conv: nn.Conv2d, math: str, proj: Optional[nn.Conv2d] = 
 # cross products accumulated in fp32 (csrc/conv_split.hip) — fp32-equivalent results at 6/16 resp.
 # 3/16 of the fp32-MFMA cost.
 MATH_MODES = ("fp32", "bf16x6", "f16x3")
-DEFAULT_MATH = os.environ.get("IDH_CONV_MATH", "fp32")
+DEFAULT_MATH = "fp32"  # process-wide default; per-plan: Plan(math=...) / the module's ``conv_math`` attribute
 SPLIT_MIN_BLOCKS = 256  # fewer 8x16x64 tiles than CUs: the fp32 kernels' finer tiles win
 
 
@@ -430,18 +429,27 @@ class Plan:
         ``idh_run_ops`` runs them as ONE grid.  This is how the many small low-resolution convs
         of the UNet++ grid (each filling only a fraction of 256 CUs) get to run side by side
         — the reference executes them strictly one after another."""
+        self.schedule_segments(0)
+
+    def schedule_segments(self, n_first: int) -> int:
+        """``schedule()`` for a plan that is replayed in two pieces — ops [0, n_first) then the rest — because a
+        kernel outside the plan (the fused cost volume) consumes the first piece's output and produces the second
+        piece's input.  Each piece is levelled on its own; returns the length of the first piece."""
         n = len(self.ops)
+        n_first = max(0, min(int(n_first), n))
+        order: List[int] = []
         level = [0] * n
-        for j in range(n):
-            mj = self.meta[j]
-            for i in range(j):
-                mi = self.meta[i]
-                if _overlap(mi["writes"], mj["reads"]) or _overlap(mi["writes"], mj["writes"]) or _overlap(mi["reads"], mj["writes"]):
-                    level[j] = max(level[j], level[i] + 1)
-        groupable = lambda k: self.ops[k].kind == OP_CONV and self.ops[k].tile_m == 9
-        order = sorted(range(n), key=lambda k: (level[k], 0 if groupable(k) else 1, k))
+        for lo, hi in ((0, n_first), (n_first, n)):
+            for j in range(lo, hi):
+                mj = self.meta[j]
+                for i in range(lo, j):
+                    mi = self.meta[i]
+                    if _overlap(mi["writes"], mj["reads"]) or _overlap(mi["writes"], mj["writes"]) or _overlap(mi["reads"], mj["writes"]):
+                        level[j] = max(level[j], level[i] + 1)
+            groupable = lambda k: self.ops[k].kind == OP_CONV and self.ops[k].tile_m == 9
+            order += sorted(range(lo, hi), key=lambda k: (level[k], 0 if groupable(k) else 1, k))
         for k in range(n):
-            self.ops[k].group = level[k] + 1 if groupable(k) else 0
+            self.ops[k].group = level[k] + 1 if (self.ops[k].kind == OP_CONV and self.ops[k].tile_m == 9) else 0
         self.ops = [self.ops[k] for k in order]
         self.meta = [self.meta[k] for k in order]
         self.levels = [level[k] for k in order]
@@ -450,6 +458,7 @@ class Plan:
             pos[old] = new
         self._pos = pos if self._pos is None else [pos[p] for p in self._pos]
         self._arr = None
+        return n_first
 
     # execution -----------------------------------------------------------------------
     def _array(self):
@@ -460,10 +469,15 @@ class Plan:
     def _idx(self, idx: int) -> int:
         return idx if self._pos is None else self._pos[idx]
 
-    def run(self):
+    def run(self, start: int = 0, end: Optional[int] = None):
+        """Replay ops [start, end) (default: all) with one C-ABI call."""
         L = _bind()
         arr = self._array()
-        _lib.check(L.idh_run_ops(C.cast(arr, C.c_void_p), len(self.ops), _lib.stream_ptr()), "idh_run_ops")
+        end = len(self.ops) if end is None else end
+        if end <= start:
+            return
+        base = C.addressof(arr) + start * C.sizeof(Op)
+        _lib.check(L.idh_run_ops(C.c_void_p(base), end - start, _lib.stream_ptr()), "idh_run_ops")
 
     def set_in(self, idx: int, t: torch.Tensor):
         """idx = op index returned at build time (stable across schedule())."""

@@ -140,6 +140,13 @@ def encoder_pyramid(
     return tuple(outs)
 
 
+def layer1_maps(B: int, K: int, H: int, W: int, seed: int = 0, channels: int = 64) -> torch.Tensor:
+    """Stand-in for the matching backbone's output — conv1/bn1/relu/maxpool/layer1 of the third-party antialiased
+    ResNet18 (reference ``modules/networks.py:262-268``): (B, K+1, 64, H, W), frame b's current image followed by its
+    K source images (``bd_model.py:149-152``); non-negative like the ReLU-terminated residual block it replaces."""
+    return torch.relu(randn((B, K + 1, channels, H, W), seed, "layer1"))
+
+
 def rendered_depth_planes(B: int, H: int, W: int, P: int = 8) -> torch.Tensor:
     """P fronto-parallel query planes 1.5..5.0 m (reference ``generic_mvs_dataset.py:242``)."""
     d = torch.linspace(1.5, 5.0, P).view(1, P, 1, 1)
@@ -212,3 +219,34 @@ def frame_tuple(B: int, K: int, img_h: int, img_w: int, seed: int = 0, P: int = 
         "cam_T_world_b44": torch.linalg.inv(src_world_T_cam), "world_T_cam_b44": src_world_T_cam.clone(),
     }
     return cur, src
+
+
+def temporal_frame(t: int, K: int, img_h: int, img_w: int, seed: int = 0):
+    """Frame ``t`` of a synthetic temporal sequence (BASELINE.json config 5; the loop of reference
+    ``inference/inference.py:106-157`` with the ``plane_2.0`` asset): the camera drifts along x and pans about y, the K
+    source views keep the DVMVS-like relative poses of ``frame_tuple``, the query is ONE fronto-parallel plane at 2 m
+    (``:128-130``), feature maps are re-drawn per frame.  Returns (cur, src, layer1 maps (1,K+1,64,h/4,w/4), encoder
+    pyramid).  The prior (previous prediction + previous cam_T_world) is carried by the caller."""
+    cur, src = frame_tuple(1, K, img_h, img_w, seed=seed, P=1)
+    world_T_cam = _rot_y(0.01 * t)
+    world_T_cam[0, 3] = 0.05 * t
+    world_T_cam[2, 3] = 0.01 * t
+    world_T_cam = world_T_cam.float()[None]
+    src_world_T_cam = world_T_cam.unsqueeze(1) @ src["world_T_cam_b44"]  # world <- cur <- src
+    cur["world_T_cam_b44"], cur["cam_T_world_b44"] = world_T_cam, torch.linalg.inv(world_T_cam)
+    src["world_T_cam_b44"], src["cam_T_world_b44"] = src_world_T_cam, torch.linalg.inv(src_world_T_cam)
+    cur["rendered_depth"] = torch.full((1, 1, img_h // 2, img_w // 2), 2.0)
+    l1 = layer1_maps(1, K, img_h // 4, img_w // 4, seed=1000 + 7 * t + seed)
+    pyr = encoder_pyramid(1, img_h, img_w, seed=2000 + 7 * t + seed)
+    return cur, src, l1, pyr
+
+
+def custom_depth_planes(B: int, D: int, H: int, W: int, seed: int = 0) -> torch.Tensor:
+    """A caller-supplied ``depth_planes_bdhw`` (reference ``modules/cost_volume.py:324-347``): per-pixel planes —
+    linearly spaced 0.4..4.5 m, tilted across the image and jittered per batch element — unlike the log-spaced,
+    image-constant planes ``generate_depth_planes`` makes."""
+    base = torch.linspace(0.4, 4.5, D).view(1, D, 1, 1)
+    ys = torch.linspace(-1, 1, H).view(1, 1, H, 1)
+    xs = torch.linspace(-1, 1, W).view(1, 1, 1, W)
+    b = torch.arange(B, dtype=torch.float32).view(B, 1, 1, 1)
+    return (base * (1.0 + 0.08 * xs - 0.05 * ys + 0.03 * b) + 0.01 * torch.sigmoid(randn((B, D, H, W), seed, "planes"))).contiguous()

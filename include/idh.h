@@ -49,6 +49,29 @@ const char *idh_error_string(int code);
 int idh_nchw_to_nhwc_f32(const float *src_nchw, float *dst_nhwc, int n_img, int C, int HW, void *stream);
 int idh_nhwc_to_nchw_f32(const float *src_nhwc, float *dst_nchw, int n_img, int C, int HW, void *stream);
 
+/* ---- options shared by the two plane-sweep volumes ------------------------------ */
+/* Optional extras of the two volume entry points (the *_ex_fwd forms; NULL = all defaults).
+ *   cur/src_batch_stride  floats between consecutive batch elements of cur_nhwc / src_nhwc (0 = dense:
+ *                         H*W*C and K*H*W*C).  Lets the matching-encoder head hand over ONE
+ *                         (B, K+1, H, W, C) buffer — frame b's current image followed by its K source images, the
+ *                         order reference bd_model.py:149-160 produces — without a regrouping copy.
+ *   planes                caller-supplied depth planes = the reference's `depth_planes_bdhw` argument
+ *                         (modules/cost_volume.py:324-347, used instead of generate_depth_planes): element
+ *                         (b,d,pixel) at planes[b*planes_batch_stride + d*planes_plane_stride +
+ *                         pixel*planes_pixel_stride]; pixel stride 0 (an expand()ed (B,D,1,1) view) or 1
+ *                         (dense per-pixel planes).  NULL = log-spaced planes from dmin/dmax; when given,
+ *                         dmin/dmax are ignored and planes_d is not written.
+ * Host struct, read during the call. */
+typedef struct idh_volume_opts {
+    int64_t cur_batch_stride;
+    int64_t src_batch_stride;
+    const float *planes;
+    int64_t planes_batch_stride;
+    int64_t planes_plane_stride;
+    int32_t planes_pixel_stride;
+    int32_t _reserved;
+} idh_volume_opts;
+
 /* ---- plane-sweep dot-product cost volume --------------------------------------- */
 /* Replaces CostVolumeManager.build_cost_volume + forward
  * (reference modules/cost_volume.py:221-358; geometry utils/geometry_utils.py:55-89):
@@ -68,6 +91,14 @@ int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const 
                             const float *src_E_44, const float *cur_invK_44, float dmin, float dmax,
                             int B, int K, int C, int H, int W, int D, float *cost, int cost_nhwc_cs,
                             float *lowest_bhw, float *planes_d, void *stream);
+int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                               const float *src_E_44, const float *cur_invK_44, float dmin, float dmax,
+                               int B, int K, int C, int H, int W, int D, float *cost, int cost_nhwc_cs,
+                               float *lowest_bhw, float *planes_d, const idh_volume_opts *opts, void *stream);
+
+/* Name of the kernel idh_cost_volume_dot*_fwd launches for this shape (what rocprofv3 --kernel-trace will show);
+ * lets bench.py label its roofline without guessing the launcher's choice. */
+const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D);
 
 /* ---- plane-sweep MLP feature volume ---------------------------------------------------- */
 /* Replaces FeatureVolumeManager.build_cost_volume + forward (reference
@@ -96,6 +127,17 @@ int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nhwc, const f
                            const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
                            unsigned char *mask_bhw, float *planes_d, void *workspace,
                            size_t workspace_bytes, void *stream);
+
+/* Same with idh_volume_opts (batch strides, caller-supplied planes); f16x3 != 0 selects the split-precision
+ * variant below (then w1_voxel / w2 are the f16 packs). */
+int idh_feature_volume_ex_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
+                              const float *src_E_44, const float *src_poses_44, const float *cur_invK_44,
+                              float dmin, float dmax, int B, int K, int C, int H, int W, int D,
+                              const void *w1_voxel, const float *w1_pixel_packed,
+                              const float *w1_pose_rowmajor, const float *b1, const void *w2,
+                              const float *vecs_b2_w3_b3, float *vol, int vol_nhwc_cs, float *lowest_bhw,
+                              unsigned char *mask_bhw, float *planes_d, void *workspace,
+                              size_t workspace_bytes, int f16x3, const idh_volume_opts *opts, void *stream);
 
 /* Split-precision ("f16x3") variant of the same kernel: the two 128-wide layers run on
  * v_mfma_f32_16x16x32_f16 with every fp32 operand expanded into two round-to-nearest f16 pieces

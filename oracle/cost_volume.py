@@ -119,24 +119,29 @@ def cost_volume_dot(
     min_depth: float,
     max_depth: float,
     D: int,
+    planes_bdhw: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """CostVolumeManager.forward restated (cost_volume.py:221-358).
 
-    Returns (cost_volume B,D,H,W ; lowest_cost B,H,W ; planes D).
+    Returns (cost_volume B,D,H,W ; lowest_cost B,H,W ; planes D).  ``planes_bdhw``: the caller-supplied
+    ``depth_planes_bdhw`` of cost_volume.py:280-288 (per-pixel planes, used instead of the log-spaced ones);
+    then ``lowest`` gathers from it (:321, :352-356) and the third result is that tensor.
     """
     B, K, C, H, W = src_feats.shape
     dt = cur_feats.dtype
-    planes = depth_planes(min_depth, max_depth, D, dt)
+    planes = depth_planes(min_depth, max_depth, D, dt) if planes_bdhw is None else None
     rays = _pixel_rays(cur_invK, H, W)
     P = _P(src_Ks, src_extrinsics)
     cur = cur_feats.reshape(B, 1, C, H * W)
     cost = torch.empty(B, D, H * W, dtype=dt)
     for i in range(D):
-        _, u, v, z = project_plane(rays, planes[i], P)
+        _, u, v, z = project_plane(rays, planes[i] if planes_bdhw is None else planes_bdhw[:, i].reshape(B, 1, H * W).to(dt), P)
         warped = bilinear_zeros(src_feats, u, v)
         mask = (z > 0).to(dt)  # always 1: z is already clamped (SURVEY.md §8a a4 quirk)
         cost[:, i] = ((warped * cur).sum(2) * mask).sum(1)
     cost = cost.view(B, D, H, W)
+    if planes_bdhw is not None:
+        return cost, torch.gather(planes_bdhw.to(dt), 1, torch.argmax(cost, 1, keepdim=True))[:, 0], planes_bdhw
     lowest = planes[torch.argmax(cost, 1)]
     return cost, lowest, planes
 
@@ -185,7 +190,7 @@ def feature_vector(
             cur,
             mask,
             z,
-            torch.full((B, 1, N), float(depth), dtype=dt),
+            (depth.to(dt).expand(B, 1, N) if torch.is_tensor(depth) and depth.dim() == 3 else torch.full((B, 1, N), float(depth), dtype=dt)),
             dots,
             angle,
             cur_ray,
@@ -227,20 +232,25 @@ def feature_volume(
     D: int,
     mlp_weights: Dict[str, torch.Tensor],
     return_mask: bool = False,
+    planes_bdhw: Optional[torch.Tensor] = None,
 ):
-    """FeatureVolumeManager.forward restated (cost_volume.py:437-706, 324-358)."""
+    """FeatureVolumeManager.forward restated (cost_volume.py:437-706, 324-358); ``planes_bdhw`` as in
+    ``cost_volume_dot``."""
     B, K, C, H, W = src_feats.shape
     dt = cur_feats.dtype
-    planes = depth_planes(min_depth, max_depth, D, dt)
+    planes = depth_planes(min_depth, max_depth, D, dt) if planes_bdhw is None else None
     vol = torch.empty(B, D, H * W, dtype=dt)
     overall = None
     for i in range(D):
         vec, m = feature_vector(
-            cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK, planes[i], return_mask
+            cur_feats, src_feats, src_extrinsics, src_poses, src_Ks, cur_invK,
+            planes[i] if planes_bdhw is None else planes_bdhw[:, i].reshape(B, 1, H * W).to(dt), return_mask
         )
         if m is not None:
             overall = m  # overwritten every plane: the LAST plane's mask survives (:603-615)
         vol[:, i] = mlp_forward(vec.transpose(1, 2), mlp_weights)[..., 0]
     vol = vol.view(B, D, H, W)
+    if planes_bdhw is not None:
+        return vol, torch.gather(planes_bdhw.to(dt), 1, torch.argmax(vol, 1, keepdim=True))[:, 0], planes_bdhw, overall
     lowest = planes[torch.argmax(vol, 1)]
     return vol, lowest, planes, overall

@@ -9,14 +9,16 @@ import torch
 
 
 def plane_iou(query_bdn, gt_b1n, pred_bdn, thresholds: Sequence[float], bins: Optional[torch.Tensor] = None,
-              bin_thresholds: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(B,D,T,3) [iou, iou_pos, iou_neg] in float32 arithmetic like the reference."""
+              bin_thresholds: Optional[torch.Tensor] = None, clamp_index: bool = False) -> torch.Tensor:
+    """(B,D,T,3) [iou, iou_pos, iou_neg] in float32 arithmetic like the reference.  ``clamp_index``: queries
+    beyond the last bin edge take the last threshold (the reference's ``thresholds[idxs]`` raises there)."""
     q, p = query_bdn.flatten(2), pred_bdn.flatten(2)
     g = gt_b1n.flatten(2).expand_as(q)
     valid = (g > 0) & (q > 0)
     tgt = (q < g) & valid
     if bins is not None:
-        thr_list = [bin_thresholds[torch.bucketize(q, bins)]]
+        idx = torch.bucketize(q, bins)
+        thr_list = [bin_thresholds[idx.clamp_max(bins.numel() - 1) if clamp_index else idx]]
     else:
         thr_list = list(thresholds)
     outs = []

@@ -139,6 +139,42 @@ def occlusion_logits(
     return torch.cat(outs, 1)
 
 
+def infer_depth(
+    feature_s0: torch.Tensor,
+    w: W,
+    prior_b1hw: Optional[torch.Tensor] = None,
+    bins: Optional[torch.Tensor] = None,
+    thresholds: Optional[torch.Tensor] = None,
+    iters: int = 12,
+    lo: float = 0.5,
+    hi: float = 8.0,
+    return_margin: bool = False,
+):
+    """bd_model.py:273-292 (``infer_depth=True``): per-pixel binary search over [0.5, 8.0] m, first query
+    (hi - lo) / 2 = 3.75 (:276), 12 dependent BinaryMLP evaluations; a pixel is "visible" at its query depth when
+    sigmoid(logit) < threshold — 0.5, or ``thresholds[bucketize(query, bins)]`` with a Thresholder
+    (utils/binary_metrics_utils.py:42-52, bd_model.py:282-283) — visible -> the query becomes the upper bound, else the
+    lower bound; next query = midpoint.  Returns (search_depths, logits of the last evaluation[, smallest
+    |sigmoid - threshold| seen per pixel])."""
+    B, _, H, W = feature_s0.shape
+    dt = feature_s0.dtype
+    min_b = torch.full((B, 1, H, W), lo, dtype=dt)
+    max_b = torch.full((B, 1, H, W), hi, dtype=dt)
+    sd = torch.full((B, 1, H, W), (hi - lo) / 2.0, dtype=dt)
+    margin = torch.full((B, 1, H, W), float("inf"), dtype=dt)
+    logit = None
+    for _ in range(iters):
+        logit = occlusion_logits(feature_s0, sd, w, prior_b1hw)
+        pred = torch.sigmoid(logit)
+        thr = 0.5 if bins is None else thresholds.to(dt)[torch.bucketize(sd, bins.to(dt))]
+        margin = torch.minimum(margin, (pred - thr).abs())
+        vis = pred < thr
+        max_b = torch.where(vis, sd, max_b)
+        min_b = torch.where(vis, min_b, sd)
+        sd = (max_b + min_b) / 2
+    return (sd, logit, margin) if return_margin else (sd, logit)
+
+
 def sample_prior(
     rendered_depth_b1hw: torch.Tensor,
     prior_prediction_b1hw: torch.Tensor,

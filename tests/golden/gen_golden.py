@@ -264,11 +264,105 @@ def gen_bdmodel(syn):
             captured["enc"] = r
             return r
         model.encoder.forward = enc_spy
+        l1 = []
+        hook = model.matching_model.net[4].register_forward_hook(lambda m, i, o: l1.append(o.detach().clone()))
         out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+        hook.remove()
         extra = {"overall_mask": out["overall_mask_bhw"]} if out["overall_mask_bhw"] is not None else {}
+        extra["layer1"] = torch.cat(l1, 0)[None]  # (1, K+1, 64, H/4, W/4): cur image then the K source images (bd_model.py:149-152)
+        if name == "g5_bdmodel_mlp":
+            extra.update(_infer_depth_goldens(model, cur, src))
         save(name, K=np.array(K), pred_0=out["pred_0"], lowest_cost=out["lowest_cost_bhw"], matching_cur=captured["mc"],
              matching_src=captured["ms"], **{f"enc{i}": e for i, e in enumerate(captured["enc"])}, **extra,
              keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))))
+
+
+def gen_custom_planes():
+    """G13: both managers called with a caller-supplied per-pixel ``depth_planes_bdhw`` (cost_volume.py:324-347) and with
+    per-sample (B,1,1,1) min/max depth tensors (generate_depth_planes broadcasts them, :98-132).
+        python tests/golden/gen_golden.py g13
+    """
+    import contextlib, io
+
+    import_reference()
+    import implicit_depth_amd.synthetic as syn
+    from modules.cost_volume import CostVolumeManager, FeatureVolumeManager
+
+    torch.set_grad_enabled(False)
+    print("G13 caller-supplied depth planes / per-sample depth ranges")
+    B, K, C, H, W, D, seed = 2, 3, 16, 20, 36, 6, 7
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed, 1, -1)
+    planes = syn.custom_depth_planes(B, D, H, W, seed=8)
+    cv, low, pl, _ = CostVolumeManager(H, W, D)(**inp, depth_planes_bdhw=planes)
+    assert pl is planes
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = FeatureVolumeManager(H, W, D, mlp_channels=[202, 128, 128, 1], num_source_views=K)
+    syn.fill_state_dict(m.mlp, seed=107, gain=1.4)
+    fv, flow, _, fmask = m(**inp, depth_planes_bdhw=planes, return_mask=True)
+    rng = dict(inp, min_depth=torch.tensor([0.25, 0.4]).view(B, 1, 1, 1), max_depth=torch.tensor([5.0, 3.0]).view(B, 1, 1, 1))
+    cv2, low2, pl2, _ = CostVolumeManager(H, W, D)(**rng)
+    fv2, flow2, _, _ = m(**rng)
+    save("g13_custom_planes", dims=np.array([B, K, C, H, W, D, seed, 1, -1]), cost_volume=cv, lowest_cost=low, feature_volume=fv,
+         fv_lowest=flow, fv_mask=fmask, range_cost_volume=cv2, range_lowest=low2, range_planes=pl2[:, :, 0, 0], range_feature_volume=fv2,
+         range_fv_lowest=flow2)
+
+
+def _stub_pytorch3d():
+    """utils/binary_metrics_utils.py imports the mesh renderer at module top; none of it is on the path."""
+    for name in ("pytorch3d", "pytorch3d.io", "pytorch3d.renderer", "pytorch3d.structures", "pytorch3d.utils"):
+        _stub(name)
+    sys.modules["pytorch3d.io"].load_ply = None
+    for n in ("FoVPerspectiveCameras", "HardFlatShader", "MeshRasterizer", "MeshRenderer", "RasterizationSettings", "TexturesAtlas", "TexturesVertex"):
+        setattr(sys.modules["pytorch3d.renderer"], n, None)
+    sys.modules["pytorch3d.structures"].Meshes = None
+    sys.modules["pytorch3d.utils"].cameras_from_opencv_projection = None
+
+
+def _thresholder():
+    """The reference's Thresholder (utils/binary_metrics_utils.py:42-52) over the 8 test planes with a non-trivial
+    per-depth threshold table; its ctor calls .cuda() on the table."""
+    _stub_pytorch3d()
+    from utils.binary_metrics_utils import Thresholder
+
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        return Thresholder(torch.tensor([1.5 + 0.5 * i for i in range(8)]), torch.tensor([0.3, 0.35, 0.45, 0.5, 0.55, 0.6, 0.65, 0.7]))
+    finally:
+        torch.Tensor.cuda = cuda
+
+
+def _infer_depth_goldens(model, cur, src, full=False):
+    """BDModel.forward(..., infer_depth=True) (bd_model.py:273-292) without and with a Thresholder: the final
+    search depths, the logits of the 12th evaluation, and — from the reference's own per-step outputs — each
+    pixel's smallest |sigmoid(logit) - threshold| over the 12 decisions (pixels below ~1e-4 may legitimately
+    branch the other way in another fp32 implementation)."""
+    res = {}
+    for tag, th in (("", None), ("_thr", _thresholder())):
+        model.thresholder = th
+        steps = []
+        orig = model.run_mlp_val
+        def spy(inputs, fmaps, rd, _o=orig):
+            r = _o(inputs, fmaps, rd)
+            steps.append((rd.detach().clone(), r["pred_0"].detach().clone()))
+            return r
+        model.run_mlp_val = spy
+        out = model("test", dict(cur), src, unbatched_matching_encoder_forward=True, return_mask=True, infer_depth=True)
+        model.run_mlp_val = orig
+        assert len(steps) == 12
+        margin = None
+        for rd, pr in steps:
+            t = 0.5 if th is None else th.get_thresholds(rd)
+            m = (torch.sigmoid(pr) - t).abs()
+            margin = m if margin is None else torch.minimum(margin, m)
+        sl = (lambda t: t[:, :, ::6, ::8]) if full else (lambda t: t)
+        res[f"search_depths{tag}"] = sl(out["search_depths"])
+        res[f"search_pred{tag}"] = sl(out["pred_0"])
+        res[f"search_margin{tag}"] = sl(margin)
+        if full:
+            res[f"search_depths{tag}_chk"] = chk(out["search_depths"])
+    model.thresholder = None
+    return res
 
 
 def gen_depthmodel(syn):
@@ -333,13 +427,7 @@ def gen_metrics(syn):
     """G10: PlaneEvaluator IoU scores (constant thresholds + per-depth Thresholder) and
     compute_depth_metrics_batched from the reference's utils/."""
     print("G10 evaluation metrics")
-    for name in ("pytorch3d", "pytorch3d.io", "pytorch3d.renderer", "pytorch3d.structures", "pytorch3d.utils"):
-        _stub(name)
-    sys.modules["pytorch3d.io"].load_ply = None
-    for n in ("FoVPerspectiveCameras", "HardFlatShader", "MeshRasterizer", "MeshRenderer", "RasterizationSettings", "TexturesAtlas", "TexturesVertex"):
-        setattr(sys.modules["pytorch3d.renderer"], n, None)
-    sys.modules["pytorch3d.structures"].Meshes = None
-    sys.modules["pytorch3d.utils"].cameras_from_opencv_projection = None
+    _stub_pytorch3d()
     from utils.binary_metrics_utils import PlaneEvaluator, Thresholder
     from utils.metrics_utils import compute_depth_metrics_batched
     q, gt, pred = metric_inputs(syn)
@@ -534,7 +622,36 @@ def gen_full_temporal():
         prior_mask_slice=cur["prior_mask"][:, :, ::6, ::8],
         lowest_slice=out["lowest_cost_bhw"][:, ::3, ::4],
         keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))),
+        **_infer_depth_goldens(model, cur, src, full=True),  # the binary depth search with the prior channel
     )
+    gen_temporal_sequence(model, syn, K, Hi, Wi)
+
+
+def gen_temporal_sequence(model, syn, K, Hi, Wi, T=16):
+    """BASELINE.json config 5 as it actually runs: the reference's temporal inference loop (inference/inference.py:
+    139-157) over T frames, each forward receiving the previous frame's sigmoid(pred_0) and cam_T_world as the prior —
+    D=96, prior-enabled occlusion MLP, one query plane at 2 m, starting at the matching backbone's layer1 map
+    (reference encoder head applied image by image)."""
+    print(f"G5 temporal sequence, {T} frames")
+    prev_pred = prev_cam_T_world = None
+    preds, priors = [], []
+    for t in range(T):
+        cur, src, l1, pyr = syn.temporal_frame(t, K, Hi, Wi, seed=31)
+        def head_feats(*a, _l1=l1, **k):
+            f = torch.cat([model.matching_model.net[5:](x) for x in _l1[0].split(1, dim=0)], 0)[None]
+            return f[:, 0], f[:, 1:].contiguous()
+        model.compute_matching_feats = head_feats
+        model.encoder.forward = lambda x, _p=list(pyr): _p
+        cur["prior_prediction"], cur["prior_cam_T_world"] = prev_pred, prev_cam_T_world
+        out = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True, infer_depth=False)
+        prev_pred = torch.sigmoid(out["pred_0"])  # sigmoid_custom(x, multiplier=1.0), inference.py:154
+        prev_cam_T_world = cur["cam_T_world_b44"]
+        preds.append(out["pred_0"])
+        priors.append(cur["prior_mask"] if "prior_mask" in cur else -torch.ones_like(out["pred_0"]))
+    pred = torch.cat(preds, 0)
+    save("g5_temporal_seq16", dims=np.array([K, Hi, Wi, model.cost_volume.num_depth_bins, T]),
+         pred_slice=pred[:, :, ::6, ::8], pred_chk=np.stack([chk(p) for p in preds]),
+         prior_slice=torch.cat(priors, 0)[:, :, ::6, ::8])
 
 
 def gen_full_bdmodel():
@@ -589,6 +706,22 @@ def gen_full_bdmodel():
         extra = {}
         if out["overall_mask_bhw"] is not None:
             extra = {"mask_count": np.array(int(out["overall_mask_bhw"].sum().item())), "mask_slice": out["overall_mask_bhw"][:, ::3, ::4]}
+        # --- the same forward starting one step earlier: at the matching backbone's layer1 map, through the
+        # reference's own encoder head net[5:] applied image by image (bd_model.py:149-160, networks.py:279-283)
+        layer1 = syn.layer1_maps(1, K, Hi // 4, Wi // 4, seed=78)
+        def head_feats(*a, _m=model, _l1=layer1, **k):
+            f = torch.cat([_m.matching_model.net[5:](x) for x in _l1[0].split(1, dim=0)], 0)[None]
+            return f[:, 0], f[:, 1:].contiguous()
+        model.compute_matching_feats = head_feats
+        outh = model("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+        fc, fs = head_feats()
+        extra.update(head_pred_chk=chk(outh["pred_0"]), head_pred_slice=outh["pred_0"][:, :, ::6, ::8],
+                     head_lowest_slice=outh["lowest_cost_bhw"][:, ::3, ::4], head_feats_chk=chk(torch.cat([fc[:, None], fs], 1)),
+                     head_feats_slice=torch.cat([fc[:, None], fs], 1)[:, :, :, ::6, ::8])
+        if outh["overall_mask_bhw"] is not None:
+            extra["head_mask_slice"] = outh["overall_mask_bhw"][:, ::3, ::4]
+        if fvt == "mlp_feature_volume":
+            extra.update({"head_" + k: v for k, v in _infer_depth_goldens(model, cur, src, full=True).items()})
         save(
             name,
             dims=np.array([K, Hi, Wi, D, P]),
@@ -597,6 +730,7 @@ def gen_full_bdmodel():
             lowest_chk=chk(out["lowest_cost_bhw"]),
             lowest_slice=out["lowest_cost_bhw"][:, ::3, ::4],
             keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))),
+            head_keys=np.array(sorted(k for k in model.state_dict() if k.startswith("matching_model.net.5") or k.startswith("matching_model.net.8"))),
             **extra,
         )
 
@@ -608,6 +742,8 @@ if __name__ == "__main__":
         gen_full_bdmodel()
     elif len(sys.argv) > 1 and sys.argv[1] == "g5_temporal":
         gen_full_temporal()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g13":
+        gen_custom_planes()
     elif len(sys.argv) > 1 and sys.argv[1] == "g9_full":
         gen_full_depthmodel()
     else:
@@ -616,3 +752,4 @@ if __name__ == "__main__":
         gen_full_bdmodel()
         gen_full_temporal()
         gen_full_depthmodel()
+        gen_custom_planes()

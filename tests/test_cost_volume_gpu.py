@@ -148,3 +148,58 @@ def test_empty_batch_and_limits():
     m = FeatureVolumeManager(8, 8, 4, num_source_views=9).cuda()
     with pytest.raises(_lib.IdhError):
         m(**k9)
+
+
+def test_depth_range_as_numbers_device_tensors_and_per_sample_tensors():
+    """min/max depth reach the kernel three ways: plain numbers (planes expanded in the kernel), the (1,1,1,1) device
+    tensors BDModel.forward passes (planes computed on the device with the reference's formula — no device->host
+    read), and (B,1,1,1) per-sample ranges (golden G13)."""
+    from implicit_depth_amd.cost_volume import CostVolumeManager, FeatureVolumeManager
+
+    g = load_golden("g13_custom_planes")
+    B, K, C, H, W, D, seed, bv, rv = [int(v) for v in g["dims"]]
+    inp = {k: v.cuda() for k, v in syn.cost_volume_inputs(B, K, C, H, W, seed, bv, rv).items()}
+    m = CostVolumeManager(H, W, D).cuda()
+    a = m(**inp)
+    b = m(**dict(inp, min_depth=0.25, max_depth=5.0))
+    assert rel_err(b[0].cpu(), a[0].cpu()) < 1e-6 and rel_err(b[2].cpu(), a[2].cpu()) < 1e-6
+    rng = dict(inp, min_depth=torch.tensor([0.25, 0.4]).view(B, 1, 1, 1).cuda(), max_depth=torch.tensor([5.0, 3.0]).view(B, 1, 1, 1).cuda())
+    cv, low, planes, _ = m(**rng)
+    assert rel_err(cv.cpu(), g["range_cost_volume"]) < TOL
+    assert rel_err(planes[:, :, 0, 0].cpu(), g["range_planes"]) < 1e-6
+    assert _lowest_mismatch(low.cpu(), g["range_lowest"]) < 5e-3
+    fm = FeatureVolumeManager(H, W, D, num_source_views=K)
+    syn.fill_state_dict(fm.mlp, seed=107, gain=1.4)
+    fm.cuda()
+    fv, flow, _, _ = fm(**rng)
+    assert rel_err(fv.cpu(), g["range_feature_volume"]) < TOL
+    assert _lowest_mismatch(flow.cpu(), g["range_fv_lowest"]) < 5e-3
+
+
+def test_caller_supplied_depth_planes_bdhw():
+    """The reference's ``depth_planes_bdhw`` argument (modules/cost_volume.py:324-347) with per-pixel planes, both
+    managers (golden G13), and an expand()ed image-constant view of the same kind generate_depth_planes returns."""
+    from implicit_depth_amd.cost_volume import CostVolumeManager, FeatureVolumeManager
+
+    g = load_golden("g13_custom_planes")
+    B, K, C, H, W, D, seed, bv, rv = [int(v) for v in g["dims"]]
+    inp = {k: v.cuda() for k, v in syn.cost_volume_inputs(B, K, C, H, W, seed, bv, rv).items()}
+    planes = syn.custom_depth_planes(B, D, H, W, seed=8).cuda()
+    m = CostVolumeManager(H, W, D).cuda()
+    cv, low, pl, mask = m(**inp, depth_planes_bdhw=planes)
+    assert mask is None and torch.equal(pl, planes)
+    assert rel_err(cv.cpu(), g["cost_volume"]) < TOL
+    assert _lowest_mismatch(low.cpu(), g["lowest_cost"]) < 5e-3
+    fm = FeatureVolumeManager(H, W, D, num_source_views=K)
+    syn.fill_state_dict(fm.mlp, seed=107, gain=1.4)
+    fm.cuda()
+    fv, flow, _, fmask = fm(**inp, depth_planes_bdhw=planes, return_mask=True)
+    assert rel_err(fv.cpu(), g["feature_volume"]) < TOL
+    assert _lowest_mismatch(flow.cpu(), g["fv_lowest"]) < 5e-3
+    assert (fmask.cpu() != torch.as_tensor(g["fv_mask"])).float().mean().item() < 2e-3
+    # image-constant planes passed as a stride-0 view == the same planes generated from min/max depth
+    gen = m.generate_depth_planes(B, inp["min_depth"], inp["max_depth"])
+    assert gen.stride(2) == 0 and gen.stride(3) == 0
+    assert rel_err(m(**inp, depth_planes_bdhw=gen)[0].cpu(), m(**inp)[0].cpu()) < 1e-6
+    with pytest.raises(ValueError):
+        m(**inp, depth_planes_bdhw=planes[:, :-1])

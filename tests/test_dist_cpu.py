@@ -70,3 +70,80 @@ def test_two_rank_gather_matches_single_process(B):
         assert g.shape == ref.shape
         assert torch.equal(torch.nan_to_num(g, nan=-1), torch.nan_to_num(ref, nan=-1))
         assert torch.allclose(m, torch.nanmean(ref, 0))
+
+
+def test_bench_shard_counts_cover_the_global_batch():
+    """bench.py's frame sharding (strong scaling of the fixed 32-frame batch) incl. ragged world sizes."""
+    import bench
+
+    for world in (1, 2, 3, 4, 8):
+        c = bench.shard_counts(32, world)
+        assert sum(c) == 32 and len(c) == world and max(c) - min(c) <= 1
+    assert bench.shard_counts(32, 3) == [11, 11, 10]
+    assert bench.shard_counts(32, 8) == [4] * 8
+    a = bench.parse([])
+    assert (a.workload, a.batch, a.views, a.planes, a.steps) == ("hot_path", 32, 7, 64, 100)
+    assert bench.parse(["--workload", "temporal"]).planes == 96 and bench.parse(["--volume", "dot"]).views == 8
+
+
+def _bench_worker(rank, world, port, B, q):
+    """What bench.py does around its timed loop, on gloo: shard the global batch with shard_counts, produce one metric
+    row per local frame, all-gather with the precomputed counts."""
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts = bench.shard_counts(B, world)
+        lo, hi = shard_range(B, world, rank)
+        assert hi - lo == counts[rank]
+        rows = torch.stack([torch.arange(lo, hi, dtype=torch.float32), torch.full((hi - lo,), float(rank))], 1)
+        g = all_gather_metrics(rows, counts=counts)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)  # the MAX-over-ranks step time
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        q.put((rank, g.numpy().copy(), t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_bench_sharding_and_gather_many_ranks(world):
+    B = 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, g, tmax in got:
+        g = torch.from_numpy(g)
+        assert g.shape == (B, 2)
+        assert torch.equal(g[:, 0], torch.arange(B, dtype=torch.float32))  # frame order = rank order
+        assert tmax == float(world)
+
+
+def _one_rank_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        rows = torch.arange(6, dtype=torch.float32).view(3, 2)
+        q.put(all_gather_metrics(rows, counts=[3]).numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_group_still_runs_the_collective():
+    """`torchrun --nproc-per-node 1 bench.py`: the all-gather is issued (RCCL on the GPU box) and is the identity."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    g = torch.from_numpy(q.get(timeout=120))
+    p.join(timeout=60)
+    assert p.exitcode == 0 and torch.equal(g, torch.arange(6, dtype=torch.float32).view(3, 2))

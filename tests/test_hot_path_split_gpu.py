@@ -47,7 +47,7 @@ def test_split_hot_path_matches_fp32_hot_path_at_bench_shape(math):
     split-precision plan vs the fp32-MFMA plan."""
     import argparse
 
-    from implicit_depth_amd.pipeline import HotPathWorkload
+    from bench import HotPathWorkload
 
     outs = {}
     for m in ("fp32", math):
@@ -147,7 +147,7 @@ def test_batch_invariance_at_bench_size(math):
     maps) up to summation order."""
     import argparse
 
-    from implicit_depth_amd.pipeline import HotPathWorkload
+    from bench import HotPathWorkload
 
     mk = lambda B: argparse.Namespace(batch=B, views=7, planes=64, height=384, width=512, volume="mlp", conv_math=math,
                                       mlp_math="f16x3" if math == "f16x3" else "fp32")
@@ -161,6 +161,7 @@ def test_batch_invariance_at_bench_size(math):
         one.d = {k: (v[i:i + 1].contiguous() if v.dim() > 0 and v.shape[0] == 32 else v) for k, v in big.d.items()}
         one.pyr = [t[i:i + 1].contiguous() for t in big.pyr]
         one.rd = big.rd[i:i + 1].contiguous()
+        one.l1 = big.l1[i:i + 1].contiguous()
         one.step()
         torch.cuda.synchronize()
         a, b = one.out["pred_0"][0], ref[i]

@@ -57,3 +57,26 @@ def test_full_resolution_iou_counts_are_exact():
     got = plane_iou(q.cuda(), gt.cuda(), pred.cuda(), [0.3, 0.5, 0.7]).cpu()
     ref = om.plane_iou(q, gt, pred, [0.3, 0.5, 0.7])
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-6, equal_nan=True)
+
+
+def test_thresholder_query_beyond_last_bin_uses_last_threshold():
+    """Query depths above bins[-1] (= 100.0) / +inf: bucketize returns nb, where the reference's
+    thresholds[idxs] would raise; the kernel takes the last threshold (as the fused infer_depth search
+    does, csrc/mlp.hip) instead of reading past the buffer."""
+    from implicit_depth_amd.metrics import Thresholder, plane_iou
+
+    B, D, H, W = 1, 3, 16, 24
+    q = syn.rendered_depth_planes(B, H, W, D).clone()
+    q[:, 1] = 250.0
+    q[:, 2] = float("inf")
+    gt = torch.full((B, 1, H, W), 300.0)
+    gt[..., : W // 2] = 2.0
+    pred = torch.sigmoid(syn.randn((B, D, H, W), 72, "pred"))
+    planes = torch.tensor([1.5 + 0.5 * x for x in range(8)])
+    thr = torch.linspace(0.2, 0.9, 8)
+    th = Thresholder(planes, thr)
+    got = plane_iou(q.cuda(), gt.cuda(), pred.cuda(), [], bins=th.bins.cuda(), bin_thresholds=thr.cuda()).cpu()
+    idx = torch.bucketize(q.flatten(2), th.bins).clamp_max(th.bins.numel() - 1)
+    ref = om.plane_iou(q.flatten(2), gt.flatten(2), pred.flatten(2), [], bins=th.bins, bin_thresholds=thr, clamp_index=True)
+    assert int(idx.max()) == th.bins.numel() - 1
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-6, equal_nan=True)

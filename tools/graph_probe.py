@@ -3,7 +3,7 @@ python tools/graph_probe.py <batch> <math>"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from implicit_depth_amd.pipeline import HotPathWorkload
+from bench import HotPathWorkload
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 math = sys.argv[2] if len(sys.argv) > 2 else "fp32"

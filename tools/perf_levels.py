@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import implicit_depth_amd.synthetic as syn
 from implicit_depth_amd import nhwc, _lib
-from implicit_depth_amd.pipeline import HotPathWorkload
+from bench import HotPathWorkload
 import argparse
 a = argparse.Namespace(batch=int(sys.argv[1]) if len(sys.argv) > 1 else 4, views=7, planes=64, height=384, width=512, volume="mlp")
 wl = HotPathWorkload(a, torch.device("cuda"), 0)
