@@ -30,7 +30,10 @@ class VolumeOpts(C.Structure):
 
     _fields_ = [("cur_batch_stride", C.c_int64), ("src_batch_stride", C.c_int64), ("planes", C.c_void_p),
                 ("planes_batch_stride", C.c_int64), ("planes_plane_stride", C.c_int64), ("planes_pixel_stride", C.c_int32),
-                ("_reserved", C.c_int32)]
+                ("kernel", C.c_int32)]
+
+
+CV_KERNEL_LANE, CV_KERNEL_QUAD, CV_KERNEL_WINDOW = 1, 2, 3  # IDH_CV_KERNEL_* of include/idh.h
 
 
 _SIGS = {

@@ -49,15 +49,15 @@ def _is_device_scalar(v) -> bool:
     return torch.is_tensor(v) and v.is_cuda
 
 
-def volume_opts(B, K, C, H, W, D, planes_bdhw: Optional[Tensor] = None, cur_batch_stride: int = 0, src_batch_stride: int = 0):
+def volume_opts(B, K, C, H, W, D, planes_bdhw: Optional[Tensor] = None, cur_batch_stride: int = 0, src_batch_stride: int = 0, kernel: int = 0):
     """``idh_volume_opts`` for one launch -> (ctypes struct or None, keep-alive list).  ``planes_bdhw`` is the
     reference's ``depth_planes_bdhw`` (modules/cost_volume.py:324-347): any (B,D,H,W) fp32 device tensor; views
     that are constant over the image (``expand()``ed (B,D,1,1) / (1,D,1,1), what generate_depth_planes returns)
     are passed by stride, anything else as a dense per-pixel map."""
-    if planes_bdhw is None and not cur_batch_stride and not src_batch_stride:
+    if planes_bdhw is None and not cur_batch_stride and not src_batch_stride and not kernel:
         return None, []
     o = _lib.VolumeOpts()
-    o.cur_batch_stride, o.src_batch_stride = int(cur_batch_stride), int(src_batch_stride)
+    o.cur_batch_stride, o.src_batch_stride, o.kernel = int(cur_batch_stride), int(src_batch_stride), int(kernel)
     keep = []
     if planes_bdhw is not None:
         pl = planes_bdhw
@@ -86,6 +86,7 @@ class CostVolumeManager(nn.Module):
         self.register_buffer("linear_ramp_1d11", torch.linspace(0, 1, num_depth_bins).view(1, num_depth_bins, 1, 1))
         self.backprojector = BackprojectDepth(height=matching_height, width=matching_width)
         self.projector = Project3D()
+        self.kernel = 0  # 0 = the launcher's choice; _lib.CV_KERNEL_* forces one of the three dot-volume kernels (tests / profiling)
 
     # -- helpers ------------------------------------------------------------------------
     def _check(self, cur_feats, src_feats):
@@ -131,7 +132,7 @@ class CostVolumeManager(nn.Module):
         lowest = torch.empty(B, H, W, device=dev, dtype=torch.float32)
         L = _lib.lib()
         planes_t, dmin, dmax = self._planes_arg(B, min_depth, max_depth, depth_planes_bdhw)
-        opts, keep = volume_opts(B, K, C, H, W, D, planes_t)
+        opts, keep = volume_opts(B, K, C, H, W, D, planes_t, kernel=self.__dict__.get("kernel", 0))
         planes_d = torch.empty(D, device=dev, dtype=torch.float32) if planes_t is None else None
         # keep the contiguous copies alive until the launch is enqueued (a temporary's block may be
         # recycled by the next .contiguous() before the kernel runs)

@@ -646,31 +646,39 @@ __global__ __launch_bounds__(256) void instnorm_stats_k(const float *__restrict_
     }
 }
 
+// mean / 1/sqrt(var + eps) per (image, channel) from the chunk partials, in fixed chunk order (deterministic);
+// stats[n][2][C] lives behind the partials in the same workspace
+__global__ __launch_bounds__(256) void instnorm_finalize_k(const float *__restrict__ part, int C, int HW, int nchunks,
+                                                           float *__restrict__ stats) {
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f, ss = 0.f;
+        for (int k = 0; k < nchunks; ++k) {
+            const float *o = part + ((size_t)(n * nchunks + k) * 2) * C + c;
+            s += o[0];
+            ss += o[C];
+        }
+        const float mean = s / (float)HW;
+        const float var = fmaxf(ss / (float)HW - mean * mean, 0.f);  // biased, as nn.InstanceNorm2d
+        stats[(size_t)n * 2 * C + c] = mean;
+        stats[(size_t)n * 2 * C + C + c] = 1.0f / sqrtf(var + 1e-5f);
+    }
+}
+
 __global__ __launch_bounds__(256) void instnorm_apply_k(const float *__restrict__ in, int cs, float *__restrict__ out, int out_cs,
-                                                        int C, int HW, int nchunks, const float *__restrict__ part, int act,
+                                                        int C, int HW, long long total, const float *__restrict__ stats, int act,
                                                         float slope) {
-    const int n = blockIdx.y;
     const int cq = C >> 2;
-    const long long total = (long long)HW * cq;
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
         const int q = (int)(t % cq);
-        const long long p = t / cq;
-        float mean[4], rstd[4];
-        for (int e = 0; e < 4; ++e) {
-            float s = 0.f, ss = 0.f;
-            for (int c = 0; c < nchunks; ++c) {
-                const float *o = part + ((size_t)(n * nchunks + c) * 2) * C + 4 * q + e;
-                s += o[0];
-                ss += o[C];
-            }
-            mean[e] = s / (float)HW;
-            const float var = fmaxf(ss / (float)HW - mean[e] * mean[e], 0.f);  // biased, as nn.InstanceNorm2d
-            rstd[e] = 1.0f / sqrtf(var + 1e-5f);
-        }
-        const float4 v = *reinterpret_cast<const float4 *>(in + ((size_t)n * HW + p) * cs + 4 * q);
-        float r[4] = {(v.x - mean[0]) * rstd[0], (v.y - mean[1]) * rstd[1], (v.z - mean[2]) * rstd[2], (v.w - mean[3]) * rstd[3]};
+        const long long np = t / cq;          // n * HW + p
+        const int n = (int)(np / HW);
+        const float4 mean = *reinterpret_cast<const float4 *>(stats + (size_t)n * 2 * C + 4 * q);
+        const float4 rstd = *reinterpret_cast<const float4 *>(stats + (size_t)n * 2 * C + C + 4 * q);
+        const float4 v = *reinterpret_cast<const float4 *>(in + (size_t)np * cs + 4 * q);
+        float r[4] = {(v.x - mean.x) * rstd.x, (v.y - mean.y) * rstd.y, (v.z - mean.z) * rstd.z, (v.w - mean.w) * rstd.w};
         for (int e = 0; e < 4; ++e) r[e] = act_apply(r[e], act, slope);
-        *reinterpret_cast<float4 *>(out + ((size_t)n * HW + p) * out_cs + 4 * q) = make_float4(r[0], r[1], r[2], r[3]);
+        *reinterpret_cast<float4 *>(out + (size_t)np * out_cs + 4 * q) = make_float4(r[0], r[1], r[2], r[3]);
     }
 }
 
@@ -928,10 +936,14 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 hipLaunchKernelGGL(instnorm_stats_k, dim3(nchunks, op.N), dim3(256), 256 * 8 * sizeof(float), st, s.in, s.cs, C, HW,
                                    nchunks, op.ws);
                 IDH_CHECK_LAUNCH();
-                int gx = idh_cdiv((long long)HW * (C >> 2), 256);
-                if (gx > 2048) gx = 2048;
-                hipLaunchKernelGGL(instnorm_apply_k, dim3(gx, op.N), dim3(256), 0, st, s.in, s.cs, op.out, op.out_cs, C, HW, nchunks,
-                                   op.ws, op.act, op.slope);
+                float *stats = op.ws + (size_t)op.N * nchunks * 2 * C;
+                hipLaunchKernelGGL(instnorm_finalize_k, dim3(op.N), dim3(256), 0, st, op.ws, C, HW, nchunks, stats);
+                IDH_CHECK_LAUNCH();
+                const long long total = (long long)op.N * HW * (C >> 2);
+                int gx = idh_cdiv(total, 256 * 4);  // ~4 float4 per thread
+                if (gx > 16384) gx = 16384;
+                hipLaunchKernelGGL(instnorm_apply_k, dim3(gx), dim3(256), 0, st, s.in, s.cs, op.out, op.out_cs, C, HW, total, stats, op.act,
+                                   op.slope);
                 IDH_CHECK_LAUNCH();
                 break;
             }

@@ -354,7 +354,398 @@ __global__ __launch_bounds__(256) void cv_dot_quad_k(const float *__restrict__ c
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-window variant (default when the matching map is at least 32 x 20 texels).
+//
+// Both kernels above fetch every bilinear tap through the vector L1 (TA/TCP): D*K*N*4 taps x 64 B = 1.6 GB per
+// 96x128x64x8 frame at <= 43 B/clk/CU, and their dot products run on unpacked v_fma_f32.  Here a 256-thread workgroup
+// owns a 16x16 pixel tile and, for one source view and FOUR consecutive planes at a time, first copies the source
+// window the tile maps into — the bounding box of the 8 corner samples (4 tile corners x first / last plane: for
+// points in front of the camera the tile x depth-slab frustum projects to the convex hull of those 8 points) — into
+// LDS with coalesced `global_load_lds_dwordx4` rows (no VGPRs, no ds_write), then every lane owns ONE pixel and reads
+// its 4 taps x 64 B from LDS with `ds_read_b128` (256 B/clk/CU, 6x the L1 gather rate) and contracts them against the
+// pixel's feature vector with v_pk_fma_f32 (two fp32 FMAs per lane per issue).  L1 traffic drops from 256 B to
+// ~40-100 B per sample and is fully coalesced.  Near planes of wide-baseline views, where four planes span more than
+// the 32-texel window, fall back to one window per plane; groups whose samples all fall outside the image are
+// skipped; whatever a window cannot cover (views behind the camera, strong rotation, caller-supplied per-pixel
+// planes) is gathered from global memory lane by lane, so the result never depends on the window guess.
+//
+// LDS layout: window rows are 32 texels x 64 B plus 16 B of padding.  `ds_read_b128` is served in four fixed groups
+// of 16 lanes; the lane -> pixel map below makes each group a 4x4 pixel block, whose texels (4 neighbouring columns in
+// 4 neighbouring rows for the near-identity warps of an MVS tuple) then fall into 16 different 16-byte bank slots:
+// (64*col + 16*row + 16*j) mod 256.  One buffer (41 KB) + the window table -> 3 workgroups per CU; the other two
+// cover a workgroup's stage -> barrier latency.
+constexpr int kTile = 16;                         // 16 x 16 pixels per workgroup, one per lane
+constexpr int kWW = 32, kWH = 20;                 // window, texels
+constexpr int kRowPitch = kWW * 64 + 16;          // bytes
+constexpr int kWinBytes = kWH * kRowPitch;        // 41,280
+constexpr int kMaxPairs = 448;                    // (4-plane groups of one workgroup) x K; bounds dynamic LDS below 64 KiB
+enum { WM_SKIP = 0, WM_WINDOW = 1, WM_GLOBAL = 2, WM_SPLIT = 3 };
+
+struct WinEntry {  // x0 | y0 << 16 ; wneed | hneed << 8 | mode << 16
+    int xy, whm;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Sample {  // one lane's bilinear cell in one source view
+    float w00, w01, w10, w11;
+    int xa0, xa1, ya0, ya1;
+};
+
+__device__ __forceinline__ Sample cv_project(float depth, float qx, float qy, float qz, const float *hm, float Wf, float Hf, int W, int H) {
+    const float cx = fmaf(depth, qx, hm[9]);
+    const float cy = fmaf(depth, qy, hm[10]);
+    const float cz = fmaf(depth, qz, hm[11]);
+    const float z = fmaxf(cz, 1e-5f);
+    float r = __builtin_amdgcn_rcpf(z);
+    r = r * fmaf(-z, r, 2.0f);
+    const float sx = fminf(fmaxf(fmaf(cx, r, -0.5f), -1.0f), Wf);
+    const float sy = fminf(fmaxf(fmaf(cy, r, -0.5f), -1.0f), Hf);
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const float fx = sx - x0f, fy = sy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx0 = (x0 >= 0 && x0 < W) ? 1.0f - fx : 0.f;
+    const float wx1 = (x0 + 1 < W) ? fx : 0.f;
+    const float wy0 = (y0 >= 0 && y0 < H) ? 1.0f - fy : 0.f;
+    const float wy1 = (y0 + 1 < H) ? fy : 0.f;
+    Sample s;
+    s.xa0 = min(max(x0, 0), W - 1); s.xa1 = min(x0 + 1, W - 1);
+    s.ya0 = min(max(y0, 0), H - 1); s.ya1 = min(y0 + 1, H - 1);
+    s.w00 = wx0 * wy0; s.w01 = wx1 * wy0; s.w10 = wx0 * wy1; s.w11 = wx1 * wy1;
+    return s;
+}
+
+// cur . tap with packed FMAs: c[i] = channels 2i, 2i+1 of the pixel's feature vector
+__device__ __forceinline__ float cv_dot16(const f32x2 (&c)[8], const float4 &t0, const float4 &t1, const float4 &t2, const float4 &t3) {
+    f32x2 a = c[0] * (f32x2){t0.x, t0.y};
+    a = __builtin_elementwise_fma(c[1], (f32x2){t0.z, t0.w}, a);
+    a = __builtin_elementwise_fma(c[2], (f32x2){t1.x, t1.y}, a);
+    a = __builtin_elementwise_fma(c[3], (f32x2){t1.z, t1.w}, a);
+    a = __builtin_elementwise_fma(c[4], (f32x2){t2.x, t2.y}, a);
+    a = __builtin_elementwise_fma(c[5], (f32x2){t2.z, t2.w}, a);
+    a = __builtin_elementwise_fma(c[6], (f32x2){t3.x, t3.y}, a);
+    a = __builtin_elementwise_fma(c[7], (f32x2){t3.z, t3.w}, a);
+    return a.x + a.y;
+}
+
+__device__ __forceinline__ float cv_tap_lds(const unsigned char *win, int off, const f32x2 (&c)[8]) {
+    const float4 *p = reinterpret_cast<const float4 *>(win + off);
+    return cv_dot16(c, p[0], p[1], p[2], p[3]);
+}
+
+__device__ __forceinline__ float cv_tap_global(const float *sb, int xa, int ya, int W, const f32x2 (&c)[8]) {
+    const float4 *p = reinterpret_cast<const float4 *>(sb + ((size_t)ya * W + xa) * kC);
+    return cv_dot16(c, p[0], p[1], p[2], p[3]);
+}
+
+// one plane of one view for this lane's pixel: WIN -> taps inside the staged window come from LDS
+template <bool WIN>
+__device__ __forceinline__ float cv_sample(const Sample &s, const unsigned char *win, int wx0, int wy0, int wneed, int hneed,
+                                           const float *sb, int W, const f32x2 (&c)[8]) {
+    if (s.w00 + s.w01 + s.w10 + s.w11 == 0.f) return 0.f;  // whole cell outside the image (weights are >= 0)
+    float d00, d01, d10, d11;
+    const int cx0 = s.xa0 - wx0, cy0 = s.ya0 - wy0, cx1 = s.xa1 - wx0, cy1 = s.ya1 - wy0;
+    if (WIN && cx0 >= 0 && cy0 >= 0 && cx1 < wneed && cy1 < hneed) {
+        const int a00 = cy0 * kRowPitch + cx0 * 64;
+        const int dx = (cx1 - cx0) * 64, dy = (cy1 - cy0) * kRowPitch;
+        d00 = cv_tap_lds(win, a00, c);
+        d01 = cv_tap_lds(win, a00 + dx, c);
+        d10 = cv_tap_lds(win, a00 + dy, c);
+        d11 = cv_tap_lds(win, a00 + dy + dx, c);
+    } else {
+        d00 = cv_tap_global(sb, s.xa0, s.ya0, W, c);
+        d01 = cv_tap_global(sb, s.xa1, s.ya0, W, c);
+        d10 = cv_tap_global(sb, s.xa0, s.ya1, W, c);
+        d11 = cv_tap_global(sb, s.xa1, s.ya1, W, c);
+    }
+    return fmaf(s.w11, d11, fmaf(s.w10, d10, fmaf(s.w01, d01, s.w00 * d00)));
+}
+
+struct WinArgs {
+    const float *cur, *src, *src_K, *src_E, *cur_invK;
+    float *cost, *lowest, *planes_out;
+    float dmin, dmax;
+    int B, K, H, W, D;
+    int tiles_x, tiles_y, psplit, groups_per_split;  // plane groups (of 4) per workgroup
+    int cost_cs;
+    CvExt ext;
+};
+
+__global__ __launch_bounds__(256) void cv_dot_win_k(const WinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *s_win = smem;                                              // kWinBytes
+    WinEntry *s_tab = reinterpret_cast<WinEntry *>(smem + kWinBytes);         // [pairs][5]
+    __shared__ float s_planes[kMaxPlanes];
+    __shared__ __attribute__((aligned(16))) float s_h[IDH_MAX_SOURCE_VIEWS][12];
+
+    const int N = a.H * a.W, W = a.W, H = a.H, K = a.K, D = a.D;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned lin = idh_xcd_remap(blockIdx.x, gridDim.x);
+    const int sp = lin % a.psplit; lin /= a.psplit;
+    const int tx = lin % a.tiles_x; lin /= a.tiles_x;
+    const int ty = lin % a.tiles_y;
+    const int b = lin / a.tiles_y;
+    const int ngroups = (D + 3) >> 2;
+    const int g0 = sp * a.groups_per_split;
+    const int ng = min(a.groups_per_split, ngroups - g0);
+    const int px0 = tx * kTile, py0 = ty * kTile;
+    const float Wf = (float)W, Hf = (float)H;
+
+    if (tid < K)
+        build_homography(a.src_K + (size_t)(b * K + tid) * 16, a.src_E + (size_t)(b * K + tid) * 16, a.cur_invK + (size_t)b * 16, s_h[tid]);
+    for (int i = tid; i < D; i += 256) {
+        const float dp = depth_plane(i, D, a.dmin, a.dmax);
+        s_planes[i] = dp;
+        if (a.planes_out != nullptr && blockIdx.x == 0) a.planes_out[i] = dp;
+    }
+    __syncthreads();
+
+    // ---- window table: one thread per (plane group, view) ------------------------------------
+    const int px1 = min(px0 + kTile, W) - 1, py1 = min(py0 + kTile, H) - 1;  // last live pixel of the tile
+    for (int pair = tid; pair < ng * K; pair += 256) {
+        const int gi = pair / K, k = pair - gi * K;
+        const int dbase = 4 * (g0 + gi), nd = min(4, D - dbase);
+        const float *hm = s_h[k];
+        WinEntry *e = s_tab + pair * 5;
+        int bx0[4], bx1[4], by0[4], by1[4];
+        bool front[4], out[4];
+        for (int j = 0; j < 4; ++j) {
+            bx0[j] = by0[j] = 1 << 20; bx1[j] = by1[j] = -1; front[j] = true;
+            bool lft = true, rgt = true, top = true, bot = true;
+            const int dj = min(dbase + j, D - 1);
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                const int cxp = (cidx & 1) ? px1 : px0, cyp = (cidx & 2) ? py1 : py0;
+                const float xf = (float)cxp + 0.5f, yf = (float)cyp + 0.5f;
+                const float depth = a.ext.planes ? a.ext.planes[(size_t)b * a.ext.planes_sb + (size_t)dj * a.ext.planes_sd +
+                                                                 (size_t)(cyp * W + cxp) * a.ext.planes_sp]
+                                                 : s_planes[dj];
+                const float qx = fmaf(hm[0], xf, fmaf(hm[1], yf, hm[2]));
+                const float qy = fmaf(hm[3], xf, fmaf(hm[4], yf, hm[5]));
+                const float qz = fmaf(hm[6], xf, fmaf(hm[7], yf, hm[8]));
+                const float cz = fmaf(depth, qz, hm[11]);
+                front[j] = front[j] && cz > 1e-4f;
+                const float r = 1.0f / fmaxf(cz, 1e-5f);
+                const float rx = fmaf(depth, qx, hm[9]) * r - 0.5f, ry = fmaf(depth, qy, hm[10]) * r - 0.5f;  // unclamped sample position
+                lft = lft && rx <= -1.01f; rgt = rgt && rx >= Wf + 0.01f; top = top && ry <= -1.01f; bot = bot && ry >= Hf + 0.01f;
+                const int x0 = (int)floorf(fminf(fmaxf(rx, -1.0f), Wf)), y0 = (int)floorf(fminf(fmaxf(ry, -1.0f), Hf));
+                bx0[j] = min(bx0[j], max(x0 - 1, 0)); bx1[j] = max(bx1[j], min(x0 + 2, W - 1));  // one texel of slack for rounding
+                by0[j] = min(by0[j], max(y0 - 1, 0)); by1[j] = max(by1[j], min(y0 + 2, H - 1));
+            }
+            out[j] = lft || rgt || top || bot;
+        }
+        auto encode = [&](int x0, int x1, int y0, int y1) {
+            WinEntry w;
+            const int ox = min(x0, W - kWW), oy = min(y0, H - kWH);
+            w.xy = ox | (oy << 16);
+            w.whm = (x1 - ox + 1) | ((y1 - oy + 1) << 8) | (WM_WINDOW << 16);
+            return w;
+        };
+        const bool exact = a.ext.planes_sp == 0;  // skipping needs the convex-hull argument: image-constant planes only
+        bool all_front = true, all_out_same = exact;
+        for (int j = 0; j < nd; ++j) all_front = all_front && front[j];
+        // the group is skipped only when the first and last plane agree on WHICH side they are outside
+        // (recomputed over both planes' corners together)
+        if (exact && all_front) {
+            bool lft = true, rgt = true, top = true, bot = true;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int dj = min(dbase + (jj ? nd - 1 : 0), D - 1);
+                for (int cidx = 0; cidx < 4; ++cidx) {
+                    const int cxp = (cidx & 1) ? px1 : px0, cyp = (cidx & 2) ? py1 : py0;
+                    const float xf = (float)cxp + 0.5f, yf = (float)cyp + 0.5f;
+                    const float depth = a.ext.planes ? a.ext.planes[(size_t)b * a.ext.planes_sb + (size_t)dj * a.ext.planes_sd] : s_planes[dj];
+                    const float qx = fmaf(hm[0], xf, fmaf(hm[1], yf, hm[2]));
+                    const float qy = fmaf(hm[3], xf, fmaf(hm[4], yf, hm[5]));
+                    const float qz = fmaf(hm[6], xf, fmaf(hm[7], yf, hm[8]));
+                    const float r = 1.0f / fmaxf(fmaf(depth, qz, hm[11]), 1e-5f);
+                    const float rx = fmaf(depth, qx, hm[9]) * r - 0.5f, ry = fmaf(depth, qy, hm[10]) * r - 0.5f;
+                    lft = lft && rx <= -1.01f; rgt = rgt && rx >= Wf + 0.01f; top = top && ry <= -1.01f; bot = bot && ry >= Hf + 0.01f;
+                }
+            }
+            all_out_same = lft || rgt || top || bot;
+        } else {
+            all_out_same = false;
+        }
+        WinEntry e0;
+        e0.xy = 0; e0.whm = WM_SPLIT << 16;
+        if (all_out_same) {
+            e0.whm = WM_SKIP << 16;
+        } else if (all_front) {
+            const int x0 = min(bx0[0], bx0[nd - 1]), x1 = max(bx1[0], bx1[nd - 1]);
+            const int y0 = min(by0[0], by0[nd - 1]), y1 = max(by1[0], by1[nd - 1]);
+            if (x1 - x0 + 1 <= kWW && y1 - y0 + 1 <= kWH) e0 = encode(x0, x1, y0, y1);
+        }
+        e[0] = e0;
+        for (int j = 0; j < 4; ++j) {
+            WinEntry w;
+            w.xy = 0; w.whm = WM_GLOBAL << 16;
+            if (j >= nd || (exact && front[j] && out[j])) w.whm = WM_SKIP << 16;
+            else if (front[j] && bx1[j] - bx0[j] + 1 <= kWW && by1[j] - by0[j] + 1 <= kWH) w = encode(bx0[j], bx1[j], by0[j], by1[j]);
+            e[1 + j] = w;
+        }
+    }
+
+    // ---- this lane's pixel: ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) -> 4x4 pixel blocks ----
+    const int m5 = lane & 31, hi = lane >> 5;
+    const bool g1 = (m5 >= 4 && m5 < 12) || (m5 >= 16 && m5 < 20) || m5 >= 28;
+    const int rank = g1 ? (m5 < 12 ? m5 - 4 : (m5 < 20 ? m5 - 8 : m5 - 16)) : (m5 < 4 ? m5 : (m5 < 16 ? m5 - 8 : m5 - 12));
+    const int lx = 4 * (2 * hi + (g1 ? 1 : 0)) + (rank & 3), ly = 4 * wave + (rank >> 2);
+    const int x_raw = px0 + lx, y_raw = py0 + ly;
+    const bool live = x_raw < W && y_raw < H;
+    const int x = min(x_raw, W - 1), y = min(y_raw, H - 1);
+    const int p = y * W + x;
+    const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
+    f32x2 c[8];
+    {
+        const float4 *cp = reinterpret_cast<const float4 *>(a.cur + (size_t)b * a.ext.cur_bs + (size_t)p * kC);
+        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+        c[0] = (f32x2){c0.x, c0.y}; c[1] = (f32x2){c0.z, c0.w}; c[2] = (f32x2){c1.x, c1.y}; c[3] = (f32x2){c1.z, c1.w};
+        c[4] = (f32x2){c2.x, c2.y}; c[5] = (f32x2){c2.z, c2.w}; c[6] = (f32x2){c3.x, c3.y}; c[7] = (f32x2){c3.z, c3.w};
+    }
+    const float *pl = a.ext.planes ? a.ext.planes + (size_t)b * a.ext.planes_sb + (size_t)p * a.ext.planes_sp : nullptr;
+    // staging role of this lane: texel column / first row / 16-byte quarter of the window it copies
+    const int scol = (tid >> 2) & 31, srow0 = tid >> 7, squart = tid & 3;
+    __attribute__((address_space(3))) unsigned char *lds_win = (__attribute__((address_space(3))) unsigned char *)s_win;
+    const int lds_wave_off = (wave >> 1) * kRowPitch + (wave & 1) * 1024;  // + m * 2 * kRowPitch + lane * 16 (implicit)
+
+    auto stage = [&](const WinEntry &e, const float *sb) {
+        const int wx0 = e.xy & 0xffff, wy0 = e.xy >> 16;
+        const int wneed = e.whm & 0xff, hneed = (e.whm >> 8) & 0xff;
+        const float *g = sb + ((size_t)(wy0 + srow0) * W + wx0 + scol) * kC + 4 * squart;
+        if (scol < wneed) {
+#pragma unroll
+            for (int m = 0; m < kWH / 2; ++m)
+                if (srow0 + 2 * m < hneed)
+                    __builtin_amdgcn_global_load_lds(g + (size_t)m * 2 * W * kC, lds_win + lds_wave_off + m * 2 * kRowPitch, 16, 0, 0);
+        }
+    };
+
+    __syncthreads();  // table visible
+    float best = -INFINITY;
+    int bidx = 0;
+    for (int gi = 0; gi < ng; ++gi) {
+        const int dbase = 4 * (g0 + gi), nd = min(4, D - dbase);
+        float depth[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dj = min(dbase + j, D - 1);
+            depth[j] = pl ? pl[(size_t)dj * a.ext.planes_sd] : s_planes[dj];
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K; ++k) {
+            const WinEntry *e = s_tab + (gi * K + k) * 5;
+            const WinEntry e0 = e[0];
+            const int mode0 = __builtin_amdgcn_readfirstlane(e0.whm >> 16);
+            if (mode0 == WM_SKIP) continue;
+            const float *hm = s_h[k];
+            const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+            const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+            const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+            const float *sb = a.src + (size_t)b * a.ext.src_bs + (size_t)k * N * kC;
+            if (mode0 == WM_WINDOW) {
+                __syncthreads();  // every wave is done with the previous window
+                stage(e0, sb);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int wx0 = e0.xy & 0xffff, wy0 = e0.xy >> 16, wneed = e0.whm & 0xff, hneed = (e0.whm >> 8) & 0xff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nd) acc[j] += cv_sample<true>(cv_project(depth[j], qx, qy, qz, hm, Wf, Hf, W, H), s_win, wx0, wy0, wneed, hneed, sb, W, c);
+            } else {
+                for (int j = 0; j < nd; ++j) {
+                    const WinEntry e1 = e[1 + j];
+                    const int mode1 = __builtin_amdgcn_readfirstlane(e1.whm >> 16);
+                    if (mode1 == WM_SKIP) continue;
+                    const float dj = j == 0 ? depth[0] : (j == 1 ? depth[1] : (j == 2 ? depth[2] : depth[3]));
+                    const Sample s = cv_project(dj, qx, qy, qz, hm, Wf, Hf, W, H);
+                    float v;
+                    if (mode1 == WM_WINDOW) {
+                        __syncthreads();
+                        stage(e1, sb);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        v = cv_sample<true>(s, s_win, e1.xy & 0xffff, e1.xy >> 16, e1.whm & 0xff, (e1.whm >> 8) & 0xff, sb, W, c);
+                    } else {
+                        v = cv_sample<false>(s, s_win, 0, 0, 0, 0, sb, W, c);
+                    }
+                    acc[0] += j == 0 ? v : 0.f; acc[1] += j == 1 ? v : 0.f; acc[2] += j == 2 ? v : 0.f; acc[3] += j == 3 ? v : 0.f;
+                }
+            }
+        }
+        if (live) {
+            if (a.cost_cs > 0) {
+                float *o = a.cost + ((size_t)b * N + p) * a.cost_cs + dbase;
+                if (nd == 4 && (a.cost_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.cost) & 15) == 0)
+                    *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                else
+                    for (int j = 0; j < nd; ++j) o[j] = acc[j];
+            } else {
+                for (int j = 0; j < nd; ++j) a.cost[((size_t)b * D + dbase + j) * N + p] = acc[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nd && acc[j] > best) { best = acc[j]; bidx = dbase + j; }
+    }
+    if (a.lowest != nullptr && a.psplit == 1 && live) a.lowest[(size_t)b * N + p] = pl ? pl[(size_t)bidx * a.ext.planes_sd] : s_planes[bidx];
+}
+
+// lowest[b,p] = plane_{argmax_d cost[b,d,p]} (first maximum wins) for launches that split the planes over workgroups
+__global__ __launch_bounds__(256) void cv_argmax_k(const float *__restrict__ cost, int cost_cs, int B, int N, int D, float dmin, float dmax,
+                                                   float *__restrict__ lowest, const CvExt ext) {
+    const long long total = (long long)B * N;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
+        const long long b = t / N, p = t - b * N;
+        float best = -INFINITY;
+        int bi = 0;
+        if (cost_cs > 0 && (cost_cs & 3) == 0 && (D & 3) == 0 && (reinterpret_cast<uintptr_t>(cost) & 15) == 0) {
+            for (int d = 0; d < D; d += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(cost + t * cost_cs + d);
+                if (v.x > best) { best = v.x; bi = d; }
+                if (v.y > best) { best = v.y; bi = d + 1; }
+                if (v.z > best) { best = v.z; bi = d + 2; }
+                if (v.w > best) { best = v.w; bi = d + 3; }
+            }
+        } else {
+            for (int d = 0; d < D; ++d) {
+                const float v = cost_cs > 0 ? cost[t * cost_cs + d] : cost[(b * D + d) * N + p];
+                if (v > best) { best = v; bi = d; }
+            }
+        }
+        lowest[t] = ext.planes ? ext.planes[b * ext.planes_sb + (long long)bi * ext.planes_sd + p * ext.planes_sp] : depth_plane(bi, D, dmin, dmax);
+    }
+}
+
 }  // namespace
+
+// plane split of the window kernel: keep the per-workgroup table inside kMaxPairs and give small batches enough
+// workgroups for 256 CUs x 3 (the arg-max then runs as a second, tiny kernel)
+static void cv_win_split(int B, int K, int H, int W, int D, int *psplit, int *groups_per_split) {
+    const int ngroups = (D + 3) / 4;
+    const long long tiles = (long long)B * idh_cdiv(W, kTile) * idh_cdiv(H, kTile);
+    int s = 1;
+    while (s < ngroups && (tiles * s < 768 || (long long)idh_cdiv(ngroups, s) * K > kMaxPairs)) ++s;
+    const int gps = idh_cdiv(ngroups, s);
+    *groups_per_split = gps;
+    *psplit = idh_cdiv(ngroups, gps);
+}
+
+// 0 = automatic; otherwise the caller's choice when that kernel covers the shape (else -1)
+static int cv_pick_kernel(int forced, int B, int K, int H, int W, int D) {
+    (void)B;
+    const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;  // 32-bit tap offsets within one (b,k) image
+    const bool win_ok = quad_ok && W >= kWW && H >= kWH && W < 65536 && H < 32768 && (long long)K <= kMaxPairs;
+    (void)D;
+    switch (forced) {
+        case 0: return win_ok ? IDH_CV_KERNEL_WINDOW : (quad_ok ? IDH_CV_KERNEL_QUAD : IDH_CV_KERNEL_LANE);
+        case IDH_CV_KERNEL_LANE: return IDH_CV_KERNEL_LANE;
+        case IDH_CV_KERNEL_QUAD: return quad_ok ? IDH_CV_KERNEL_QUAD : -1;
+        case IDH_CV_KERNEL_WINDOW: return win_ok ? IDH_CV_KERNEL_WINDOW : -1;
+        default: return -1;
+    }
+}
 
 static int cv_resolve_ext(const idh_volume_opts *o, int K, int H, int W, CvExt *e) {
     const long long N = (long long)H * W;
@@ -388,8 +779,29 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
     CvExt ext;
     if (int rc = cv_resolve_ext(opts, K, H, W, &ext)) return rc;
     if (own_planes) { planes_d = nullptr; dmin = dmax = 1.f; }
-    const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;  // 32-bit tap offsets within one (b,k) image
-    if (quad_ok) {  // default: 1.4-1.7x faster than the one-lane-per-tap kernel at every batch size measured
+    const int which = cv_pick_kernel(opts ? opts->kernel : 0, B, K, H, W, D);
+    if (which < 0) return IDH_EINVAL;
+    if (which == IDH_CV_KERNEL_WINDOW) {
+        WinArgs a{};
+        a.cur = cur_nhwc; a.src = src_nhwc; a.src_K = src_K_44; a.src_E = src_E_44; a.cur_invK = cur_invK_44;
+        a.cost = cost; a.lowest = lowest_bhw; a.planes_out = planes_d; a.dmin = dmin; a.dmax = dmax;
+        a.B = B; a.K = K; a.H = H; a.W = W; a.D = D; a.cost_cs = cost_nhwc_cs; a.ext = ext;
+        a.tiles_x = idh_cdiv(W, kTile); a.tiles_y = idh_cdiv(H, kTile);
+        cv_win_split(B, K, H, W, D, &a.psplit, &a.groups_per_split);
+        const size_t lds = (size_t)kWinBytes + (size_t)a.groups_per_split * K * 5 * sizeof(WinEntry);
+        const long long blocks = (long long)B * a.tiles_x * a.tiles_y * a.psplit;
+        if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
+        hipLaunchKernelGGL(cv_dot_win_k, dim3((unsigned)blocks), dim3(256), lds, idh_stream(stream), a);
+        IDH_CHECK_LAUNCH();
+        if (a.psplit > 1 && lowest_bhw) {
+            int g2 = idh_cdiv((long long)B * H * W, 256);
+            if (g2 > 8192) g2 = 8192;
+            hipLaunchKernelGGL(cv_argmax_k, dim3(g2), dim3(256), 0, idh_stream(stream), cost, cost_nhwc_cs, B, H * W, D, dmin, dmax, lowest_bhw, ext);
+            IDH_CHECK_LAUNCH();
+        }
+        return IDH_OK;
+    }
+    if (which == IDH_CV_KERNEL_QUAD) {  // 1.4-1.7x faster than the one-lane-per-tap kernel at every batch size measured
         const int tiles4 = idh_cdiv((long long)H * W, 4);
         hipLaunchKernelGGL(cv_dot_quad_k, dim3((unsigned)(B * tiles4)), dim3(256), 0, idh_stream(stream), cur_nhwc, src_nhwc, src_K_44,
                            src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles4, cost_nhwc_cs, cost, lowest_bhw, planes_d, ext);
@@ -405,9 +817,8 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
 }
 
 extern "C" const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D) {
-    (void)B; (void)D;
-    const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;
-    return quad_ok ? "cv_dot_quad_k" : "cv_dot_k";
+    const int which = cv_pick_kernel(0, B, K, H, W, D);
+    return which == IDH_CV_KERNEL_WINDOW ? "cv_dot_win_k" : (which == IDH_CV_KERNEL_QUAD ? "cv_dot_quad_k" : "cv_dot_k");
 }
 
 extern "C" int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,

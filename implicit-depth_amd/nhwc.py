@@ -332,7 +332,7 @@ class Plan:
         s = op.src[0]
         s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
         op.out, op.out_cs, op.act, op.slope = out.ptr, out.cs, act, slope
-        ws = torch.empty(x.N * (-(-(x.H * x.W) // 1024)) * 2 * x.C, device=self.device, dtype=torch.float32)
+        ws = torch.empty(x.N * (-(-(x.H * x.W) // 1024) + 1) * 2 * x.C, device=self.device, dtype=torch.float32)
         self.keep.append(ws)
         op.ws = ws.data_ptr()
         self.ops.append(op)

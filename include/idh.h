@@ -69,8 +69,13 @@ typedef struct idh_volume_opts {
     int64_t planes_batch_stride;
     int64_t planes_plane_stride;
     int32_t planes_pixel_stride;
-    int32_t _reserved;
+    int32_t kernel; /* dot-product volume only: 0 = automatic (the launcher's choice), or force one IDH_CV_KERNEL_* —
+                       a test / profiling hook so that every kernel can be checked against the same goldens */
 } idh_volume_opts;
+
+#define IDH_CV_KERNEL_LANE 1   /* cv_dot_k: one lane per sample, taps through the vector L1 */
+#define IDH_CV_KERNEL_QUAD 2   /* cv_dot_quad_k: four lanes per sample, quad-coalesced taps */
+#define IDH_CV_KERNEL_WINDOW 3 /* cv_dot_win_k: source windows staged in LDS (needs a map of >= 32 x 20 texels) */
 
 /* ---- plane-sweep dot-product cost volume --------------------------------------- */
 /* Replaces CostVolumeManager.build_cost_volume + forward

@@ -28,7 +28,7 @@ enum {
     IDH_OP_COPY = 9,        /* channel-strided NHWC -> NHWC slice copy */
     IDH_OP_UPSAMPLE2_NEAREST = 8, /* nearest x2 (SkipDecoder, networks_fast.py:43) */
     IDH_OP_INSTNORM = 7     /* nn.InstanceNorm2d (no affine, eps 1e-5) [+ LeakyReLU] on NHWC; matching-encoder
-                               head networks.py:279-283.  ws: N*ceil(HW/1024)*2*C floats */
+                               head networks.py:279-283.  ws: N*(ceil(HW/1024)+1)*2*C floats (chunk partials + mean/rstd) */
 };
 
 #define IDH_PAD_ZEROS 0

@@ -11,11 +11,12 @@ from oracle import cost_volume as ocv
 pytestmark = pytest.mark.gpu
 
 
-def _run(inp, D):
+def _run(inp, D, kernel=0):
     from implicit_depth_amd.cost_volume import CostVolumeManager
 
     B, K, C, H, W = inp["src_feats"].shape
     m = CostVolumeManager(H, W, D).cuda()
+    m.kernel = kernel
     dev = {k: v.cuda() for k, v in inp.items()}
     cv, low, planes, mask = m(**dev)
     torch.cuda.synchronize()
@@ -203,3 +204,87 @@ def test_caller_supplied_depth_planes_bdhw():
     assert rel_err(m(**inp, depth_planes_bdhw=gen)[0].cpu(), m(**inp)[0].cpu()) < 1e-6
     with pytest.raises(ValueError):
         m(**inp, depth_planes_bdhw=planes[:, :-1])
+
+
+# ---- the three kernels behind idh_cost_volume_dot_fwd (one lane per sample / quad-coalesced / LDS windows) ----
+KERNELS = {"lane": 1, "quad": 2, "window": 3}
+
+
+@pytest.mark.parametrize("kernel", ["lane", "quad", "window"])
+@pytest.mark.parametrize("name", ["g1_small", "g1_b2k7", "g1_ragged"])
+def test_every_kernel_matches_reference_golden(name, kernel):
+    """g1_b2k7 has a view behind the camera and a strongly rotated one: the window kernel's per-lane global
+    fallback and its skip / split / global table modes are all exercised."""
+    g = load_golden(name)
+    B, K, C, H, W, D, seed, bv, rv = [int(v) for v in g["dims"]]
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed, bv, rv)
+    cv, low, planes = _run(inp, D, KERNELS[kernel])
+    assert rel_err(cv, g["cost_volume"]) < TOL
+    assert _lowest_mismatch(low, g["lowest_cost"]) < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 40, 50, 9), (1, 8, 16, 33, 47, 13), (3, 7, 16, 24, 32, 64), (1, 2, 16, 20, 32, 1),
+                                   (2, 16, 16, 37, 70, 6)])
+def test_window_kernel_matches_oracle_fp64(shape):
+    """Ragged tiles (maps that are not multiples of 16), D not a multiple of 4, K up to 16, views behind the camera
+    and strongly rotated views, batch > 1."""
+    B, K, C, H, W, D = shape
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed=B + K, behind_view=K - 1 if K > 2 else -1, big_rotation_view=0 if K > 3 else -1)
+    cv, low, planes = _run(inp, D, KERNELS["window"])
+    d = {k: v.double() for k, v in inp.items()}
+    ref, rlow, rplanes = ocv.cost_volume_dot(d["cur_feats"], d["src_feats"], d["src_extrinsics"], d["src_Ks"], d["cur_invK"], 0.25, 5.0, D)
+    assert rel_err(cv, ref) < TOL
+    assert _lowest_mismatch(low, rlow) < 5e-3
+    # and the quad kernel agrees with it to rounding
+    cvq, _, _ = _run(inp, D, KERNELS["quad"])
+    assert rel_err(cv, cvq) < 2e-6
+
+
+@pytest.mark.parametrize("kernel", ["lane", "quad", "window"])
+def test_every_kernel_full_size_golden(kernel):
+    g = load_golden("g1_full_k8d64")
+    B, K, C, H, W, D = [int(v) for v in g["dims"][:6]]
+    inp = syn.cost_volume_inputs(B, K, C, H, W, 0)
+    cv, low, _ = _run(inp, D, KERNELS[kernel])
+    assert rel_err(cv[:, ::4, ::6, ::8], g["cost_slice"]) < TOL
+    s = cv.double()
+    np.testing.assert_allclose([s.sum().item(), s.abs().sum().item(), (s * s).sum().item()], g["cost_chk"], rtol=1e-4, atol=1e-2)
+    assert _lowest_mismatch(low[:, ::3, ::4], g["lowest_slice"]) < 5e-3
+
+
+def test_window_kernel_caller_planes_nhwc_output_and_strides():
+    """The window kernel with per-pixel caller planes (never skips, per-lane fallback), the (B,H,W,D) output the
+    pipeline uses, and batch-strided inputs."""
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd.cost_volume import CostVolumeManager, to_nhwc, volume_opts
+
+    B, K, C, H, W, D = 2, 3, 16, 40, 50, 8
+    inp = {k: v.cuda() for k, v in syn.cost_volume_inputs(B, K, C, H, W, 3, 2, -1).items()}
+    planes = syn.custom_depth_planes(B, D, H, W, seed=4).cuda()
+    m = CostVolumeManager(H, W, D).cuda()
+    ref = {}
+    for name, kern in KERNELS.items():
+        m.kernel = kern
+        ref[name] = m(**inp, depth_planes_bdhw=planes)
+    for name in ("lane", "window"):
+        assert rel_err(ref[name][0].cpu(), ref["quad"][0].cpu()) < 2e-6
+        assert _lowest_mismatch(ref[name][1].cpu(), ref["quad"][1].cpu()) < 5e-3
+    d = {k: v.double().cpu() for k, v in inp.items()}
+    oref = ocv.cost_volume_dot(d["cur_feats"], d["src_feats"], d["src_extrinsics"], d["src_Ks"], d["cur_invK"], 0, 0, D, planes_bdhw=planes.double().cpu())[0]
+    assert rel_err(ref["window"][0].cpu(), oref) < TOL
+    # one (B, K+1, H, W, C) feature buffer addressed with batch strides, NHWC output with a channel stride > D
+    feats = torch.cat([to_nhwc(inp["cur_feats"])[:, None], to_nhwc(inp["src_feats"])], 1).contiguous()
+    hw = H * W * C
+    out = torch.zeros(B, H, W, D + 8, device="cuda")
+    low = torch.empty(B, H, W, device="cuda")
+    pl = torch.empty(D, device="cuda")
+    for kern in (2, 3):
+        opts, keep = volume_opts(B, K, C, H, W, D, None, (K + 1) * hw, (K + 1) * hw, kernel=kern)
+        _lib.check(_lib.lib().idh_cost_volume_dot_ex_fwd(feats.data_ptr(), feats.data_ptr() + 4 * hw, inp["src_Ks"].data_ptr(), inp["src_extrinsics"].data_ptr(),
+                                                         inp["cur_invK"].data_ptr(), 0.25, 5.0, B, K, C, H, W, D, out.data_ptr(), D + 8, low.data_ptr(),
+                                                         pl.data_ptr(), opts, _lib.stream_ptr()), "dot")
+        m.kernel = kern
+        want = m(**inp)
+        assert rel_err(out[..., :D].permute(0, 3, 1, 2).cpu(), want[0].cpu()) < 1e-6
+        assert float(out[..., D:].abs().max()) == 0.0
+        assert torch.equal(low, want[1])

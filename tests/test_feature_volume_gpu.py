@@ -94,7 +94,8 @@ def test_pipeline_with_feature_volume():
     rd = syn.rendered_depth_planes(B, H * 2, W * 2, P).cuda()
     out = model(inp["cur_feats"], inp["src_feats"], pyr, inp["src_extrinsics"], inp["src_poses"], inp["src_Ks"], inp["cur_invK"],
                 rendered_depth=rd, return_mask=True, return_features=True)
-    vol, low, _, mask = cv(**inp, return_mask=True)
+    # plain numbers: planes expanded in the kernel exactly as HotPath does (device tensors take the torch-computed planes)
+    vol, low, _, mask = cv(**dict(inp, min_depth=0.25, max_depth=5.0), return_mask=True)
     enc = cve(vol, pyr[1:])
     feats = dec([pyr[0]] + enc)
     assert rel_err(out["feature_s0_b1hw"], feats["feature_s0_b1hw"]) < 1e-6

@@ -62,7 +62,7 @@ def test_bd_hot_path_matches_oracle(cfg):
     d2 = {k: v.cuda() for k, v in inp2.items()}
     out2 = model(d2["cur_feats"], d2["src_feats"], [t.cuda() for t in pyr], d2["src_extrinsics"], d2["src_poses"], d2["src_Ks"], d2["cur_invK"],
                  rendered_depth=rd.cuda(), return_features=True)
-    cvol, _, _, _ = model.cost_volume(**d2)
+    cvol, _, _, _ = model.cost_volume(**dict(d2, min_depth=0.25, max_depth=5.0))  # numbers: planes expanded in the kernel, as in HotPath
     enc = model.cost_volume_net(cvol, [t.cuda() for t in pyr[1:]])
     feats = model.depth_decoder([pyr[0].cuda()] + enc)
     assert rel_err(out2["feature_s0_b1hw"], feats["feature_s0_b1hw"]) < 1e-6
