@@ -355,35 +355,43 @@ __global__ __launch_bounds__(256) void cv_dot_quad_k(const float *__restrict__ c
 }
 
 // ------------------------------------------------------------------------------------------
-// LDS-window variant (default when the matching map is at least 32 x 20 texels).
+// LDS-window variant (default when the matching map is at least 48 x 12 texels).
 //
 // Both kernels above fetch every bilinear tap through the vector L1 (TA/TCP): D*K*N*4 taps x 64 B = 1.6 GB per
 // 96x128x64x8 frame at <= 43 B/clk/CU, and their dot products run on unpacked v_fma_f32.  Here a 256-thread workgroup
-// owns a 16x16 pixel tile and, for one source view and FOUR consecutive planes at a time, first copies the source
-// window the tile maps into — the bounding box of the 8 corner samples (4 tile corners x first / last plane: for
-// points in front of the camera the tile x depth-slab frustum projects to the convex hull of those 8 points) — into
-// LDS with coalesced `global_load_lds_dwordx4` rows (no VGPRs, no ds_write), then every lane owns ONE pixel and reads
-// its 4 taps x 64 B from LDS with `ds_read_b128` (256 B/clk/CU, 6x the L1 gather rate) and contracts them against the
-// pixel's feature vector with v_pk_fma_f32 (two fp32 FMAs per lane per issue).  L1 traffic drops from 256 B to
-// ~40-100 B per sample and is fully coalesced.  Near planes of wide-baseline views, where four planes span more than
-// the 32-texel window, fall back to one window per plane; groups whose samples all fall outside the image are
-// skipped; whatever a window cannot cover (views behind the camera, strong rotation, caller-supplied per-pixel
-// planes) is gathered from global memory lane by lane, so the result never depends on the window guess.
+// owns a 32x8 pixel tile and works on one source view and a RUN of consecutive planes at a time: it first copies
+// the source window the tile sweeps over those planes — the bounding box of the tile corners' samples at every plane
+// of the run (for points in front of the camera the tile x depth-slab frustum projects into the convex hull of those
+// samples) — into LDS with coalesced `global_load_lds_dwordx4` rows (no VGPRs, no ds_write), then every lane owns ONE
+// pixel and reads its 4 taps x 64 B from LDS with `ds_read_b128` (256 B/clk/CU, 6x the L1 gather rate) and
+// contracts them against the pixel's feature vector with v_pk_fma_f32 (two fp32 FMAs per lane per issue).  Runs are
+// as long as the 48-texel window allows: planes come in super-groups of 16; a (super-group, view) pair is served by
+// one window when the sweep fits (far planes / short baselines), else by two 8-plane or four 4-plane windows, else
+// plane by plane.  L1 traffic drops from 256 B to 12-100 B per sample and is fully coalesced; runs whose samples
+// all fall outside the image are skipped outright; whatever a window cannot cover (views behind the camera, strong
+// rotation, caller-supplied per-pixel planes) is gathered from global memory lane by lane, so the result never
+// depends on the window guess.
 //
-// LDS layout: window rows are 32 texels x 64 B plus 16 B of padding.  `ds_read_b128` is served in four fixed groups
+// LDS layout: window rows are 48 texels x 64 B plus 16 B of padding.  `ds_read_b128` is served in four fixed groups
 // of 16 lanes; the lane -> pixel map below makes each group a 4x4 pixel block, whose texels (4 neighbouring columns in
 // 4 neighbouring rows for the near-identity warps of an MVS tuple) then fall into 16 different 16-byte bank slots:
-// (64*col + 16*row + 16*j) mod 256.  One buffer (41 KB) + the window table -> 3 workgroups per CU; the other two
+// (64*col + 16*row + 16*j) mod 256.  One buffer (36 KB) + the window table -> 3 workgroups per CU; the other two
 // cover a workgroup's stage -> barrier latency.
-constexpr int kTile = 16;                         // 16 x 16 pixels per workgroup, one per lane
-constexpr int kWW = 32, kWH = 20;                 // window, texels
+constexpr int kTileW = 32, kTileH = 8;            // pixels per workgroup, one per lane
+constexpr int kWW = 48, kWH = 12;                 // window, texels (3 x 16-texel DMA chunks per row)
 constexpr int kRowPitch = kWW * 64 + 16;          // bytes
-constexpr int kWinBytes = kWH * kRowPitch;        // 41,280
-constexpr int kMaxPairs = 448;                    // (4-plane groups of one workgroup) x K; bounds dynamic LDS below 64 KiB
-enum { WM_SKIP = 0, WM_WINDOW = 1, WM_GLOBAL = 2, WM_SPLIT = 3 };
+constexpr int kWinBytes = kWH * kRowPitch;        // 37,056
+constexpr int kSG = 16;                           // planes per super-group
+constexpr int kNodes = 1 + 2 + 4 + 16;            // run tree of one (super-group, view): 16 | 8 8 | 4 4 4 4 | 16 x 1
+constexpr int kMaxPairs = 64;                     // (super-groups of one workgroup) x K; bounds dynamic LDS below 64 KiB
+enum { WM_SKIP = 0, WM_WINDOW = 1, WM_GLOBAL = 2, WM_DESCEND = 3 };
 
 struct WinEntry {  // x0 | y0 << 16 ; wneed | hneed << 8 | mode << 16
     int xy, whm;
+};
+struct PlaneBox {  // per (pair, plane): clamped tap bounding box of the 4 tile corners, flags
+    short x0, x1, y0, y1;
+    int flags;     // bit 0: all corners in front; bits 1-4: all corners left / right / above / below the image
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -439,26 +447,40 @@ __device__ __forceinline__ float cv_tap_global(const float *sb, int xa, int ya, 
     return cv_dot16(c, p[0], p[1], p[2], p[3]);
 }
 
-// one plane of one view for this lane's pixel: WIN -> taps inside the staged window come from LDS
-template <bool WIN>
-__device__ __forceinline__ float cv_sample(const Sample &s, const unsigned char *win, int wx0, int wy0, int wneed, int hneed,
-                                           const float *sb, int W, const f32x2 (&c)[8]) {
-    if (s.w00 + s.w01 + s.w10 + s.w11 == 0.f) return 0.f;  // whole cell outside the image (weights are >= 0)
-    float d00, d01, d10, d11;
+// One plane of one view for this lane's pixel from the staged window, branch-free (the four planes of a unit are then
+// one basic block the scheduler can interleave: 64 ds_read_b128 against 128 packed FMAs).  Lanes whose cell is not
+// inside the window read address 0 and are masked; `fb` = the cell has weight but lies outside the window -> the
+// caller gathers it from global memory.
+struct WinCell {
+    int a00, dx, dy;
+    bool ok, fb;
+};
+__device__ __forceinline__ WinCell cv_cell(const Sample &s, int wx0, int wy0, int wneed, int hneed) {
     const int cx0 = s.xa0 - wx0, cy0 = s.ya0 - wy0, cx1 = s.xa1 - wx0, cy1 = s.ya1 - wy0;
-    if (WIN && cx0 >= 0 && cy0 >= 0 && cx1 < wneed && cy1 < hneed) {
-        const int a00 = cy0 * kRowPitch + cx0 * 64;
-        const int dx = (cx1 - cx0) * 64, dy = (cy1 - cy0) * kRowPitch;
-        d00 = cv_tap_lds(win, a00, c);
-        d01 = cv_tap_lds(win, a00 + dx, c);
-        d10 = cv_tap_lds(win, a00 + dy, c);
-        d11 = cv_tap_lds(win, a00 + dy + dx, c);
-    } else {
-        d00 = cv_tap_global(sb, s.xa0, s.ya0, W, c);
-        d01 = cv_tap_global(sb, s.xa1, s.ya0, W, c);
-        d10 = cv_tap_global(sb, s.xa0, s.ya1, W, c);
-        d11 = cv_tap_global(sb, s.xa1, s.ya1, W, c);
-    }
+    const bool inside = cx0 >= 0 && cy0 >= 0 && cx1 < wneed && cy1 < hneed;
+    const bool any_w = s.w00 + s.w01 + s.w10 + s.w11 > 0.f;  // weights are >= 0
+    WinCell c;
+    c.ok = inside && any_w;
+    c.fb = any_w && !inside;
+    c.a00 = c.ok ? cy0 * kRowPitch + cx0 * 64 : 0;
+    c.dx = c.ok ? (cx1 - cx0) * 64 : 0;
+    c.dy = c.ok ? (cy1 - cy0) * kRowPitch : 0;
+    return c;
+}
+__device__ __forceinline__ float cv_sample_win(const Sample &s, const WinCell &w, const unsigned char *win, const f32x2 (&c)[8]) {
+    const float d00 = cv_tap_lds(win, w.a00, c);
+    const float d01 = cv_tap_lds(win, w.a00 + w.dx, c);
+    const float d10 = cv_tap_lds(win, w.a00 + w.dy, c);
+    const float d11 = cv_tap_lds(win, w.a00 + w.dy + w.dx, c);
+    const float v = fmaf(s.w11, d11, fmaf(s.w10, d10, fmaf(s.w01, d01, s.w00 * d00)));
+    return w.ok ? v : 0.f;  // select, not multiply: a masked lane may have read stale LDS bits
+}
+__device__ __forceinline__ float cv_sample_global(const Sample &s, const float *sb, int W, const f32x2 (&c)[8]) {
+    if (s.w00 + s.w01 + s.w10 + s.w11 == 0.f) return 0.f;  // whole cell outside the image
+    const float d00 = cv_tap_global(sb, s.xa0, s.ya0, W, c);
+    const float d01 = cv_tap_global(sb, s.xa1, s.ya0, W, c);
+    const float d10 = cv_tap_global(sb, s.xa0, s.ya1, W, c);
+    const float d11 = cv_tap_global(sb, s.xa1, s.ya1, W, c);
     return fmaf(s.w11, d11, fmaf(s.w10, d10, fmaf(s.w01, d01, s.w00 * d00)));
 }
 
@@ -467,15 +489,15 @@ struct WinArgs {
     float *cost, *lowest, *planes_out;
     float dmin, dmax;
     int B, K, H, W, D;
-    int tiles_x, tiles_y, psplit, groups_per_split;  // plane groups (of 4) per workgroup
+    int tiles_x, tiles_y, psplit, units_per_split;  // 4-plane units per workgroup: 1, 2 or a multiple of 4
     int cost_cs;
     CvExt ext;
 };
 
-__global__ __launch_bounds__(256) void cv_dot_win_k(const WinArgs a) {
+__global__ __launch_bounds__(256, 3) void cv_dot_win_k(const WinArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *s_win = smem;                                              // kWinBytes
-    WinEntry *s_tab = reinterpret_cast<WinEntry *>(smem + kWinBytes);         // [pairs][5]
+    unsigned char *s_win = smem;                                              // kWinBytes (first used as PlaneBox scratch)
+    WinEntry *s_tab = reinterpret_cast<WinEntry *>(smem + kWinBytes);         // [pairs][kNodes]
     __shared__ float s_planes[kMaxPlanes];
     __shared__ __attribute__((aligned(16))) float s_h[IDH_MAX_SOURCE_VIEWS][12];
 
@@ -488,10 +510,11 @@ __global__ __launch_bounds__(256) void cv_dot_win_k(const WinArgs a) {
     const int tx = lin % a.tiles_x; lin /= a.tiles_x;
     const int ty = lin % a.tiles_y;
     const int b = lin / a.tiles_y;
-    const int ngroups = (D + 3) >> 2;
-    const int g0 = sp * a.groups_per_split;
-    const int ng = min(a.groups_per_split, ngroups - g0);
-    const int px0 = tx * kTile, py0 = ty * kTile;
+    const int nunits_all = (D + 3) >> 2;
+    const int ua = sp * a.units_per_split, ub = min(ua + a.units_per_split, nunits_all);  // this workgroup's 4-plane units
+    const int sg0 = ua >> 2;
+    const int nsg = ((ub + 3) >> 2) - sg0;
+    const int px0 = tx * kTileW, py0 = ty * kTileH;
     const float Wf = (float)W, Hf = (float)H;
 
     if (tid < K)
@@ -503,19 +526,20 @@ __global__ __launch_bounds__(256) void cv_dot_win_k(const WinArgs a) {
     }
     __syncthreads();
 
-    // ---- window table: one thread per (plane group, view) ------------------------------------
-    const int px1 = min(px0 + kTile, W) - 1, py1 = min(py0 + kTile, H) - 1;  // last live pixel of the tile
-    for (int pair = tid; pair < ng * K; pair += 256) {
-        const int gi = pair / K, k = pair - gi * K;
-        const int dbase = 4 * (g0 + gi), nd = min(4, D - dbase);
-        const float *hm = s_h[k];
-        WinEntry *e = s_tab + pair * 5;
-        int bx0[4], bx1[4], by0[4], by1[4];
-        bool front[4], out[4];
-        for (int j = 0; j < 4; ++j) {
-            bx0[j] = by0[j] = 1 << 20; bx1[j] = by1[j] = -1; front[j] = true;
-            bool lft = true, rgt = true, top = true, bot = true;
-            const int dj = min(dbase + j, D - 1);
+    // ---- window table, pass 1: per (pair, plane) the tap bounding box of the four tile corners ------------------
+    const int px1 = min(px0 + kTileW, W) - 1, py1 = min(py0 + kTileH, H) - 1;  // last live pixel of the tile
+    const int npairs = nsg * K;
+    PlaneBox *s_pb = reinterpret_cast<PlaneBox *>(s_win);
+    for (int it = tid; it < npairs * kSG; it += 256) {
+        const int pair = it / kSG, j = it - pair * kSG;
+        const int sgi = pair / K, k = pair - sgi * K;
+        const int dj = kSG * (sg0 + sgi) + j;
+        PlaneBox pb;
+        pb.x0 = pb.y0 = 32767; pb.x1 = pb.y1 = -1; pb.flags = 0;
+        if (dj < D) {
+            const float *hm = s_h[k];
+            bool front = true, lft = true, rgt = true, top = true, bot = true;
+            int x0m = 1 << 20, x1m = -1, y0m = 1 << 20, y1m = -1;
             for (int cidx = 0; cidx < 4; ++cidx) {
                 const int cxp = (cidx & 1) ? px1 : px0, cyp = (cidx & 2) ? py1 : py0;
                 const float xf = (float)cxp + 0.5f, yf = (float)cyp + 0.5f;
@@ -526,72 +550,57 @@ __global__ __launch_bounds__(256) void cv_dot_win_k(const WinArgs a) {
                 const float qy = fmaf(hm[3], xf, fmaf(hm[4], yf, hm[5]));
                 const float qz = fmaf(hm[6], xf, fmaf(hm[7], yf, hm[8]));
                 const float cz = fmaf(depth, qz, hm[11]);
-                front[j] = front[j] && cz > 1e-4f;
+                front = front && cz > 1e-4f;
                 const float r = 1.0f / fmaxf(cz, 1e-5f);
                 const float rx = fmaf(depth, qx, hm[9]) * r - 0.5f, ry = fmaf(depth, qy, hm[10]) * r - 0.5f;  // unclamped sample position
                 lft = lft && rx <= -1.01f; rgt = rgt && rx >= Wf + 0.01f; top = top && ry <= -1.01f; bot = bot && ry >= Hf + 0.01f;
                 const int x0 = (int)floorf(fminf(fmaxf(rx, -1.0f), Wf)), y0 = (int)floorf(fminf(fmaxf(ry, -1.0f), Hf));
-                bx0[j] = min(bx0[j], max(x0 - 1, 0)); bx1[j] = max(bx1[j], min(x0 + 2, W - 1));  // one texel of slack for rounding
-                by0[j] = min(by0[j], max(y0 - 1, 0)); by1[j] = max(by1[j], min(y0 + 2, H - 1));
+                // no slack: a lane whose cell rounds one texel outside the box takes the per-lane global path
+                x0m = min(x0m, max(x0, 0)); x1m = max(x1m, min(x0 + 1, W - 1));
+                y0m = min(y0m, max(y0, 0)); y1m = max(y1m, min(y0 + 1, H - 1));
             }
-            out[j] = lft || rgt || top || bot;
+            pb.x0 = (short)x0m; pb.x1 = (short)x1m; pb.y0 = (short)y0m; pb.y1 = (short)y1m;
+            pb.flags = (front ? 1 : 0) | (lft ? 2 : 0) | (rgt ? 4 : 0) | (top ? 8 : 0) | (bot ? 16 : 0) | 32;  // 32: plane exists
         }
-        auto encode = [&](int x0, int x1, int y0, int y1) {
-            WinEntry w;
+        s_pb[it] = pb;
+    }
+    __syncthreads();
+    // ---- pass 2: one thread per node of the run tree: 16 | 8 8 | 4 4 4 4 | 1 x 16 ---------------------------------
+    const bool exact = a.ext.planes_sp == 0;  // skipping needs the convex-hull argument: image-constant planes only
+    for (int it = tid; it < npairs * kNodes; it += 256) {
+        const int pair = it / kNodes, node = it - pair * kNodes;
+        int j0, L;
+        if (node == 0) { j0 = 0; L = 16; }
+        else if (node < 3) { j0 = 8 * (node - 1); L = 8; }
+        else if (node < 7) { j0 = 4 * (node - 3); L = 4; }
+        else { j0 = node - 7; L = 1; }
+        int x0 = 1 << 20, x1 = -1, y0 = 1 << 20, y1 = -1, andf = 31, cnt = 0;
+        for (int j = j0; j < j0 + L; ++j) {
+            const PlaneBox pb = s_pb[pair * kSG + j];
+            if (!(pb.flags & 32)) continue;
+            ++cnt;
+            x0 = min(x0, (int)pb.x0); x1 = max(x1, (int)pb.x1); y0 = min(y0, (int)pb.y0); y1 = max(y1, (int)pb.y1);
+            andf &= pb.flags;
+        }
+        WinEntry w;
+        w.xy = 0;
+        if (cnt == 0 || (exact && (andf & 1) && (andf & 30))) {
+            w.whm = WM_SKIP << 16;  // no plane, or every vertex of the slab's hull is outside the image on the SAME side
+        } else if ((andf & 1) && x1 - x0 + 1 <= kWW && y1 - y0 + 1 <= kWH) {
             const int ox = min(x0, W - kWW), oy = min(y0, H - kWH);
             w.xy = ox | (oy << 16);
             w.whm = (x1 - ox + 1) | ((y1 - oy + 1) << 8) | (WM_WINDOW << 16);
-            return w;
-        };
-        const bool exact = a.ext.planes_sp == 0;  // skipping needs the convex-hull argument: image-constant planes only
-        bool all_front = true, all_out_same = exact;
-        for (int j = 0; j < nd; ++j) all_front = all_front && front[j];
-        // the group is skipped only when the first and last plane agree on WHICH side they are outside
-        // (recomputed over both planes' corners together)
-        if (exact && all_front) {
-            bool lft = true, rgt = true, top = true, bot = true;
-            for (int jj = 0; jj < 2; ++jj) {
-                const int dj = min(dbase + (jj ? nd - 1 : 0), D - 1);
-                for (int cidx = 0; cidx < 4; ++cidx) {
-                    const int cxp = (cidx & 1) ? px1 : px0, cyp = (cidx & 2) ? py1 : py0;
-                    const float xf = (float)cxp + 0.5f, yf = (float)cyp + 0.5f;
-                    const float depth = a.ext.planes ? a.ext.planes[(size_t)b * a.ext.planes_sb + (size_t)dj * a.ext.planes_sd] : s_planes[dj];
-                    const float qx = fmaf(hm[0], xf, fmaf(hm[1], yf, hm[2]));
-                    const float qy = fmaf(hm[3], xf, fmaf(hm[4], yf, hm[5]));
-                    const float qz = fmaf(hm[6], xf, fmaf(hm[7], yf, hm[8]));
-                    const float r = 1.0f / fmaxf(fmaf(depth, qz, hm[11]), 1e-5f);
-                    const float rx = fmaf(depth, qx, hm[9]) * r - 0.5f, ry = fmaf(depth, qy, hm[10]) * r - 0.5f;
-                    lft = lft && rx <= -1.01f; rgt = rgt && rx >= Wf + 0.01f; top = top && ry <= -1.01f; bot = bot && ry >= Hf + 0.01f;
-                }
-            }
-            all_out_same = lft || rgt || top || bot;
         } else {
-            all_out_same = false;
+            w.whm = (L == 1 ? WM_GLOBAL : WM_DESCEND) << 16;
         }
-        WinEntry e0;
-        e0.xy = 0; e0.whm = WM_SPLIT << 16;
-        if (all_out_same) {
-            e0.whm = WM_SKIP << 16;
-        } else if (all_front) {
-            const int x0 = min(bx0[0], bx0[nd - 1]), x1 = max(bx1[0], bx1[nd - 1]);
-            const int y0 = min(by0[0], by0[nd - 1]), y1 = max(by1[0], by1[nd - 1]);
-            if (x1 - x0 + 1 <= kWW && y1 - y0 + 1 <= kWH) e0 = encode(x0, x1, y0, y1);
-        }
-        e[0] = e0;
-        for (int j = 0; j < 4; ++j) {
-            WinEntry w;
-            w.xy = 0; w.whm = WM_GLOBAL << 16;
-            if (j >= nd || (exact && front[j] && out[j])) w.whm = WM_SKIP << 16;
-            else if (front[j] && bx1[j] - bx0[j] + 1 <= kWW && by1[j] - by0[j] + 1 <= kWH) w = encode(bx0[j], bx1[j], by0[j], by1[j]);
-            e[1 + j] = w;
-        }
+        s_tab[it] = w;
     }
 
     // ---- this lane's pixel: ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) -> 4x4 pixel blocks ----
     const int m5 = lane & 31, hi = lane >> 5;
     const bool g1 = (m5 >= 4 && m5 < 12) || (m5 >= 16 && m5 < 20) || m5 >= 28;
     const int rank = g1 ? (m5 < 12 ? m5 - 4 : (m5 < 20 ? m5 - 8 : m5 - 16)) : (m5 < 4 ? m5 : (m5 < 16 ? m5 - 8 : m5 - 12));
-    const int lx = 4 * (2 * hi + (g1 ? 1 : 0)) + (rank & 3), ly = 4 * wave + (rank >> 2);
+    const int lx = 16 * (wave & 1) + 4 * (2 * hi + (g1 ? 1 : 0)) + (rank & 3), ly = 4 * (wave >> 1) + (rank >> 2);
     const int x_raw = px0 + lx, y_raw = py0 + ly;
     const bool live = x_raw < W && y_raw < H;
     const int x = min(x_raw, W - 1), y = min(y_raw, H - 1);
@@ -605,89 +614,152 @@ __global__ __launch_bounds__(256) void cv_dot_win_k(const WinArgs a) {
         c[4] = (f32x2){c2.x, c2.y}; c[5] = (f32x2){c2.z, c2.w}; c[6] = (f32x2){c3.x, c3.y}; c[7] = (f32x2){c3.z, c3.w};
     }
     const float *pl = a.ext.planes ? a.ext.planes + (size_t)b * a.ext.planes_sb + (size_t)p * a.ext.planes_sp : nullptr;
-    // staging role of this lane: texel column / first row / 16-byte quarter of the window it copies
-    const int scol = (tid >> 2) & 31, srow0 = tid >> 7, squart = tid & 3;
+    // staging: a window row is 3 chunks of 16 texels (1 KiB = one global_load_lds_dwordx4 of a wave); the 36 chunks
+    // of a window go round-robin to the 4 waves (chunk i = wave + 4m -> row i / 3, columns 16 (i % 3) ..), lane l
+    // copies 16-byte quarter (l & 3) of texel column (l >> 2) of its chunk
+    const int slane_col = lane >> 2, squart = lane & 3;
     __attribute__((address_space(3))) unsigned char *lds_win = (__attribute__((address_space(3))) unsigned char *)s_win;
-    const int lds_wave_off = (wave >> 1) * kRowPitch + (wave & 1) * 1024;  // + m * 2 * kRowPitch + lane * 16 (implicit)
+    constexpr int kChunksPerRow = kWW / 16, kChunks = kWH * kChunksPerRow;
 
     auto stage = [&](const WinEntry &e, const float *sb) {
         const int wx0 = e.xy & 0xffff, wy0 = e.xy >> 16;
         const int wneed = e.whm & 0xff, hneed = (e.whm >> 8) & 0xff;
-        const float *g = sb + ((size_t)(wy0 + srow0) * W + wx0 + scol) * kC + 4 * squart;
-        if (scol < wneed) {
+        const float *g = sb + ((size_t)wy0 * W + wx0 + slane_col) * kC + 4 * squart;
 #pragma unroll
-            for (int m = 0; m < kWH / 2; ++m)
-                if (srow0 + 2 * m < hneed)
-                    __builtin_amdgcn_global_load_lds(g + (size_t)m * 2 * W * kC, lds_win + lds_wave_off + m * 2 * kRowPitch, 16, 0, 0);
+        for (int m = 0; m < (kChunks + 3) / 4; ++m) {
+            const int ch = wave + 4 * m;                       // wave-uniform
+            const int row = ch / kChunksPerRow, cc = ch - row * kChunksPerRow;
+            if (ch < kChunks && row < hneed && 16 * cc < wneed) {
+                if (16 * cc + slane_col < wneed)
+                    __builtin_amdgcn_global_load_lds(g + ((size_t)row * W + 16 * cc) * kC, lds_win + row * kRowPitch + cc * 1024, 16, 0, 0);
+            }
         }
     };
 
-    __syncthreads();  // table visible
+    __syncthreads();  // table visible, PlaneBox scratch (aliasing the window) dead
     float best = -INFINITY;
     int bidx = 0;
-    for (int gi = 0; gi < ng; ++gi) {
-        const int dbase = 4 * (g0 + gi), nd = min(4, D - dbase);
-        float depth[4];
+    for (int sgi = 0; sgi < nsg; ++sgi) {
+        const int dbase = kSG * (sg0 + sgi), nd = min(kSG, D - dbase);
+        float4 acc[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int dj = min(dbase + j, D - 1);
-            depth[j] = pl ? pl[(size_t)dj * a.ext.planes_sd] : s_planes[dj];
-        }
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // units of this super-group that belong to this workgroup (whole super-groups unless the launch splits finer)
+        const int ulo = max(ua - 4 * (sg0 + sgi), 0), uhi = min(ub - 4 * (sg0 + sgi), 4);
         for (int k = 0; k < K; ++k) {
-            const WinEntry *e = s_tab + (gi * K + k) * 5;
-            const WinEntry e0 = e[0];
-            const int mode0 = __builtin_amdgcn_readfirstlane(e0.whm >> 16);
-            if (mode0 == WM_SKIP) continue;
+            const WinEntry *tab = s_tab + (sgi * K + k) * kNodes;
+            const WinEntry e16 = tab[0];
+            const int m16 = __builtin_amdgcn_readfirstlane(e16.whm >> 16);
+            if (m16 == WM_SKIP) continue;
             const float *hm = s_h[k];
             const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
             const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
             const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
             const float *sb = a.src + (size_t)b * a.ext.src_bs + (size_t)k * N * kC;
-            if (mode0 == WM_WINDOW) {
-                __syncthreads();  // every wave is done with the previous window
-                stage(e0, sb);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                const int wx0 = e0.xy & 0xffff, wy0 = e0.xy >> 16, wneed = e0.whm & 0xff, hneed = (e0.whm >> 8) & 0xff;
+            auto depth_of = [&](int j) {  // plane j of this super-group (clamped to the last real plane)
+                const int dj = min(dbase + j, D - 1);
+                return pl ? pl[(size_t)dj * a.ext.planes_sd] : s_planes[dj];
+            };
+            auto add_unit = [&](int u, const float4 &r) {  // acc[u] += r with a run-time u (keeps acc in registers)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < nd) acc[j] += cv_sample<true>(cv_project(depth[j], qx, qy, qz, hm, Wf, Hf, W, H), s_win, wx0, wy0, wneed, hneed, sb, W, c);
-            } else {
-                for (int j = 0; j < nd; ++j) {
-                    const WinEntry e1 = e[1 + j];
-                    const int mode1 = __builtin_amdgcn_readfirstlane(e1.whm >> 16);
-                    if (mode1 == WM_SKIP) continue;
-                    const float dj = j == 0 ? depth[0] : (j == 1 ? depth[1] : (j == 2 ? depth[2] : depth[3]));
-                    const Sample s = cv_project(dj, qx, qy, qz, hm, Wf, Hf, W, H);
-                    float v;
-                    if (mode1 == WM_WINDOW) {
-                        __syncthreads();
-                        stage(e1, sb);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
-                        v = cv_sample<true>(s, s_win, e1.xy & 0xffff, e1.xy >> 16, e1.whm & 0xff, (e1.whm >> 8) & 0xff, sb, W, c);
-                    } else {
-                        v = cv_sample<false>(s, s_win, 0, 0, 0, 0, sb, W, c);
+                for (int i = 0; i < 4; ++i) {
+                    const bool m = (u == i);
+                    acc[i].x += m ? r.x : 0.f; acc[i].y += m ? r.y : 0.f; acc[i].z += m ? r.z : 0.f; acc[i].w += m ? r.w : 0.f;
+                }
+            };
+            // a run of 4-plane units [u0, u0+nu) served by ONE window
+            auto run = [&](const WinEntry &e, int u0, int nu) {
+#ifndef IDH_ABL_NOBARRIER
+                __syncthreads();  // every wave is done with the previous window
+#endif
+#ifndef IDH_ABL_NOSTAGE
+                stage(e, sb);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef IDH_ABL_NOBARRIER
+                __syncthreads();
+#endif
+#ifdef IDH_ABL_NOCOMPUTE
+                return;
+#endif
+                const int wx0 = e.xy & 0xffff, wy0 = e.xy >> 16, wneed = e.whm & 0xff, hneed = (e.whm >> 8) & 0xff;
+                for (int u = u0; u < u0 + nu; ++u) {
+                    if (4 * u >= nd) break;
+                    Sample sm[4];
+                    WinCell wc[4];
+                    float r[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sm[j] = cv_project(depth_of(4 * u + j), qx, qy, qz, hm, Wf, Hf, W, H);
+                        wc[j] = cv_cell(sm[j], wx0, wy0, wneed, hneed);
                     }
-                    acc[0] += j == 0 ? v : 0.f; acc[1] += j == 1 ? v : 0.f; acc[2] += j == 2 ? v : 0.f; acc[3] += j == 3 ? v : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = cv_sample_win(sm[j], wc[j], s_win, c);
+                    if (__builtin_amdgcn_ballot_w64(wc[0].fb || wc[1].fb || wc[2].fb || wc[3].fb) != 0) {  // rare: cells outside the window
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (wc[j].fb) r[j] = cv_sample_global(sm[j], sb, W, c);
+                    }
+                    add_unit(u, make_float4(r[0], r[1], r[2], r[3]));
+                }
+            };
+            const bool own16 = ulo == 0 && uhi == 4;
+            if (m16 == WM_WINDOW && own16) { run(e16, 0, 4); continue; }
+            for (int h8 = 0; h8 < 2; ++h8) {
+                if (2 * h8 + 2 <= ulo || 2 * h8 >= uhi) continue;  // not this workgroup's planes
+                const WinEntry e8 = tab[1 + h8];
+                const int m8 = __builtin_amdgcn_readfirstlane(e8.whm >> 16);
+                if (m8 == WM_SKIP) continue;
+                const bool own8 = 2 * h8 >= ulo && 2 * h8 + 2 <= uhi;
+                if (m8 == WM_WINDOW && own8) { run(e8, 2 * h8, 2); continue; }
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const int u = 2 * h8 + q4;
+                    if (u < ulo || u >= uhi) continue;
+                    const WinEntry e4 = tab[3 + u];
+                    const int m4 = __builtin_amdgcn_readfirstlane(e4.whm >> 16);
+                    if (m4 == WM_SKIP) continue;
+                    if (m4 == WM_WINDOW) { run(e4, u, 1); continue; }
+                    for (int j = 0; j < 4; ++j) {  // plane by plane: own window, or (behind the camera / oversized) global taps
+                        const WinEntry e1 = tab[7 + 4 * u + j];
+                        const int m1 = __builtin_amdgcn_readfirstlane(e1.whm >> 16);
+                        if (m1 == WM_SKIP) continue;
+                        const Sample sm = cv_project(depth_of(4 * u + j), qx, qy, qz, hm, Wf, Hf, W, H);
+                        float v;
+                        if (m1 == WM_WINDOW) {
+                            __syncthreads();
+                            stage(e1, sb);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                            const WinCell wc = cv_cell(sm, e1.xy & 0xffff, e1.xy >> 16, e1.whm & 0xff, (e1.whm >> 8) & 0xff);
+                            v = cv_sample_win(sm, wc, s_win, c);
+                            if (wc.fb) v = cv_sample_global(sm, sb, W, c);
+                        } else {
+                            v = cv_sample_global(sm, sb, W, c);
+                        }
+                        add_unit(u, make_float4(j == 0 ? v : 0.f, j == 1 ? v : 0.f, j == 2 ? v : 0.f, j == 3 ? v : 0.f));
+                    }
                 }
             }
         }
-        if (live) {
-            if (a.cost_cs > 0) {
-                float *o = a.cost + ((size_t)b * N + p) * a.cost_cs + dbase;
-                if (nd == 4 && (a.cost_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.cost) & 15) == 0)
-                    *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                else
-                    for (int j = 0; j < nd; ++j) o[j] = acc[j];
-            } else {
-                for (int j = 0; j < nd; ++j) a.cost[((size_t)b * D + dbase + j) * N + p] = acc[j];
-            }
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < nd && acc[j] > best) { best = acc[j]; bidx = dbase + j; }
+        for (int u = 0; u < 4; ++u) {
+            const int d0 = dbase + 4 * u, n4 = min(4, D - d0);
+            if (n4 <= 0) break;
+            if (u < ulo || u >= uhi) continue;
+            const float a4[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+            if (live) {
+                if (a.cost_cs > 0) {
+                    float *o = a.cost + ((size_t)b * N + p) * a.cost_cs + d0;
+                    if (n4 == 4 && (a.cost_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.cost) & 15) == 0) *reinterpret_cast<float4 *>(o) = acc[u];
+                    else
+                        for (int j = 0; j < n4; ++j) o[j] = a4[j];
+                } else {
+                    for (int j = 0; j < n4; ++j) a.cost[((size_t)b * D + d0 + j) * N + p] = a4[j];
+                }
+            }
+            for (int j = 0; j < n4; ++j)
+                if (a4[j] > best) { best = a4[j]; bidx = d0 + j; }
+        }
     }
     if (a.lowest != nullptr && a.psplit == 1 && live) a.lowest[(size_t)b * N + p] = pl ? pl[(size_t)bidx * a.ext.planes_sd] : s_planes[bidx];
 }
@@ -722,24 +794,29 @@ __global__ __launch_bounds__(256) void cv_argmax_k(const float *__restrict__ cos
 
 // plane split of the window kernel: keep the per-workgroup table inside kMaxPairs and give small batches enough
 // workgroups for 256 CUs x 3 (the arg-max then runs as a second, tiny kernel)
-static void cv_win_split(int B, int K, int H, int W, int D, int *psplit, int *groups_per_split) {
-    const int ngroups = (D + 3) / 4;
-    const long long tiles = (long long)B * idh_cdiv(W, kTile) * idh_cdiv(H, kTile);
-    int s = 1;
-    while (s < ngroups && (tiles * s < 768 || (long long)idh_cdiv(ngroups, s) * K > kMaxPairs)) ++s;
-    const int gps = idh_cdiv(ngroups, s);
-    *groups_per_split = gps;
-    *psplit = idh_cdiv(ngroups, gps);
+static void cv_win_split(int B, int K, int H, int W, int D, int *psplit, int *units_per_split) {
+    const int nunits = (D + 3) / 4;
+    const int nsg = (nunits + 3) / 4;
+    const long long tiles = (long long)B * idh_cdiv(W, kTileW) * idh_cdiv(H, kTileH);
+    // whole super-groups per workgroup (longest runs) unless that leaves CUs idle: then 8- or 4-plane slices
+    int per = 4 * nsg;  // units per workgroup
+    while (per > 4 && (tiles * idh_cdiv(nunits, per) < 768 || (long long)(per / 4) * K > kMaxPairs)) per = 4 * idh_cdiv(per / 4, 2);
+    if (per == 4 && tiles * idh_cdiv(nunits, per) < 512) per = 2;
+    if (per == 2 && tiles * idh_cdiv(nunits, per) < 512) per = 1;
+    *units_per_split = per;
+    *psplit = idh_cdiv(nunits, per);
 }
 
 // 0 = automatic; otherwise the caller's choice when that kernel covers the shape (else -1)
 static int cv_pick_kernel(int forced, int B, int K, int H, int W, int D) {
-    (void)B;
     const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;  // 32-bit tap offsets within one (b,k) image
-    const bool win_ok = quad_ok && W >= kWW && H >= kWH && W < 65536 && H < 32768 && (long long)K <= kMaxPairs;
+    const bool win_ok = quad_ok && W >= kWW && H >= kWH && W < 65536 && H < 32768 && K <= kMaxPairs;
     (void)D;
+    // measured (tools/perf_dot.py, 96x128 map, K=8, D=64): window 25 us/frame at B=32, 35 at B=8, 42 at B=4, 71 at B=1;
+    // quad 51 / 57 / 57 / 59 -> a single frame (48 tiles) cannot fill 256 CUs with whole tiles and stays on the quad kernel
+    const bool win_pays = (long long)B * idh_cdiv(W, kTileW) * idh_cdiv(H, kTileH) >= 96;
     switch (forced) {
-        case 0: return win_ok ? IDH_CV_KERNEL_WINDOW : (quad_ok ? IDH_CV_KERNEL_QUAD : IDH_CV_KERNEL_LANE);
+        case 0: return (win_ok && win_pays) ? IDH_CV_KERNEL_WINDOW : (quad_ok ? IDH_CV_KERNEL_QUAD : IDH_CV_KERNEL_LANE);
         case IDH_CV_KERNEL_LANE: return IDH_CV_KERNEL_LANE;
         case IDH_CV_KERNEL_QUAD: return quad_ok ? IDH_CV_KERNEL_QUAD : -1;
         case IDH_CV_KERNEL_WINDOW: return win_ok ? IDH_CV_KERNEL_WINDOW : -1;
@@ -786,9 +863,9 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
         a.cur = cur_nhwc; a.src = src_nhwc; a.src_K = src_K_44; a.src_E = src_E_44; a.cur_invK = cur_invK_44;
         a.cost = cost; a.lowest = lowest_bhw; a.planes_out = planes_d; a.dmin = dmin; a.dmax = dmax;
         a.B = B; a.K = K; a.H = H; a.W = W; a.D = D; a.cost_cs = cost_nhwc_cs; a.ext = ext;
-        a.tiles_x = idh_cdiv(W, kTile); a.tiles_y = idh_cdiv(H, kTile);
-        cv_win_split(B, K, H, W, D, &a.psplit, &a.groups_per_split);
-        const size_t lds = (size_t)kWinBytes + (size_t)a.groups_per_split * K * 5 * sizeof(WinEntry);
+        a.tiles_x = idh_cdiv(W, kTileW); a.tiles_y = idh_cdiv(H, kTileH);
+        cv_win_split(B, K, H, W, D, &a.psplit, &a.units_per_split);
+        const size_t lds = (size_t)kWinBytes + (size_t)((a.units_per_split + 3) / 4) * K * kNodes * sizeof(WinEntry);
         const long long blocks = (long long)B * a.tiles_x * a.tiles_y * a.psplit;
         if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
         hipLaunchKernelGGL(cv_dot_win_k, dim3((unsigned)blocks), dim3(256), lds, idh_stream(stream), a);

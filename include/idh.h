@@ -75,7 +75,7 @@ typedef struct idh_volume_opts {
 
 #define IDH_CV_KERNEL_LANE 1   /* cv_dot_k: one lane per sample, taps through the vector L1 */
 #define IDH_CV_KERNEL_QUAD 2   /* cv_dot_quad_k: four lanes per sample, quad-coalesced taps */
-#define IDH_CV_KERNEL_WINDOW 3 /* cv_dot_win_k: source windows staged in LDS (needs a map of >= 32 x 20 texels) */
+#define IDH_CV_KERNEL_WINDOW 3 /* cv_dot_win_k: source windows staged in LDS (needs a map of >= 48 x 12 texels) */
 
 /* ---- plane-sweep dot-product cost volume --------------------------------------- */
 /* Replaces CostVolumeManager.build_cost_volume + forward

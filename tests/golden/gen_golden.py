@@ -277,6 +277,24 @@ def gen_bdmodel(syn):
              keys=np.array(sorted(k for k in model.state_dict() if k.split(".")[0] in ("cost_volume", "cost_volume_net", "depth_decoder", "binary_mlp"))))
 
 
+def gen_g1_window():
+    """G1 case sized for the LDS-window kernel (map >= 64 x 12): B=2, K=7, one view behind the camera, one strongly
+    rotated, 28x72 map (ragged 32x8 tiles), D=12 (a partial 16-plane super-group).
+        python tests/golden/gen_golden.py g1_win
+    """
+    import_reference()
+    import implicit_depth_amd.synthetic as syn
+    from modules.cost_volume import CostVolumeManager
+
+    torch.set_grad_enabled(False)
+    print("G1 cost volume (dot), window-kernel shape")
+    B, K, C, H, W, D, seed, bv, rv = 2, 7, 16, 28, 72, 12, 6, 3, 5
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed, bv, rv)
+    cv, low, planes, mask = CostVolumeManager(H, W, D)(**inp)
+    save("g1_win_b2k7", dims=np.array([B, K, C, H, W, D, seed, bv, rv]), cost_volume=cv, lowest_cost=low, planes=planes[0, :, 0, 0],
+         in_chk=np.stack([chk(inp["cur_feats"]), chk(inp["src_feats"]), chk(inp["src_extrinsics"])]))
+
+
 def gen_custom_planes():
     """G13: both managers called with a caller-supplied per-pixel ``depth_planes_bdhw`` (cost_volume.py:324-347) and with
     per-sample (B,1,1,1) min/max depth tensors (generate_depth_planes broadcasts them, :98-132).
@@ -742,6 +760,8 @@ if __name__ == "__main__":
         gen_full_bdmodel()
     elif len(sys.argv) > 1 and sys.argv[1] == "g5_temporal":
         gen_full_temporal()
+    elif len(sys.argv) > 1 and sys.argv[1] == "g1_win":
+        gen_g1_window()
     elif len(sys.argv) > 1 and sys.argv[1] == "g13":
         gen_custom_planes()
     elif len(sys.argv) > 1 and sys.argv[1] == "g9_full":
@@ -753,3 +773,4 @@ if __name__ == "__main__":
         gen_full_temporal()
         gen_full_depthmodel()
         gen_custom_planes()
+        gen_g1_window()

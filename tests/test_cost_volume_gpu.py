@@ -211,23 +211,30 @@ KERNELS = {"lane": 1, "quad": 2, "window": 3}
 
 
 @pytest.mark.parametrize("kernel", ["lane", "quad", "window"])
-@pytest.mark.parametrize("name", ["g1_small", "g1_b2k7", "g1_ragged"])
+@pytest.mark.parametrize("name", ["g1_small", "g1_b2k7", "g1_ragged", "g1_win_b2k7"])
 def test_every_kernel_matches_reference_golden(name, kernel):
-    """g1_b2k7 has a view behind the camera and a strongly rotated one: the window kernel's per-lane global
-    fallback and its skip / split / global table modes are all exercised."""
+    """g1_b2k7 / g1_win_b2k7 have a view behind the camera and a strongly rotated one: the window kernel's per-lane
+    global fallback and its skip / descend / global table modes are all exercised.  The window kernel needs a map of at
+    least 48 x 12 texels; forcing it on a smaller one is an error, not a silent substitution."""
+    from implicit_depth_amd import _lib
+
     g = load_golden(name)
     B, K, C, H, W, D, seed, bv, rv = [int(v) for v in g["dims"]]
     inp = syn.cost_volume_inputs(B, K, C, H, W, seed, bv, rv)
+    if kernel == "window" and (W < 48 or H < 12):
+        with pytest.raises(_lib.IdhError):
+            _run(inp, D, KERNELS[kernel])
+        return
     cv, low, planes = _run(inp, D, KERNELS[kernel])
     assert rel_err(cv, g["cost_volume"]) < TOL
     assert _lowest_mismatch(low, g["lowest_cost"]) < 5e-3
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 16, 40, 50, 9), (1, 8, 16, 33, 47, 13), (3, 7, 16, 24, 32, 64), (1, 2, 16, 20, 32, 1),
-                                   (2, 16, 16, 37, 70, 6)])
+@pytest.mark.parametrize("shape", [(2, 3, 16, 40, 70, 9), (1, 8, 16, 33, 67, 13), (3, 7, 16, 24, 64, 64), (1, 2, 16, 12, 64, 1),
+                                   (2, 16, 16, 37, 90, 6), (1, 4, 16, 21, 130, 35)])
 def test_window_kernel_matches_oracle_fp64(shape):
-    """Ragged tiles (maps that are not multiples of 16), D not a multiple of 4, K up to 16, views behind the camera
-    and strongly rotated views, batch > 1."""
+    """Ragged tiles (maps that are not multiples of 32 x 8), D not a multiple of 16 or 4, K up to 16, views behind the
+    camera and strongly rotated views, batch > 1."""
     B, K, C, H, W, D = shape
     inp = syn.cost_volume_inputs(B, K, C, H, W, seed=B + K, behind_view=K - 1 if K > 2 else -1, big_rotation_view=0 if K > 3 else -1)
     cv, low, planes = _run(inp, D, KERNELS["window"])
@@ -248,7 +255,7 @@ def test_every_kernel_full_size_golden(kernel):
     cv, low, _ = _run(inp, D, KERNELS[kernel])
     assert rel_err(cv[:, ::4, ::6, ::8], g["cost_slice"]) < TOL
     s = cv.double()
-    np.testing.assert_allclose([s.sum().item(), s.abs().sum().item(), (s * s).sum().item()], g["cost_chk"], rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["cost_chk"][1:], rtol=1e-4)  # the plain sum cancels to 1e-3 of |.|
     assert _lowest_mismatch(low[:, ::3, ::4], g["lowest_slice"]) < 5e-3
 
 
@@ -258,7 +265,7 @@ def test_window_kernel_caller_planes_nhwc_output_and_strides():
     from implicit_depth_amd import _lib
     from implicit_depth_amd.cost_volume import CostVolumeManager, to_nhwc, volume_opts
 
-    B, K, C, H, W, D = 2, 3, 16, 40, 50, 8
+    B, K, C, H, W, D = 2, 3, 16, 40, 80, 8
     inp = {k: v.cuda() for k, v in syn.cost_volume_inputs(B, K, C, H, W, 3, 2, -1).items()}
     planes = syn.custom_depth_planes(B, D, H, W, seed=4).cuda()
     m = CostVolumeManager(H, W, D).cuda()
@@ -280,8 +287,9 @@ def test_window_kernel_caller_planes_nhwc_output_and_strides():
     pl = torch.empty(D, device="cuda")
     for kern in (2, 3):
         opts, keep = volume_opts(B, K, C, H, W, D, None, (K + 1) * hw, (K + 1) * hw, kernel=kern)
-        _lib.check(_lib.lib().idh_cost_volume_dot_ex_fwd(feats.data_ptr(), feats.data_ptr() + 4 * hw, inp["src_Ks"].data_ptr(), inp["src_extrinsics"].data_ptr(),
-                                                         inp["cur_invK"].data_ptr(), 0.25, 5.0, B, K, C, H, W, D, out.data_ptr(), D + 8, low.data_ptr(),
+        Ks, E, iK = (inp[k].contiguous() for k in ("src_Ks", "src_extrinsics", "cur_invK"))  # linalg.inv hands back column-major batches
+        _lib.check(_lib.lib().idh_cost_volume_dot_ex_fwd(feats.data_ptr(), feats.data_ptr() + 4 * hw, Ks.data_ptr(), E.data_ptr(),
+                                                         iK.data_ptr(), 0.25, 5.0, B, K, C, H, W, D, out.data_ptr(), D + 8, low.data_ptr(),
                                                          pl.data_ptr(), opts, _lib.stream_ptr()), "dot")
         m.kernel = kern
         want = m(**inp)

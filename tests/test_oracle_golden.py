@@ -367,3 +367,11 @@ def test_custom_depth_planes_and_per_sample_ranges_match_reference():
     assert rel_err(ocv.cost_volume_dot(*a, inp["src_Ks"], inp["cur_invK"], 0.0, 0.0, D, planes_bdhw=pl)[0], g["range_cost_volume"]) < 2e-5
     assert rel_err(ocv.feature_volume(*a, inp["src_poses"], inp["src_Ks"], inp["cur_invK"], 0.0, 0.0, D, w, planes_bdhw=pl)[0],
                    g["range_feature_volume"]) < 5e-5
+
+
+def test_cost_volume_dot_window_shape_matches_reference():
+    g = load_golden("g1_win_b2k7")
+    inp, D = _inputs(g)
+    cost, low, planes = ocv.cost_volume_dot(inp["cur_feats"], inp["src_feats"], inp["src_extrinsics"], inp["src_Ks"], inp["cur_invK"], 0.25, 5.0, D)
+    assert rel_err(cost, g["cost_volume"]) < 2e-5
+    assert ((low - torch.as_tensor(g["lowest_cost"])).abs() > 1e-6).float().mean().item() < 5e-3
