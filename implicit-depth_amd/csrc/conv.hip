@@ -222,7 +222,11 @@ struct LdsConvArgs {
     int tiles_x, tiles_y;  // spatial tiles per image
 };
 
-template <int RW>
+// UP: some K chunks come from x2-upsampled low-resolution maps (idh_conv_src.up_*): the loader fetches the four
+// low-resolution neighbours of every halo pixel and the commit blends them with exactly upsample2_k's expression
+// (bit-identical to materialising the upsampled tensor first), so F.interpolate + torch.cat cost no launch and no
+// HBM round trip.  Separate instantiation: the 4x register prefetch does not touch the plain kernel's occupancy.
+template <int RW, bool UP>
 __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned blk_in, unsigned nblk) {
     constexpr int kLT_H = 4 * RW, kHaloH = kLT_H + 2;
     constexpr int kASlots = kHaloH * 4 * kHaloW;  // 720 (RW=2) / 432 (RW=1) float4
@@ -263,9 +267,46 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     // ---- staging: global -> registers (prefetch) -> LDS -----------------------------------
     // A slots are enumerated (hy, hx, q) with q fastest so that 4 consecutive lanes read the 64
     // contiguous bytes of one pixel; the LDS image is [hy][q][hx].
-    f32x4 pa[kALoads], pb[9];
+    f32x4 pa[(UP ? 4 : 1) * kALoads], pb[9];
+    // low-resolution neighbours + weights of hi-res pixel (iy, ix) under x2 bilinear, align_corners=False
+    auto up_taps = [&](const ConvSrc &s, int c, int iy, int ix, int q, bool ok, const float *(&tp)[4]) {
+        const int rel = 16 * c - s.up_c0;
+        const int seg = rel >= s.up_C ? 1 : 0;
+        const int Hl = s.H >> 1, Wl = s.W >> 1, ucs = s.up_cs[seg];
+        const int yl = iy >> 1, xl = ix >> 1;
+        int y0, y1, x0, x1;
+        if (iy & 1) { y0 = yl; y1 = min(yl + 1, Hl - 1); } else { y0 = max(yl - 1, 0); y1 = yl; }
+        if (ix & 1) { x0 = xl; x1 = min(xl + 1, Wl - 1); } else { x0 = max(xl - 1, 0); x1 = xl; }
+        const float *b = s.up_in[seg] + (size_t)n * Hl * Wl * ucs + (rel - seg * s.up_C) + 4 * q;
+        tp[0] = ok ? b + ((size_t)y0 * Wl + x0) * ucs : g_zero_page;
+        tp[1] = ok ? b + ((size_t)y0 * Wl + x1) * ucs : g_zero_page;
+        tp[2] = ok ? b + ((size_t)y1 * Wl + x0) * ucs : g_zero_page;
+        tp[3] = ok ? b + ((size_t)y1 * Wl + x1) * ucs : g_zero_page;
+    };
+    auto up_blend = [&](int iy, int ix, const f32x4 &p00, const f32x4 &p01, const f32x4 &p10, const f32x4 &p11) {
+        const float hy0 = (iy & 1) ? 0.75f : 0.25f, hy1 = (iy & 1) ? 0.25f : 0.75f;
+        const float wx0 = (ix & 1) ? 0.75f : 0.25f, wx1 = (ix & 1) ? 0.25f : 0.75f;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = hy0 * (wx0 * p00[e] + wx1 * p01[e]) + hy1 * (wx0 * p10[e] + wx1 * p11[e]);  // == upsample2_k
+        return o;
+    };
     auto issue3 = [&](int c) {  // 3x3 source 0, chunk c
         const ConvSrc &s = a.s[0];
+        if (UP && s.up_in[0] != nullptr && 16 * c >= s.up_c0) {
+#pragma unroll
+            for (int k = 0; k < kALoads; ++k) {
+                const int slot = tid + 256 * k;
+                const int q = slot & 3, pix = slot >> 2;
+                const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
+                const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+                const bool ok = (slot < kASlots) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+                const float *tp[4];
+                up_taps(s, c, iy, ix, q, ok, tp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pa[(UP ? 4 : 1) * k + (UP ? e : 0)] = *reinterpret_cast<const f32x4 *>(tp[e]);
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < kALoads; ++k) {
             const int slot = tid + 256 * k;
@@ -274,7 +315,8 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             const int iy = y0 + hy - 1, ix = x0 + hx - 1;
             const bool ok = (slot < kASlots) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
             const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
-            pa[k] = *reinterpret_cast<const f32x4 *>(p);
+            pa[(UP ? 4 : 1) * k] = *reinterpret_cast<const f32x4 *>(p);
+        }
         }
         const float *wb = s.w + ((size_t)(4 * c) * a.Cout_pad + n0) * 4;
 #pragma unroll
@@ -283,13 +325,16 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             pb[k] = *reinterpret_cast<const f32x4 *>(p);
         }
     };
-    auto commit3 = [&]() {
+    auto commit3 = [&](int c) {
+        const bool up = UP && a.s[0].up_in[0] != nullptr && 16 * c >= a.s[0].up_c0;
 #pragma unroll
         for (int k = 0; k < kALoads; ++k) {
             const int slot = tid + 256 * k;
             const int q = slot & 3, pix = slot >> 2;
             const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
-            if (slot < kASlots) sA[(hy * 4 + q) * kHaloW + hx] = pa[k];
+            f32x4 v = pa[(UP ? 4 : 1) * k];
+            if (UP && up) v = up_blend(y0 + hy - 1, x0 + hx - 1, pa[4 * k], pa[4 * k + 1], pa[4 * k + 2], pa[4 * k + 3]);
+            if (slot < kASlots) sA[(hy * 4 + q) * kHaloW + hx] = v;
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) sB[k * 256 + tid] = pb[k];
@@ -315,6 +360,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     // 1x1 source 1: A = the centre pixels of the tile (kCLoads float4 per thread), B = 4 x 64 float4
     auto issue1 = [&](int c) {
         const ConvSrc &s = a.s[1];
+        const bool up = UP && s.up_in[0] != nullptr && 16 * c >= s.up_c0;
 #pragma unroll
         for (int k = 0; k < kCLoads; ++k) {
             const int slot = tid + 256 * k;
@@ -322,18 +368,28 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             const int py = pix >> 4, px = pix & 15;
             const int iy = y0 + py, ix = x0 + px;
             const bool ok = (iy < s.H) & (ix < s.W);
-            const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
-            pa[k] = *reinterpret_cast<const f32x4 *>(p);
+            if (UP && up) {
+                const float *tp[4];
+                up_taps(s, c, iy, ix, q, ok, tp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pa[4 * k + e] = *reinterpret_cast<const f32x4 *>(tp[e]);
+            } else {
+                const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
+                pa[(UP ? 4 : 1) * k] = *reinterpret_cast<const f32x4 *>(p);
+            }
         }
         pb[0] = *reinterpret_cast<const f32x4 *>(s.w + ((size_t)(4 * c + (tid >> 6)) * a.Cout_pad + n0 + (tid & 63)) * 4);
     };
-    auto commit1 = [&]() {
+    auto commit1 = [&](int c) {
+        const bool up = UP && a.s[1].up_in[0] != nullptr && 16 * c >= a.s[1].up_c0;
 #pragma unroll
         for (int k = 0; k < kCLoads; ++k) {
             const int slot = tid + 256 * k;
             const int q = slot & 3, pix = slot >> 2;
             const int py = pix >> 4, px = pix & 15;
-            sA[((py + 1) * 4 + q) * kHaloW + px + 1] = pa[k];
+            f32x4 v = pa[(UP ? 4 : 1) * k];
+            if (UP && up) v = up_blend(y0 + py, x0 + px, pa[4 * k], pa[4 * k + 1], pa[4 * k + 2], pa[4 * k + 3]);
+            sA[((py + 1) * 4 + q) * kHaloW + px + 1] = v;
         }
         sB[tid] = pb[0];
     };
@@ -359,7 +415,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
 #pragma unroll 1
         for (int c = lo; c < hi; ++c) {
             __syncthreads();  // every wave is done reading the previous chunk's LDS image
-            commit3();
+            commit3(c);
             __syncthreads();
             if (c + 1 < hi) issue3(c + 1);  // in flight under the 288 MFMAs below
             compute3();
@@ -372,7 +428,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
 #pragma unroll 1
         for (int c = lo; c < hi; ++c) {
             __syncthreads();
-            commit1();
+            commit1(c);
             __syncthreads();
             if (c + 1 < hi) issue1(c + 1);
             compute1();
@@ -408,9 +464,14 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     }
 }
 
-template <int RW>
+template <int RW, bool UP>
 __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
-    conv3x3_lds_body<RW>(la, blockIdx.x, gridDim.x);
+    conv3x3_lds_body<RW, UP>(la, blockIdx.x, gridDim.x);
+}
+// fused-upsample variants: keep 3 workgroups / CU (what the LDS footprint allows) although the 4x prefetch wants ~180 VGPRs
+template <int RW>
+__global__ __launch_bounds__(256, 3) void conv3x3_lds_up_k(const LdsConvArgs la) {
+    conv3x3_lds_body<RW, true>(la, blockIdx.x, gridDim.x);
 }
 
 // Grouped launch: up to kMaxGroup INDEPENDENT convolutions (same dependency level of a plan, see
@@ -424,12 +485,12 @@ struct LdsGroupArgs {
     LdsConvArgs op[kMaxGroup];
 };
 
-template <int RW>
+template <int RW, bool UP>
 __global__ __launch_bounds__(256) void conv3x3_lds_group_k(const LdsGroupArgs g) {
     int idx = 0;
     for (int i = 1; i < g.n; ++i)
         if (blockIdx.x >= g.start[i]) idx = i;
-    conv3x3_lds_body<RW>(g.op[idx], blockIdx.x - g.start[idx], g.start[idx + 1] - g.start[idx]);
+    conv3x3_lds_body<RW, UP>(g.op[idx], blockIdx.x - g.start[idx], g.start[idx + 1] - g.start[idx]);
 }
 
 struct ReduceDesc {
@@ -692,12 +753,14 @@ struct PreparedConv {
     int lds_rows, tm, tn;  // lds_rows = 16: split-precision kernel, tm = IDH_SPLIT_* mode
     int n_img;
     unsigned blocks;
+    bool up;         // some source has fused x2-upsampled segments (LDS kernels only)
     ReduceDesc red;  // valid when a.S > 1
 };
 
 int prep_conv(const idh_op &op, PreparedConv &pc) {
     ConvArgs &a = pc.a;
     a = ConvArgs{};
+    pc.up = false;
     int steps = 0;
     for (int i = 0; i < 2; ++i) {
         const idh_conv_src &s = op.src[i];
@@ -706,7 +769,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         if (!s.in) continue;
         // the K loop reads whole 16-channel blocks: the buffer must be readable (and finite) up to
         // ceil16(Cin) channels per pixel; packed weights are zero there.
-        if (!s.w || s.Cin <= 0 || s.cs < ceil16(s.Cin) || (s.cs & 3) || (s.ks != 1 && s.ks != 3) ||
+        if (!s.w || s.Cin <= 0 || s.cs < (s.up_in[0] ? s.up_c0 : ceil16(s.Cin)) || (s.cs & 3) || (s.ks != 1 && s.ks != 3) ||
             (s.stride != 1 && s.stride != 2) || s.H <= 0 || s.W <= 0)
             return IDH_EINVAL;
         if (ceil16(s.Cin) > kZeroFloats) return IDH_EUNSUPPORTED;
@@ -715,6 +778,16 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
             return IDH_EINVAL;
         d.w = s.w; d.cs = s.cs; d.H = s.H; d.W = s.W; d.Cin = s.Cin; d.ks = s.ks; d.stride = s.stride;
         d.pad_mode = s.pad_mode; d.cblocks = ceil16(s.Cin) / 16;
+        d.up_in[0] = s.up_in[0]; d.up_in[1] = s.up_in[1]; d.up_cs[0] = s.up_cs[0]; d.up_cs[1] = s.up_cs[1];
+        d.up_c0 = s.up_c0; d.up_C = s.up_C;
+        if (s.up_in[0]) {
+            const int nseg = s.up_in[1] ? 2 : 1;
+            if (s.up_c0 < 0 || (s.up_c0 & 15) || s.up_C <= 0 || (s.up_C & 15) || s.up_c0 + nseg * s.up_C != s.Cin || (s.H & 1) || (s.W & 1) ||
+                s.stride != 1 || (s.up_c0 > 0 && s.cs < s.up_c0) || s.up_cs[0] < s.up_C || (s.up_cs[0] & 3) ||
+                (nseg == 2 && (s.up_cs[1] < s.up_C || (s.up_cs[1] & 3))))
+                return IDH_EINVAL;
+            pc.up = true;
+        }
         steps += s.ks * s.ks * d.cblocks;
     }
     if (!a.s[0].in || !op.out || op.Cout <= 0 || op.N <= 0) return IDH_EINVAL;
@@ -769,6 +842,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         if ((waves + 3) / 4 >= (1ll << 31)) return IDH_EUNSUPPORTED;
         pc.blocks = (unsigned)((waves + 3) / 4);
     }
+    if (pc.up && pc.lds_rows != 8 && pc.lds_rows != 4) return IDH_EUNSUPPORTED;  // fused upsampling lives in the LDS loader
     if (a.S > 1) {
         if (!op.ws) return IDH_EWORKSPACE;
         pc.red = ReduceDesc{op.ws, op.bias, op.res, op.out, a.M, op.Cout, a.Cout_pad, a.S, op.res_cs, op.out_cs, op.act, op.slope};
@@ -778,8 +852,10 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
 
 int launch_conv(const PreparedConv &pc, hipStream_t st) {
     if (pc.lds_rows == 16) return launch_conv_split(pc.a, pc.n_img, pc.tm, pc.tn, st);
-    if (pc.lds_rows == 8) hipLaunchKernelGGL(conv3x3_lds_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
-    else if (pc.lds_rows == 4) hipLaunchKernelGGL(conv3x3_lds_k<1>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    if (pc.lds_rows == 8 && pc.up) hipLaunchKernelGGL(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8) hipLaunchKernelGGL((conv3x3_lds_k<2, false>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.up) hipLaunchKernelGGL(conv3x3_lds_up_k<1>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4) hipLaunchKernelGGL((conv3x3_lds_k<1, false>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else {
 #define IDH_CASE(TM_, TN_) \
     if (pc.tm == TM_ && pc.tn == TN_) hipLaunchKernelGGL((conv_mfma_k<TM_, TN_>), dim3(pc.blocks), dim3(256), 0, st, pc.a);
@@ -819,7 +895,10 @@ int launch_group(const PreparedConv *pcs, int n, hipStream_t st) {
         cursor += pcs[i].blocks;
     }
     g.start[n] = cursor;
-    hipLaunchKernelGGL(conv3x3_lds_group_k<1>, dim3(cursor), dim3(256), 0, st, g);
+    bool any_up = false;
+    for (int i = 0; i < n; ++i) any_up = any_up || pcs[i].up;
+    if (any_up) hipLaunchKernelGGL((conv3x3_lds_group_k<1, true>), dim3(cursor), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((conv3x3_lds_group_k<1, false>), dim3(cursor), dim3(256), 0, st, g);
     IDH_CHECK_LAUNCH();
     return launch_reduces(pcs, n, st);
 }

@@ -12,6 +12,10 @@ struct ConvSrc {
     const float *w;
     int cs, H, W, Cin;
     int ks, stride, pad_mode, cblocks;  // cblocks = Cin_pad / 16
+    // fused x2-upsampled segments of a virtual concat (idh_conv_src.up_*); up_in[0] == nullptr: none
+    const float *up_in[2];
+    int up_cs[2];
+    int up_c0, up_C;
 };
 
 struct ConvArgs {

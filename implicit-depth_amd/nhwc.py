@@ -32,7 +32,8 @@ PAD_ZEROS, PAD_REPLICATE = 0, 1
 
 class ConvSrc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("w", C.c_void_p), ("cs", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("Cin", C.c_int32), ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("_r", C.c_int32)]
+                ("Cin", C.c_int32), ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("_r", C.c_int32),
+                ("up_in", C.c_void_p * 2), ("up_cs", C.c_int32 * 2), ("up_c0", C.c_int32), ("up_C", C.c_int32)]
 
 
 class Op(C.Structure):
@@ -80,6 +81,32 @@ class View:
 
     def dense(self) -> torch.Tensor:
         return self.buf[..., self.c0 : self.c0 + self.C]
+
+
+@dataclass
+class CatView:
+    """``torch.cat([direct, upsample(ups[0]), upsample(ups[1])], 1)`` that is never materialised: the consumer conv
+    reads ``direct`` as it is and interpolates the x2 bilinear upsampling of the low-resolution ``ups`` maps while it
+    stages its halo (idh_conv_src.up_*; reference networks.py:64-76 + generic_utils.py:94-103)."""
+
+    direct: View
+    ups: List[View]
+
+    @property
+    def N(self):
+        return self.direct.N
+
+    @property
+    def H(self):
+        return self.direct.H
+
+    @property
+    def W(self):
+        return self.direct.W
+
+    @property
+    def C(self):
+        return self.direct.C + sum(u.C for u in self.ups)
 
 
 def ceil16(v: int) -> int:
@@ -186,6 +213,16 @@ def choose_split_rows(N: int, Ho: int, Wo: int, cout: int) -> int:
     return 16 if Ho >= 16 and eff(16, 1.0) >= eff(8, 0.93) else 8
 
 
+# Decoder concats: optionally fold the x2 upsampling (and the concat itself) into the consumer conv's halo loader
+# instead of running upsample2_k into a concat buffer.  Bit-identical, 16 launches and ~1 GB of HBM traffic less per
+# 32-frame step — and SLOWER on MI355X (tools/perf_up.py, profiles/r02/fused_upsample_experiment.txt: 82.2 ms
+# materialised vs 91.0 ms fused with 8-row tiles / 85.8 ms with 4-row tiles at B=32; 4.10 vs 4.16 ms at B=1): the 4x
+# register prefetch of the loader either spills (8-row tile) or costs the tile's operand reuse (4-row), which outweighs
+# the 2.6 ms upsample2_k takes at HBM speed.  Off by default; FUSED_UP_ROWS = tile rows of the convs that read such a
+# concat.
+FUSE_UPSAMPLE = False
+FUSED_UP_ROWS = 4
+
 TARGET_WAVES = 2048  # ~2 waves per SIMD over 256 CUs x 4 SIMDs
 MIN_WAVES = 1024
 
@@ -268,7 +305,14 @@ class Plan:
             ks, st = cv.kernel_size[0], cv.stride[0]
             if v.C != cv.in_channels:
                 raise _lib.IdhError(f"conv expects {cv.in_channels} input channels, view has {v.C}")
-            if v.C % 16 and (v.c0 != 0 or v.cs != ceil16(v.C)):
+            cat = v if isinstance(v, CatView) else None
+            if cat is not None:
+                if use_split or not lds_eligible(srcs, conv.out_channels, out.W, pad_mode) or st != 1:
+                    raise _lib.IdhError("a fused-upsample concat can only feed the LDS-staged fp32 conv kernel")
+                if cat.direct.C % 16 or any(u.C != cat.ups[0].C or u.C % 16 or (2 * u.H, 2 * u.W) != (cat.H, cat.W) for u in cat.ups) or not 1 <= len(cat.ups) <= 2:
+                    raise _lib.IdhError("fused-upsample concat: channel counts must be multiples of 16 and the maps exactly half size")
+                v = cat.direct
+            elif v.C % 16 and (v.c0 != 0 or v.cs != ceil16(v.C)):
                 raise _lib.IdhError("a conv input whose channel count is not a multiple of 16 must be a whole zero-padded buffer")
             if use_split:  # one blob: [3x3 panels][1x1 panels of the second source][scales]
                 w = split_packed_weight(conv, self.math, conv2)
@@ -276,9 +320,14 @@ class Plan:
                 w = packed_weight(cv)
             self.keep.append(w)
             s = op.src[i]
-            s.in_, s.w, s.cs, s.H, s.W, s.Cin = v.ptr, w.data_ptr(), v.cs, v.H, v.W, v.C
+            cin = cat.C if cat is not None else v.C
+            s.in_, s.w, s.cs, s.H, s.W, s.Cin = v.ptr, w.data_ptr(), v.cs, v.H, v.W, cin
             s.ks, s.stride, s.pad_mode = ks, st, pad_mode
-            steps += ks * ks * (ceil16(v.C) // 16)
+            if cat is not None:
+                s.up_c0, s.up_C = cat.direct.C, cat.ups[0].C
+                for ui, u in enumerate(cat.ups):
+                    s.up_in[ui], s.up_cs[ui] = u.ptr, u.cs
+            steps += ks * ks * (ceil16(cin) // 16)
             self.flops += 2 * out.N * out.H * out.W * cv.out_channels * cv.in_channels * ks * ks
         bias = conv.bias
         if conv2 is not None and conv2.bias is not None:
@@ -298,6 +347,8 @@ class Plan:
         elif lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
             chunks = sum(ceil16(v.C) // 16 for v, _ in srcs)
             tm, split = choose_lds_tile(out.N, out.H, out.W, conv.out_channels, chunks)
+            if tm == 8 and FUSED_UP_ROWS == 4 and any(isinstance(v, CatView) for v, _ in srcs):
+                tm = 9
             tn = 0
         else:
             tm, tn, split = choose_tiles(M, conv.out_channels, steps)
@@ -307,7 +358,12 @@ class Plan:
             self.keep.append(ws)
             op.ws = ws.data_ptr()
         self.ops.append(op)
-        reads = [_region(v, pad16=True) for v, _ in srcs] + ([_region(res)] if res is not None else [])
+        reads = ([_region(res)] if res is not None else [])
+        for v, _ in srcs:
+            if isinstance(v, CatView):
+                reads += [_region(v.direct)] + [_region(u) for u in v.ups]
+            else:
+                reads.append(_region(v, pad16=True))
         self.meta.append({"reads": reads, "writes": [_region(out)]})
         self._arr = None
         return out
@@ -606,16 +662,27 @@ def build_decoder(p: Plan, dec, feats: List[View]):
             cout = right.conv1.out_channels
             has_up = (i + j) != 4
             xi = prev[i]
-            cat = p.buffer(xi.N, xi.H, xi.W, cout * (3 if has_up else 2))
-            p.basic_block(xi, right, out=cat.slice(0, cout))
-            lo = p.basic_block(prev[i + 1], diag)
-            if (lo.H * 2, lo.W * 2) != (xi.H, xi.W):
-                raise _lib.IdhError("decoder pyramid levels must differ by exactly x2")
-            p.upsample2(lo, cat.slice(cout, cout))
-            if has_up:
-                lo2 = p.basic_block(outputs[-1], dec.convs[f"up_conv_{i + 1}{j}"])
-                p.upsample2(lo2, cat.slice(2 * cout, cout))
             seq = dec.convs[f"in_conv_{i}{j}"]
+            fuse = (FUSE_UPSAMPLE and p.math == "fp32" and cout % 16 == 0 and xi.W >= 16 and
+                    lds_eligible([(xi, seq[0].conv1)], seq[0].conv1.out_channels, xi.W, PAD_ZEROS) and seq[0].downsample is not None and
+                    seq[0].downsample[0].kernel_size[0] == 1)
+            if fuse:  # torch.cat + F.interpolate live in the consumer's loader
+                r = p.basic_block(xi, right)
+                lo = p.basic_block(prev[i + 1], diag)
+                if (lo.H * 2, lo.W * 2) != (xi.H, xi.W):
+                    raise _lib.IdhError("decoder pyramid levels must differ by exactly x2")
+                ups = [lo] + ([p.basic_block(outputs[-1], dec.convs[f"up_conv_{i + 1}{j}"])] if has_up else [])
+                cat = CatView(r, ups)
+            else:
+                cat = p.buffer(xi.N, xi.H, xi.W, cout * (3 if has_up else 2))
+                p.basic_block(xi, right, out=cat.slice(0, cout))
+                lo = p.basic_block(prev[i + 1], diag)
+                if (lo.H * 2, lo.W * 2) != (xi.H, xi.W):
+                    raise _lib.IdhError("decoder pyramid levels must differ by exactly x2")
+                p.upsample2(lo, cat.slice(cout, cout))
+                if has_up:
+                    lo2 = p.basic_block(outputs[-1], dec.convs[f"up_conv_{i + 1}{j}"])
+                    p.upsample2(lo2, cat.slice(2 * cout, cout))
             y = p.basic_block(cat, seq[0])
             y = p.basic_block(y, seq.conv_0)
             outputs.append(y)

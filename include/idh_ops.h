@@ -42,6 +42,15 @@ typedef struct idh_conv_src {
     const float *w;  /* packed by idh_pack_conv_weight: [ks*ks][Cin_pad/4][Cout_pad][4] */
     int32_t cs, H, W, Cin;
     int32_t ks, stride, pad_mode, _r;
+    /* Virtual concat with fused bilinear x2 (the UNet++ decoder's torch.cat([x, upsample(a), upsample(b)], 1),
+     * networks.py:64-76): channels [0, up_c0) come from `in`; channels [up_c0 + i*up_C, up_c0 + (i+1)*up_C) are the
+     * x2 bilinear upsampling (align_corners=False, generic_utils.py:94-103) of up_in[i], an NHWC map of (H/2, W/2)
+     * with channel stride up_cs[i], interpolated while the consumer conv stages its halo — the upsampled tensor and
+     * the concat buffer are never written.  up_in[0] == NULL: plain source.  LDS-staged 3x3 / fused 1x1 sources
+     * only; up_c0 and up_C multiples of 16, H and W even, Cin == up_c0 + n_segments * up_C. */
+    const float *up_in[2];
+    int32_t up_cs[2];
+    int32_t up_c0, up_C;
 } idh_conv_src;
 
 typedef struct idh_op {

@@ -157,3 +157,34 @@ def test_skip_decoder_golden(reg):
     assert sorted(out) == sorted(k for k in g if k != "keys")
     for k in out:
         assert rel_err(out[k].cpu(), g[k]) < TOL, k
+
+
+def test_fused_upsample_concat_is_bit_identical_to_materialised():
+    """nhwc.FUSE_UPSAMPLE: the decoder's x2 bilinear upsampling + concat interpolated inside the consumer conv's halo
+    loader (idh_conv_src.up_*) instead of upsample2_k writing a concat buffer — same blend expression, so the outputs
+    must be bit-identical (B=2: 8-row tiles at the top level, 4-row + grouped launches below)."""
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd import nhwc
+
+    dec = net.BDDecoderPP([24, 64, 128, 256, 384])
+    syn.fill_state_dict(dec, seed=21)
+    dec.cuda()
+    pyr = syn.encoder_pyramid(2, 256, 384, seed=5, channels=(24, 64, 128, 256, 384))
+    feats = [t.cuda() for t in pyr]
+    old = nhwc.FUSE_UPSAMPLE, nhwc.FUSED_UP_ROWS
+    try:
+        outs = {}
+        for fuse, rows in ((False, 8), (True, 8), (True, 4)):
+            nhwc.FUSE_UPSAMPLE, nhwc.FUSED_UP_ROWS = fuse, rows
+            dec.__dict__.pop("_idh_plans", None)
+            outs[(fuse, rows)] = {k: v.clone() for k, v in dec(feats).items()}
+            plan = next(iter(dec.__dict__["_idh_plans"].values()))[0]
+            n_up = sum(1 for op in plan.ops if op.kind == nhwc.OP_UPSAMPLE2)
+            fused_srcs = sum(1 for op in plan.ops if op.kind == nhwc.OP_CONV and (op.src[0].up_in[0] or op.src[1].up_in[0]))
+            assert (n_up == 0 and fused_srcs > 0) if fuse else (n_up > 0 and fused_srcs == 0)
+    finally:
+        nhwc.FUSE_UPSAMPLE, nhwc.FUSED_UP_ROWS = old
+        dec.__dict__.pop("_idh_plans", None)
+    for key in ((True, 8), (True, 4)):
+        for k, v in outs[(False, 8)].items():
+            assert torch.equal(outs[key][k], v), (key, k)
