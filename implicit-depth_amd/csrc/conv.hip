@@ -213,9 +213,8 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
 //   B in LDS: [tap 9][q 4][co 64] float4
 // RW = tile rows per wave: RW = 2 -> 8x16 tile (best operand reuse), RW = 1 -> 4x16 tile (twice the
 // workgroups: used when an 8-row grid cannot fill 256 CUs x 3 resident workgroups).
-constexpr int kLT_W = 16, kLT_N = 64;
+constexpr int kLT_W = 16;
 constexpr int kHaloW = kLT_W + 2;
-constexpr int kBSlots3 = 9 * 4 * kLT_N;       // 2304 float4
 
 struct LdsConvArgs {
     ConvArgs c;
@@ -226,14 +225,20 @@ struct LdsConvArgs {
 // low-resolution neighbours of every halo pixel and the commit blends them with exactly upsample2_k's expression
 // (bit-identical to materialising the upsampled tensor first), so F.interpolate + torch.cat cost no launch and no
 // HBM round trip.  Separate instantiation: the 4x register prefetch does not touch the plain kernel's occupancy.
-template <int RW, bool UP>
+// NJ = 16-channel output sub-tiles per workgroup: 4 (64 channels, the default), 2 or 1 — narrow layers (the matching
+// encoder's 128 -> 16 conv) and small maps at small batch (twice / four times the workgroups) use the narrower tiles;
+// the staged halo is then amortised over fewer MFMAs but still feeds all 9 taps from one HBM/L2 read.
+template <int RW, bool UP, int NJ>
 __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned blk_in, unsigned nblk) {
+    constexpr int kN = 16 * NJ;                  // output channels per workgroup
+    constexpr int kBSlots3 = 9 * 4 * kN;         // weight panel of one 16-channel chunk, float4
+    constexpr int kBLoads = (kBSlots3 + 255) / 256;
     constexpr int kLT_H = 4 * RW, kHaloH = kLT_H + 2;
     constexpr int kASlots = kHaloH * 4 * kHaloW;  // 720 (RW=2) / 432 (RW=1) float4
     constexpr int kALoads = (kASlots + 255) / 256;
     constexpr int kCLoads = (kLT_H * kLT_W * 4) / 256;  // centre pixels for the 1x1 source
     __shared__ f32x4 sA[kASlots];
-    __shared__ f32x4 sB[kBSlots3];
+    __shared__ f32x4 sB[kBSlots3];  // 36 KiB at NJ = 4
     const ConvArgs &a = la.c;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -250,13 +255,14 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     const int n = blk % N_img;
     const int sp = blk / N_img;
     const int y0 = ty * kLT_H, x0 = tx * kLT_W;
-    const int n0 = nt * kLT_N;
+    const int n0 = nt * kN;
+    const bool replicate = a.s[0].pad_mode == IDH_PAD_REPLICATE;  // nn.Conv2d(padding_mode="replicate"): clamp instead of the zero page
 
-    f32x4 acc[RW][4];
+    f32x4 acc[RW][NJ];
 #pragma unroll
     for (int i = 0; i < RW; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // chunk list = [source-0 chunks][source-1 chunks]; this block's split owns [t0,t1)
     const int nc0 = a.s[0].cblocks;
@@ -267,7 +273,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     // ---- staging: global -> registers (prefetch) -> LDS -----------------------------------
     // A slots are enumerated (hy, hx, q) with q fastest so that 4 consecutive lanes read the 64
     // contiguous bytes of one pixel; the LDS image is [hy][q][hx].
-    f32x4 pa[(UP ? 4 : 1) * kALoads], pb[9];
+    f32x4 pa[(UP ? 4 : 1) * kALoads], pb[kBLoads];
     // low-resolution neighbours + weights of hi-res pixel (iy, ix) under x2 bilinear, align_corners=False
     auto up_taps = [&](const ConvSrc &s, int c, int iy, int ix, int q, bool ok, const float *(&tp)[4]) {
         const int rel = 16 * c - s.up_c0;
@@ -312,16 +318,20 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             const int slot = tid + 256 * k;
             const int q = slot & 3, pix = slot >> 2;
             const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
-            const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-            const bool ok = (slot < kASlots) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            int iy = y0 + hy - 1, ix = x0 + hx - 1;
+            bool ok = (slot < kASlots) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            if (replicate) { iy = min(max(iy, 0), s.H - 1); ix = min(max(ix, 0), s.W - 1); ok = slot < kASlots; }
             const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
             pa[(UP ? 4 : 1) * k] = *reinterpret_cast<const f32x4 *>(p);
         }
         }
         const float *wb = s.w + ((size_t)(4 * c) * a.Cout_pad + n0) * 4;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {  // slot = (tap k, q = tid>>6, co = tid&63)
-            const float *p = wb + ((size_t)(k * s.cblocks * 4 + (tid >> 6)) * a.Cout_pad + (tid & 63)) * 4;
+        for (int k = 0; k < kBLoads; ++k) {  // slot = ((tap * 4 + q) * kN + co); NJ = 4: tap k, q = tid >> 6, co = tid & 63
+            const int slot = tid + 256 * k;
+            const int co = slot % kN, tq = slot / kN;
+            const int tap = tq >> 2, q = tq & 3;
+            const float *p = (slot < kBSlots3) ? wb + ((size_t)(tap * s.cblocks * 4 + q) * a.Cout_pad + co) * 4 : g_zero_page;
             pb[k] = *reinterpret_cast<const f32x4 *>(p);
         }
     };
@@ -337,23 +347,24 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             if (slot < kASlots) sA[(hy * 4 + q) * kHaloW + hx] = v;
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) sB[k * 256 + tid] = pb[k];
+        for (int k = 0; k < kBLoads; ++k)
+            if (tid + 256 * k < kBSlots3) sB[k * 256 + tid] = pb[k];
     };
     auto compute3 = [&]() {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
-            f32x4 A[RW], Bf[4];
+            f32x4 A[RW], Bf[NJ];
 #pragma unroll
             for (int i = 0; i < RW; ++i) A[i] = sA[((RW * wave + i + dy) * 4 + h) * kHaloW + ln + dx];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Bf[j] = sB[(tap * 4 + h) * kLT_N + 16 * j + ln];
+            for (int j = 0; j < NJ; ++j) Bf[j] = sB[(tap * 4 + h) * kN + 16 * j + ln];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < RW; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
         }
     };
@@ -378,7 +389,9 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
                 pa[(UP ? 4 : 1) * k] = *reinterpret_cast<const f32x4 *>(p);
             }
         }
-        pb[0] = *reinterpret_cast<const f32x4 *>(s.w + ((size_t)(4 * c + (tid >> 6)) * a.Cout_pad + n0 + (tid & 63)) * 4);
+        // 1x1 panel: slot = q * kN + co (4 * kN float4)
+        pb[0] = (tid < 4 * kN) ? *reinterpret_cast<const f32x4 *>(s.w + ((size_t)(4 * c + tid / kN) * a.Cout_pad + n0 + (tid % kN)) * 4)
+                               : (f32x4){0.f, 0.f, 0.f, 0.f};
     };
     auto commit1 = [&](int c) {
         const bool up = UP && a.s[1].up_in[0] != nullptr && 16 * c >= a.s[1].up_c0;
@@ -391,20 +404,20 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             if (UP && up) v = up_blend(y0 + py, x0 + px, pa[4 * k], pa[4 * k + 1], pa[4 * k + 2], pa[4 * k + 3]);
             sA[((py + 1) * 4 + q) * kHaloW + px + 1] = v;
         }
-        sB[tid] = pb[0];
+        if (tid < 4 * kN) sB[tid] = pb[0];
     };
     auto compute1 = [&]() {
-        f32x4 A[RW], Bf[4];
+        f32x4 A[RW], Bf[NJ];
 #pragma unroll
         for (int i = 0; i < RW; ++i) A[i] = sA[((RW * wave + i + 1) * 4 + h) * kHaloW + ln + 1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Bf[j] = sB[h * kLT_N + 16 * j + ln];
+        for (int j = 0; j < NJ; ++j) Bf[j] = sB[h * kN + 16 * j + ln];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < RW; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
     };
 
@@ -444,13 +457,13 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
         if (a.S > 1) {
             float *o = a.ws + ((size_t)sp * a.M + m) * a.Cout_pad + n0 + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(o + 16 * j) = acc[i][j];
+            for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4 *>(o + 16 * j) = acc[i][j];
             continue;
         }
         float *o = a.out + m * a.out_cs;
         const float *rp = a.res ? a.res + m * a.res_cs : nullptr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int co = n0 + 16 * j + 4 * h;
             f32x4 v = acc[i][j];
             if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
@@ -464,14 +477,14 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     }
 }
 
-template <int RW, bool UP>
+template <int RW, bool UP, int NJ = 4>
 __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
-    conv3x3_lds_body<RW, UP>(la, blockIdx.x, gridDim.x);
+    conv3x3_lds_body<RW, UP, NJ>(la, blockIdx.x, gridDim.x);
 }
 // fused-upsample variants: keep 3 workgroups / CU (what the LDS footprint allows) although the 4x prefetch wants ~180 VGPRs
 template <int RW>
 __global__ __launch_bounds__(256, 3) void conv3x3_lds_up_k(const LdsConvArgs la) {
-    conv3x3_lds_body<RW, true>(la, blockIdx.x, gridDim.x);
+    conv3x3_lds_body<RW, true, 4>(la, blockIdx.x, gridDim.x);
 }
 
 // Grouped launch: up to kMaxGroup INDEPENDENT convolutions (same dependency level of a plan, see
@@ -485,12 +498,12 @@ struct LdsGroupArgs {
     LdsConvArgs op[kMaxGroup];
 };
 
-template <int RW, bool UP>
+template <int RW, bool UP, int NJ = 4>
 __global__ __launch_bounds__(256) void conv3x3_lds_group_k(const LdsGroupArgs g) {
     int idx = 0;
     for (int i = 1; i < g.n; ++i)
         if (blockIdx.x >= g.start[i]) idx = i;
-    conv3x3_lds_body<RW, UP>(g.op[idx], blockIdx.x - g.start[idx], g.start[idx + 1] - g.start[idx]);
+    conv3x3_lds_body<RW, UP, NJ>(g.op[idx], blockIdx.x - g.start[idx], g.start[idx + 1] - g.start[idx]);
 }
 
 struct ReduceDesc {
@@ -754,6 +767,7 @@ struct PreparedConv {
     int n_img;
     unsigned blocks;
     bool up;         // some source has fused x2-upsampled segments (LDS kernels only)
+    int nj;          // LDS kernels: 16-channel output sub-tiles per workgroup (4, 2, 1)
     ReduceDesc red;  // valid when a.S > 1
 };
 
@@ -761,6 +775,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     ConvArgs &a = pc.a;
     a = ConvArgs{};
     pc.up = false;
+    pc.nj = 4;
     int steps = 0;
     for (int i = 0; i < 2; ++i) {
         const idh_conv_src &s = op.src[i];
@@ -805,12 +820,15 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     if (a.S > steps) a.S = steps;
     // LDS-staged kernel for the dominant shape family: tile_m 8 / 9 request the 8- / 4-row tile,
     // 0 = auto (8-row)
-    const bool lds_ok = a.s[0].ks == 3 && a.s[0].stride == 1 && a.s[0].pad_mode == IDH_PAD_ZEROS && (op.Cout % kLT_N) == 0 &&
+    // LDS kernels: tile_n = output sub-tiles of 16 channels per workgroup (0 = 4 -> 64 channels; 2; 1)
+    const int nj = (op.tile_m == 8 || op.tile_m == 9 || op.tile_m == 0) ? (op.tile_n == 0 ? 4 : op.tile_n) : 4;
+    const bool lds_ok = a.s[0].ks == 3 && a.s[0].stride == 1 && (nj == 4 || nj == 2 || nj == 1) && (op.Cout % (16 * nj)) == 0 &&
+                        (a.s[0].pad_mode == IDH_PAD_ZEROS || (a.s[0].pad_mode == IDH_PAD_REPLICATE && !a.s[1].in)) &&
                         (!a.s[1].in || (a.s[1].ks == 1 && a.s[1].stride == 1)) && op.Wo >= kLT_W;
     pc.lds_rows = 0;
     if (op.tile_m == IDH_SPLIT_BF16X6 || op.tile_m == IDH_SPLIT_F16X3) {
         // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
-        if (!lds_ok || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1 || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16))
+        if (!lds_ok || a.s[0].pad_mode != IDH_PAD_ZEROS || (op.Cout % 64) || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1 || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16))
             return IDH_EUNSUPPORTED;
         a.NT = op.Cout / 64;
         pc.lds_rows = 16;
@@ -822,7 +840,8 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         const int rows = op.tile_m == 9 ? 4 : 8;
         const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
         if (a.S > chunks) a.S = chunks;
-        a.NT = op.Cout / kLT_N;
+        a.NT = op.Cout / (16 * nj);
+        pc.nj = nj;
         pc.la = LdsConvArgs{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + rows - 1) / rows};
         const long long blocks = (long long)a.S * op.N * pc.la.tiles_x * pc.la.tiles_y * a.NT;
         if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
@@ -842,7 +861,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         if ((waves + 3) / 4 >= (1ll << 31)) return IDH_EUNSUPPORTED;
         pc.blocks = (unsigned)((waves + 3) / 4);
     }
-    if (pc.up && pc.lds_rows != 8 && pc.lds_rows != 4) return IDH_EUNSUPPORTED;  // fused upsampling lives in the LDS loader
+    if (pc.up && ((pc.lds_rows != 8 && pc.lds_rows != 4) || pc.nj != 4)) return IDH_EUNSUPPORTED;  // fused upsampling lives in the 64-channel LDS loader
     if (a.S > 1) {
         if (!op.ws) return IDH_EWORKSPACE;
         pc.red = ReduceDesc{op.ws, op.bias, op.res, op.out, a.M, op.Cout, a.Cout_pad, a.S, op.res_cs, op.out_cs, op.act, op.slope};
@@ -853,6 +872,10 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
 int launch_conv(const PreparedConv &pc, hipStream_t st) {
     if (pc.lds_rows == 16) return launch_conv_split(pc.a, pc.n_img, pc.tm, pc.tn, st);
     if (pc.lds_rows == 8 && pc.up) hipLaunchKernelGGL(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8 && pc.nj == 2) hipLaunchKernelGGL((conv3x3_lds_k<2, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8 && pc.nj == 1) hipLaunchKernelGGL((conv3x3_lds_k<2, false, 1>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.nj == 2) hipLaunchKernelGGL((conv3x3_lds_k<1, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.nj == 1) hipLaunchKernelGGL((conv3x3_lds_k<1, false, 1>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 8) hipLaunchKernelGGL((conv3x3_lds_k<2, false>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 4 && pc.up) hipLaunchKernelGGL(conv3x3_lds_up_k<1>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 4) hipLaunchKernelGGL((conv3x3_lds_k<1, false>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
@@ -898,6 +921,8 @@ int launch_group(const PreparedConv *pcs, int n, hipStream_t st) {
     bool any_up = false;
     for (int i = 0; i < n; ++i) any_up = any_up || pcs[i].up;
     if (any_up) hipLaunchKernelGGL((conv3x3_lds_group_k<1, true>), dim3(cursor), dim3(256), 0, st, g);
+    else if (pcs[0].nj == 2) hipLaunchKernelGGL((conv3x3_lds_group_k<1, false, 2>), dim3(cursor), dim3(256), 0, st, g);
+    else if (pcs[0].nj == 1) hipLaunchKernelGGL((conv3x3_lds_group_k<1, false, 1>), dim3(cursor), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((conv3x3_lds_group_k<1, false>), dim3(cursor), dim3(256), 0, st, g);
     IDH_CHECK_LAUNCH();
     return launch_reduces(pcs, n, st);
@@ -942,7 +967,7 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                     while (i + cnt < n && cnt < kMaxGroup && ops[i + cnt].kind == IDH_OP_CONV && ops[i + cnt].group == op.group) {
                         rc = prep_conv(ops[i + cnt], pcs[cnt]);
                         if (rc != IDH_OK) return rc;
-                        if (pcs[cnt].lds_rows != 4) break;
+                        if (pcs[cnt].lds_rows != 4 || pcs[cnt].nj != pcs[0].nj || (pcs[cnt].up && pcs[0].nj != 4)) break;
                         ++cnt;
                     }
                 }

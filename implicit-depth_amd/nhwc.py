@@ -230,7 +230,9 @@ MIN_WAVES = 1024
 def lds_eligible(srcs, cout: int, Wo: int, pad_mode: int) -> bool:
     """Shape family of the LDS-staged kernel (csrc/conv.hip conv3x3_lds_k)."""
     (v0, c0) = srcs[0]
-    if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64 or Wo < 16:
+    if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or cout % 16 or Wo < 16:
+        return False
+    if pad_mode != PAD_ZEROS and (pad_mode != PAD_REPLICATE or len(srcs) > 1):
         return False
     if len(srcs) > 1:
         (v1, c1) = srcs[1]
@@ -239,12 +241,25 @@ def lds_eligible(srcs, cout: int, Wo: int, pad_mode: int) -> bool:
     return True
 
 
+def lds_subtiles(cout: int) -> int:
+    """16-channel output sub-tiles per workgroup of the LDS-staged kernel (the op's tile_n): 64 channels when the
+    layer has them, else 32 / 16 (the matching encoder's 128 -> 16 conv)."""
+    return 4 if cout % 64 == 0 else (2 if cout % 32 == 0 else 1)
+
+
+# Small grids (one frame, low-resolution levels): halve the workgroup's channel tile (64 -> 32) when even 4-row tiles
+# leave fewer than this many workgroups, to shorten each workgroup's MFMA phase and spread it over more CUs.
+# Measured (tools/perf_levels.py <B> <threshold>, conv stage of the hot path): B=1 3.31 -> 3.04 ms, B=2 5.06 -> 4.88 ms,
+# B=4 and B=8 unchanged with 400; 800 / 1600 cost 1-1.5 % at B=4.
+NARROW_TILE_BELOW = 400
+
+
 def choose_lds_tile(N: int, Ho: int, Wo: int, cout: int, chunks: int):
     """(tile code, split): 8-row tiles (code 8) when they already give one full round of
     256 CUs x 3 resident workgroups, else 4-row tiles (code 9); split K only when the grid still
     cannot fill the chip AND every split keeps >= 6 chunks of 16 channels (measured on MI355X,
     tools/perf_conv_layers.py)."""
-    per_row_tiles = N * (-(-Wo // 16)) * (cout // 64)
+    per_row_tiles = N * (-(-Wo // 16)) * (cout // (16 * lds_subtiles(cout)))
     code, rows = 8, 8
     if per_row_tiles * (-(-Ho // 8)) < 768:
         code, rows = 9, 4
@@ -349,7 +364,11 @@ class Plan:
             tm, split = choose_lds_tile(out.N, out.H, out.W, conv.out_channels, chunks)
             if tm == 8 and FUSED_UP_ROWS == 4 and any(isinstance(v, CatView) for v, _ in srcs):
                 tm = 9
-            tn = 0
+            tn = lds_subtiles(conv.out_channels)
+            if (tn == 4 and tm == 9 and NARROW_TILE_BELOW and not any(isinstance(v, CatView) for v, _ in srcs)
+                    and out.N * (-(-out.H // 4)) * (-(-out.W // 16)) * (conv.out_channels // 64) * split < NARROW_TILE_BELOW):
+                tn = 2
+            tn = 0 if tn == 4 else tn
         else:
             tm, tn, split = choose_tiles(M, conv.out_channels, steps)
         op.tile_m, op.tile_n, op.split_k = tm, tn, split
@@ -503,7 +522,7 @@ class Plan:
                     if _overlap(mi["writes"], mj["reads"]) or _overlap(mi["writes"], mj["writes"]) or _overlap(mi["reads"], mj["writes"]):
                         level[j] = max(level[j], level[i] + 1)
             groupable = lambda k: self.ops[k].kind == OP_CONV and self.ops[k].tile_m == 9
-            order += sorted(range(lo, hi), key=lambda k: (level[k], 0 if groupable(k) else 1, k))
+            order += sorted(range(lo, hi), key=lambda k: (level[k], 0 if groupable(k) else 1, self.ops[k].tile_n if groupable(k) else 0, k))
         for k in range(n):
             self.ops[k].group = level[k] + 1 if (self.ops[k].kind == OP_CONV and self.ops[k].tile_m == 9) else 0
         self.ops = [self.ops[k] for k in order]

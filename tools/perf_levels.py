@@ -7,6 +7,7 @@ from implicit_depth_amd import nhwc, _lib
 from bench import HotPathWorkload
 import argparse
 a = argparse.Namespace(batch=int(sys.argv[1]) if len(sys.argv) > 1 else 4, views=7, planes=64, height=384, width=512, volume="mlp")
+if len(sys.argv) > 2: nhwc.NARROW_TILE_BELOW = int(sys.argv[2])  # narrow (32-channel) tiles below this many workgroups
 wl = HotPathWorkload(a, torch.device("cuda"), 0)
 for _ in range(2): wl.step()
 torch.cuda.synchronize()
@@ -16,7 +17,7 @@ units, i = [], 0
 while i < len(p.ops):
     op = p.ops[i]; j = i + 1
     if op.kind == 1 and op.group != 0 and op.tile_m == 9:
-        while j < len(p.ops) and j - i < 12 and p.ops[j].kind == 1 and p.ops[j].group == op.group and p.ops[j].tile_m == 9: j += 1
+        while j < len(p.ops) and j - i < 12 and p.ops[j].kind == 1 and p.ops[j].group == op.group and p.ops[j].tile_m == 9 and p.ops[j].tile_n == op.tile_n: j += 1
     units.append((i, j)); i = j
 def flops(op): return sum(2 * op.N * op.Ho * op.Wo * op.Cout * s.Cin * s.ks * s.ks for s in op.src if s.in_) if op.kind == 1 else 0
 rows = []
@@ -29,7 +30,7 @@ for (i, j) in units:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     fl = sum(flops(o) for o in p.ops[i:j])
-    desc = " | ".join((f"{o.src[0].Cin}" + (f"+{o.src[1].Cin}" if o.src[1].in_ else "") + f">{o.Cout}@{o.Ho}x{o.Wo} t{o.tile_m}s{o.split_k}") if o.kind == 1 else f"k{o.kind}:{o.src[0].Cin}@{o.src[0].H}x{o.src[0].W}" for o in p.ops[i:j])
+    desc = " | ".join((f"{o.src[0].Cin}" + (f"+{o.src[1].Cin}" if o.src[1].in_ else "") + f">{o.Cout}@{o.Ho}x{o.Wo} t{o.tile_m}n{o.tile_n}s{o.split_k}") if o.kind == 1 else f"k{o.kind}:{o.src[0].Cin}@{o.src[0].H}x{o.src[0].W}" for o in p.ops[i:j])
     rows.append((ms, fl, p.levels[i], j - i, desc))
 tot = sum(r[0] for r in rows)
 print(f"B={a.batch} units={len(rows)} ops={len(p.ops)} total {tot:.3f} ms  conv TF={sum(r[1] for r in rows)/tot/1e9:.1f}")
