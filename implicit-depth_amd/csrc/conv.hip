@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void export_nchw_k(const float *__restrict__ s
 // 1x1 conv to a single channel: one thread per pixel
 __global__ __launch_bounds__(256) void pointwise_head_k(const float *__restrict__ in, const float *__restrict__ w,
                                                         const float *__restrict__ bias, float *__restrict__ out,
-                                                        long long M, int C, int in_cs) {
+                                                        float *__restrict__ out_exp, long long M, int C, int in_cs) {
     for (long long m = blockIdx.x * 256ll + threadIdx.x; m < M; m += gridDim.x * 256ll) {
         const float4 *p = reinterpret_cast<const float4 *>(in + m * in_cs);
         const float4 *wv = reinterpret_cast<const float4 *>(w);
@@ -685,7 +685,9 @@ __global__ __launch_bounds__(256) void pointwise_head_k(const float *__restrict_
             const float4 a = p[q], b = wv[q];
             s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
         }
-        out[m] = s + (bias ? bias[0] : 0.f);
+        const float v = s + (bias ? bias[0] : 0.f);
+        out[m] = v;
+        if (out_exp) out_exp[m] = expf(v);  // depth = exp(log-depth), depth_model.py:425-433
     }
 }
 
@@ -1017,7 +1019,7 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 const long long M = (long long)op.N * s.H * s.W;
                 int grid = idh_cdiv(M, 256);
                 if (grid > 8192) grid = 8192;
-                hipLaunchKernelGGL(pointwise_head_k, dim3(grid), dim3(256), 0, st, s.in, s.w, op.bias, op.out, M, s.Cin,
+                hipLaunchKernelGGL(pointwise_head_k, dim3(grid), dim3(256), 0, st, s.in, s.w, op.bias, op.out, op.ws, M, s.Cin,
                                    s.cs);
                 IDH_CHECK_LAUNCH();
                 break;

@@ -558,8 +558,12 @@ class Plan:
         """idx = op index returned at build time (stable across schedule())."""
         self._array()[self._idx(idx)].src[0].in_ = t.data_ptr()
 
-    def set_out(self, idx: int, t: torch.Tensor):
-        self._array()[self._idx(idx)].out = t.data_ptr()
+    def set_out(self, idx: int, t: torch.Tensor, exp_out: Optional[torch.Tensor] = None):
+        """Patch an op's output pointer; ``exp_out``: the head op's optional exp(output) tensor."""
+        op = self._array()[self._idx(idx)]
+        op.out = t.data_ptr()
+        if exp_out is not None:
+            op.ws = exp_out.data_ptr()
 
 
 def math_of(module: nn.Module) -> str:

@@ -190,12 +190,11 @@ class HotPath(nn.Module):
             for i, idx in ent["heads"].items():
                 v = final[i]
                 t = torch.empty(B, 1, v.H, v.W, device=dev)
-                p.set_out(idx, t)
+                e = torch.empty(B, 1, v.H, v.W, device=dev)
+                p.set_out(idx, t, exp_out=e)  # the head kernel writes log-depth and exp(log-depth) (depth_model.py:425-433)
                 out[f"log_depth_pred_s{i}_b1hw"] = t
+                out[f"depth_pred_s{i}_b1hw"] = e
         p.run(ent["n_head_ops"])
-        if ent["heads"]:
-            for i in ent["heads"]:
-                out[f"depth_pred_s{i}_b1hw"] = torch.exp(out[f"log_depth_pred_s{i}_b1hw"])  # depth_model.py:425-433
 
         # 3. occlusion MLP over every query plane (BDModel only)
         if self.binary_mlp is not None and rendered_depth is not None:

@@ -24,7 +24,8 @@ enum {
     IDH_OP_NCHW_TO_NHWC = 3,/* strided layout import: (N,C,H,W) -> NHWC slice                */
     IDH_OP_NHWC_TO_NCHW = 4,/* strided layout export: NHWC slice -> (N,C,H,W)                */
     IDH_OP_SPLITK_REDUCE = 5,/* sum split-K partials + bias + residual + activation          */
-    IDH_OP_POINTWISE_HEAD = 6,/* 1x1 conv to 1 channel (DepthDecoderPP heads, networks.py:158-161) */
+    IDH_OP_POINTWISE_HEAD = 6,/* 1x1 conv to 1 channel (DepthDecoderPP heads, networks.py:158-161); ws != NULL: a second
+                                 (N,1,H,W) output = exp(out), the depth map of depth_model.py:425-433 */
     IDH_OP_COPY = 9,        /* channel-strided NHWC -> NHWC slice copy */
     IDH_OP_UPSAMPLE2_NEAREST = 8, /* nearest x2 (SkipDecoder, networks_fast.py:43) */
     IDH_OP_INSTNORM = 7     /* nn.InstanceNorm2d (no affine, eps 1e-5) [+ LeakyReLU] on NHWC; matching-encoder
