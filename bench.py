@@ -60,10 +60,10 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--no-head", action="store_true", help="start at finished matching features (round-1 workload) instead of the layer1 map")
-    ap.add_argument("--conv-math", default="fp32", choices=["fp32", "bf16x6", "f16x3"],
+    ap.add_argument("--conv-math", default="fp32", choices=["fp32", "f16x3"],
                     help="arithmetic of the 3x3 stride-1 convs: fp32 MFMA (default) or the fp32-equivalent split-precision kernels")
     ap.add_argument("--mlp-math", default="fp32", choices=["fp32", "f16x3"], help="arithmetic of the MLP kernels (feature volume)")
-    ap.add_argument("--math", default=None, choices=["fp32", "bf16x6", "f16x3"],
+    ap.add_argument("--math", default=None, choices=["fp32", "f16x3"],
                     help="shorthand: sets --conv-math, and --mlp-math f16x3 when f16x3")
     ap.add_argument("--no-split-line", action="store_true", help="skip the secondary split-precision measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the warp_match / temporal objects")
@@ -281,7 +281,7 @@ class HotPathWorkload:
             ev[1].record()
 
     # roofline of the dominant kernel -------------------------------------------------------
-    dominant_kernel = "conv3x3_lds_k<2>"
+    dominant_kernel = "conv3x3_lds_k<2, false, 4>"  # as rocprofv3 --kernel-trace names it
 
     def _replay_ms(self, ops, iters=10, batches=3):
         """ms per pass of `ops` replayed alone between HIP events on the launch stream: median of
@@ -322,10 +322,10 @@ class HotPathWorkload:
         dom = [op for op in convs if op.tile_m == 8]
         if self.conv_math != "fp32":
             dom = [op for op in convs if op.tile_m in (10, 11)]
-            self.dominant_kernel = "conv3x3_split_k<8, 1, 0, *>" if self.conv_math == "bf16x6" else "conv3x3_split_k<4, 2, 1, *>"
+            self.dominant_kernel = "conv3x3_split_k<4, 2, 1, *>"
         if not dom:  # small batches: every layer runs on the 4-row tile variant
             dom = [op for op in convs if op.tile_m == 9]
-            self.dominant_kernel = "conv3x3_lds_k<1> + conv3x3_lds_group_k<1>"
+            self.dominant_kernel = "conv3x3_lds_k<1, false, *> + conv3x3_lds_group_k<1, false, *>"
         dom_res = (self._replay_ms(dom, iters), len(dom), sum(self._conv_flops(o) for o in dom))
         all_res = (self._replay_ms(convs, iters), len(convs), sum(self._conv_flops(o) for o in convs))
         return dom_res, all_res
@@ -543,9 +543,9 @@ def main():
             (dom_ms, dom_n, dom_fl), (all_ms, all_n, all_fl) = wl.conv_only_ms()
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
             math = getattr(wl, "conv_math", "fp32")
-            # split-precision convs execute 6 (bf16x6) / 3 (f16x3) 16-bit MFMA products per fp32-equivalent
+            # split-precision convs execute 3 f16 MFMA products per fp32-equivalent
             # MAC: their roofline is the dense 16-bit MFMA peak divided by that count
-            peak = {"fp32": MFMA_F32_PEAK_TFLOPS, "bf16x6": MFMA_16BIT_PEAK_TFLOPS / 6, "f16x3": MFMA_16BIT_PEAK_TFLOPS / 3}[math]
+            peak = {"fp32": MFMA_F32_PEAK_TFLOPS, "f16x3": MFMA_16BIT_PEAK_TFLOPS / 3}[math]
             roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": None, "kernel": wl.dominant_kernel, "kernel_ms": dom_ms / dom_n, "launches_per_step": dom_n,
                     "kernel_ms_per_step": dom_ms, "algorithmic_flops_per_launch": dom_fl / dom_n,
@@ -554,7 +554,7 @@ def main():
                     "step_ms_hip_events": kernel_ms}
             if math != "fp32":
                 roof["peak_note"] = (f"fp32-equivalent flops; peak = {MFMA_16BIT_PEAK_TFLOPS:.0f} TFLOP/s dense 16-bit MFMA / "
-                                     f"{6 if math == 'bf16x6' else 3} products per MAC; the fp32-MFMA peak is 157.3")
+                                     "3 products per MAC; the fp32-MFMA peak is 157.3")
         key = f"{wl.name}/{getattr(wl, 'volume', 'dot')}/b{wl.B}" if wl.name != "warp_match_dot" else f"{wl.name}/b{wl.B}"
         if getattr(wl, "conv_math", "fp32") != "fp32":
             key += "/" + wl.conv_math
@@ -575,7 +575,7 @@ def main():
             "higher_is_better": True,
             "scaling": wl.scaling,
             "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x6": "f32 (3x3 convs: bf16x3-split operands, 6 products, f32 accumulate)",
+            "dtype": {"fp32": "f32",
                       "f16x3": "f32 (3x3 convs: scaled f16x2-split operands, 3 products, f32 accumulate)"}[getattr(wl, "conv_math", "fp32")],
             "data": "synthetic",
             "config": dict(wl.config(), global_batch=frames_per_step_total),

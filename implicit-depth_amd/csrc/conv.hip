@@ -828,7 +828,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
                         (a.s[0].pad_mode == IDH_PAD_ZEROS || (a.s[0].pad_mode == IDH_PAD_REPLICATE && !a.s[1].in)) &&
                         (!a.s[1].in || (a.s[1].ks == 1 && a.s[1].stride == 1)) && op.Wo >= kLT_W;
     pc.lds_rows = 0;
-    if (op.tile_m == IDH_SPLIT_BF16X6 || op.tile_m == IDH_SPLIT_F16X3) {
+    if (op.tile_m == IDH_SPLIT_F16X3) {
         // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
         if (!lds_ok || a.s[0].pad_mode != IDH_PAD_ZEROS || (op.Cout % 64) || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1 || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16))
             return IDH_EUNSUPPORTED;

@@ -1,13 +1,10 @@
 // 3x3 stride-1 convolution on the 16-bit matrix cores with fp32-equivalent results ("split
 // precision").  gfx950 runs bf16 / f16 MFMA at 16x the fp32-MFMA rate (2.5 PFLOP/s vs 157 TFLOP/s
 // dense) and has no TF32, so the fp32 operands are expanded into 16-bit pieces whose cross
-// products are accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16}.  Opt-in (IDH_OP_CONV with
-// tile_m = 10 / 11); the default path stays on v_mfma_f32_16x16x4_f32.
+// products are accumulated in fp32 by v_mfma_f32_32x32x16_f16.  Opt-in (IDH_OP_CONV with
+// tile_m = 11); the default path stays on v_mfma_f32_16x16x4_f32.  (A three-piece bf16 variant, "bf16x6", existed in
+// round 1; it was 1.5x slower than f16x3 at the same accuracy and was removed to shrink the surface.)
 //
-//  MODE_BF16X6 (tile_m = 10): x = x0 + x1 + x2 EXACTLY, three truncated bf16 pieces (8+8+8 bits,
-//     bf16 keeps fp32's exponent range so no scaling is involved).  x*w expands into 9 products;
-//     the 6 with piece-index sum <= 2 carry everything above 2^-24 relative:
-//     x0w0 + x0w1 + x1w0 + x0w2 + x1w1 + x2w0.  Every bf16 product is exact in fp32.
 //  MODE_F16X3 (tile_m = 11): x/s = x0 + x1, two round-to-nearest f16 pieces (11+11 bits + sign:
 //     |x/s - x0 - x1| <= 2^-23 |x/s|), products x0w0 + x0w1 + x1w0 (the dropped x1w1 is 2^-22).
 //     f16 has a 5-bit exponent, so operands are scaled by exact powers of two into [2^14, 2^15):
@@ -15,7 +12,7 @@
 //     maximum of the workgroup's chunk maxima (the accumulators are rescaled, again by an exact
 //     power of two, when that maximum grows).  Elements more than 2^18 below the running maximum
 //     fall into f16's subnormal range and keep an absolute error of 2^-40 of that maximum.
-//  Measured against fp64 (tests/test_conv_split_gpu.py): both modes err by ~4e-7 of the output
+//  Measured against fp64 (tests/test_conv_split_gpu.py): it errs by ~4e-7 of the output
 //  scale at K = 576..1728, the fp32-MFMA kernel by ~5e-7 (bar: 1e-4).
 //
 // Shape family: the layers that carry the flops of CVEncoder / UNet++ (layers.py:59-95): 3x3,
@@ -43,18 +40,17 @@ using namespace idh_conv;
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
-constexpr int MODE_BF16X6 = 0, MODE_F16X3 = 1;
+constexpr int MODE_F16X3 = 1;
 constexpr int kHalo = kSplitTile + 2;    // 18 halo columns
 constexpr int kMinExp = -100;            // lower clamp of the scaling exponents (all-zero tiles)
 
-constexpr int pieces_of(int mode) { return mode == MODE_BF16X6 ? 3 : 2; }
+constexpr int pieces_of(int) { return 2; }
 constexpr int wslots_of(int mode) { return 3 * pieces_of(mode) * 2 * 64; }  // 16-B slots per (chunk, tap row, 64-channel tile)
 // slots per (piece, kg) plane of a (rows+2) x 18 halo, padded to 8 mod 16 slots (bank offset 32 between the
 // two kg planes -> conflict-free ds_write_b64): 324 -> 328 (16 rows), 180 -> 184 (8 rows)
@@ -62,19 +58,6 @@ constexpr int plane_of(int rows) { return (((rows + 2) * kHalo + 7) / 16) * 16 +
 constexpr int lds_bytes_of(int mode, int rows) { return (pieces_of(mode) * 2 * plane_of(rows) + 2 * wslots_of(mode)) * 16 + 64; }
 
 __device__ float g_zero16[16];
-
-// x = h0 + h1 + h2 exactly; the bf16 payload of each piece is the top half of the returned word.
-__device__ __forceinline__ void split3_bf16(float x, unsigned &h0, unsigned &h1, unsigned &h2) {
-    const unsigned u0 = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(u0);
-    const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(u1);
-    h0 = u0;
-    h1 = u1;
-    h2 = __float_as_uint(r2);
-}
-// {bf16(lo), bf16(hi)} -> one dword (element 0 in the low half)
-__device__ __forceinline__ unsigned pack2_hi(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
 // x (already scaled into f16 range) ~= h0 + h1, both round-to-nearest-even
 __device__ __forceinline__ void split2_f16(float x, _Float16 &h0, _Float16 &h1) {
@@ -196,16 +179,7 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
             const int slot = tid + NT_ * k;
             const int q = slot & 3, pix = slot >> 2;
             unsigned w[NP][2];
-            if constexpr (MODE == MODE_BF16X6) {
-                unsigned h[4][3];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split3_bf16(ph_[k][e], h[e][0], h[e][1], h[e][2]);
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    w[pc][0] = pack2_hi(h[0][pc], h[1][pc]);
-                    w[pc][1] = pack2_hi(h[2][pc], h[3][pc]);
-                }
-            } else {
+            {
                 _Float16 h[4][2];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) split2_f16(ph_[k][e] * mul, h[e][0], h[e][1]);
@@ -284,8 +258,7 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
                 for (int g = 0; g < G; ++g) B[g][pc] = hb[pc * 2 * kPlane + 2 * g * kHalo + t];
             }
             // smallest terms first; independent accumulators between dependent MFMAs
-            constexpr int kTerms = MODE == MODE_BF16X6 ? 6 : 3;
-            constexpr int kPa6[6] = {2, 0, 1, 1, 0, 0}, kPb6[6] = {0, 2, 1, 0, 1, 0};  // weight / activation piece
+            constexpr int kTerms = 3;
             constexpr int kPa3[3] = {1, 0, 0}, kPb3[3] = {0, 1, 0};
 #pragma unroll
             for (int m = 0; m < kTerms; ++m)
@@ -293,11 +266,7 @@ __global__ __launch_bounds__(64 * WAVES, G == 1 ? 4 : 2) void conv3x3_split_k(co
                 for (int g = 0; g < G; ++g)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if constexpr (MODE == MODE_BF16X6)
-                            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[j][kPa6[m]]),
-                                                                                __builtin_bit_cast(bf16x8, B[g][kPb6[m]]), acc[g][j], 0, 0, 0);
-                        else
-                            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[j][kPa3[m]]),
+                        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[j][kPa3[m]]),
                                                                                __builtin_bit_cast(f16x8, B[g][kPb3[m]]), acc[g][j], 0, 0, 0);
                     }
         }
@@ -456,9 +425,7 @@ __global__ __launch_bounds__(256) void pack_split_weight_k(const float *__restri
         for (int e = 0; e < 8; ++e) {
             const int ci = 16 * c + 8 * kg + e;
             const float v = (ci < Cin && cout < Cout) ? w[((size_t)cout * Cin + ci) * (KS * KS) + tap] : 0.f;
-            if constexpr (MODE == MODE_BF16X6) {
-                split3_bf16(v, h[e][0], h[e][1], h[e][2]);
-            } else {
+            {
                 _Float16 a0, a1;
                 split2_f16(v * mul, a0, a1);
                 h[e][0] = __builtin_bit_cast(unsigned short, a0);
@@ -468,10 +435,7 @@ __global__ __launch_bounds__(256) void pack_split_weight_k(const float *__restri
         const size_t base = ((size_t)(c * kRowsK + r) * NT + nt) * kWSlots;
         for (int pc = 0; pc < NP; ++pc) {
             u32x4 v;
-            if constexpr (MODE == MODE_BF16X6)
-                v = (u32x4){pack2_hi(h[0][pc], h[1][pc]), pack2_hi(h[2][pc], h[3][pc]), pack2_hi(h[4][pc], h[5][pc]), pack2_hi(h[6][pc], h[7][pc])};
-            else
-                v = (u32x4){h[0][pc] | (h[1][pc] << 16), h[2][pc] | (h[3][pc] << 16), h[4][pc] | (h[5][pc] << 16), h[6][pc] | (h[7][pc] << 16)};
+            v = (u32x4){h[0][pc] | (h[1][pc] << 16), h[2][pc] | (h[3][pc] << 16), h[4][pc] | (h[5][pc] << 16), h[6][pc] | (h[7][pc] << 16)};
             dst[base + ((t * NP + pc) * 2 + kg) * 64 + co] = v;
         }
     }
@@ -513,35 +477,28 @@ int launch_one_src(const ConvArgs &a, int N, hipStream_t st) {
 namespace idh_conv {
 
 int launch_conv_split(const ConvArgs &a, int N, int mode, int rows, hipStream_t st) {
-    if (rows == 8) {
-        if (mode == IDH_SPLIT_BF16X6) return launch_one<4, 1, MODE_BF16X6>(a, N, st);
-        if (mode == IDH_SPLIT_F16X3) return launch_one<4, 1, MODE_F16X3>(a, N, st);
-        return IDH_EINVAL;
-    }
-    // measured on MI355X (tools/perf_split.py): f16x3 is 5-9 % faster with 4 waves (166 VGPRs, 44.5 KiB ->
-    // 3 workgroups per CU), bf16x6 is indifferent (4 waves: 206 VGPRs -> 2 workgroups either way)
-    static const int env_waves = getenv("IDH_SPLIT_WAVES") ? atoi(getenv("IDH_SPLIT_WAVES")) : 0;
-    const int waves = env_waves ? env_waves : (mode == IDH_SPLIT_F16X3 ? 4 : 8);
-    if (mode == IDH_SPLIT_BF16X6) return waves == 4 ? launch_one<4, 2, MODE_BF16X6>(a, N, st) : launch_one<8, 1, MODE_BF16X6>(a, N, st);
-    if (mode == IDH_SPLIT_F16X3) return waves == 4 ? launch_one<4, 2, MODE_F16X3>(a, N, st) : launch_one<8, 1, MODE_F16X3>(a, N, st);
-    return IDH_EINVAL;
+    if (mode != IDH_SPLIT_F16X3) return IDH_EINVAL;
+    if (rows == 8) return launch_one<4, 1, MODE_F16X3>(a, N, st);
+    // measured on MI355X (tools/perf_split.py): 5-9 % faster with 4 waves x 2 tile groups (166 VGPRs, 44.5 KiB ->
+    // 3 workgroups per CU) than with 8 waves
+    return launch_one<4, 2, MODE_F16X3>(a, N, st);
 }
 
 }  // namespace idh_conv
 
 extern "C" size_t idh_packed_split_weight_bytes(int Cout, int Cin, int Cin_1x1, int mode) {
-    if (Cout <= 0 || Cin <= 0 || Cin_1x1 < 0 || Cout % 64 || (mode != IDH_SPLIT_BF16X6 && mode != IDH_SPLIT_F16X3)) return 0;
-    const int m = mode == IDH_SPLIT_BF16X6 ? MODE_BF16X6 : MODE_F16X3;
+    if (Cout <= 0 || Cin <= 0 || Cin_1x1 < 0 || Cout % 64 || mode != IDH_SPLIT_F16X3) return 0;
+    const int m = MODE_F16X3;
     return panel_bytes(m, Cout, Cin) + panel1_bytes(m, Cout, Cin_1x1) + (size_t)Cout * 8;  // + per-channel scale floats + exponents
 }
 
 extern "C" int idh_pack_conv_weight_split(const float *w, const float *w_1x1, void *dst, int Cout, int Cin, int Cin_1x1, int mode,
                                           void *stream) {
     if (!w || !dst || Cout <= 0 || Cin <= 0 || Cin_1x1 < 0 || (Cin_1x1 > 0) != (w_1x1 != nullptr) ||
-        (mode != IDH_SPLIT_BF16X6 && mode != IDH_SPLIT_F16X3))
+        mode != IDH_SPLIT_F16X3)
         return IDH_EINVAL;
     if (Cout % 64) return IDH_EUNSUPPORTED;
-    const int m = mode == IDH_SPLIT_BF16X6 ? MODE_BF16X6 : MODE_F16X3;
+    const int m = MODE_F16X3;
     const int nC = ceil16i(Cin) / 16, NT = Cout / 64, nC2 = Cin_1x1 > 0 ? ceil16i(Cin_1x1) / 16 : 0;
     char *d8 = static_cast<char *>(dst);
     u32x4 *d3 = reinterpret_cast<u32x4 *>(d8), *d1 = reinterpret_cast<u32x4 *>(d8 + panel_bytes(m, Cout, Cin));
@@ -552,13 +509,11 @@ extern "C" int idh_pack_conv_weight_split(const float *w, const float *w_1x1, vo
     IDH_CHECK_LAUNCH();
     auto grid_of = [](long long total) { int g = idh_cdiv(total, 256); return g > 4096 ? 4096 : g; };
     const int g3 = grid_of((long long)nC * 3 * NT * 3 * 2 * 64);
-    if (m == MODE_BF16X6) hipLaunchKernelGGL((pack_split_weight_k<MODE_BF16X6, 3>), dim3(g3), dim3(256), 0, st, w, d3, wexp, Cout, Cin, nC, NT);
-    else hipLaunchKernelGGL((pack_split_weight_k<MODE_F16X3, 3>), dim3(g3), dim3(256), 0, st, w, d3, wexp, Cout, Cin, nC, NT);
+    hipLaunchKernelGGL((pack_split_weight_k<MODE_F16X3, 3>), dim3(g3), dim3(256), 0, st, w, d3, wexp, Cout, Cin, nC, NT);
     IDH_CHECK_LAUNCH();
     if (nC2 > 0) {
         const int g1 = grid_of((long long)nC2 * NT * 2 * 64);
-        if (m == MODE_BF16X6) hipLaunchKernelGGL((pack_split_weight_k<MODE_BF16X6, 1>), dim3(g1), dim3(256), 0, st, w_1x1, d1, wexp, Cout, Cin_1x1, nC2, NT);
-        else hipLaunchKernelGGL((pack_split_weight_k<MODE_F16X3, 1>), dim3(g1), dim3(256), 0, st, w_1x1, d1, wexp, Cout, Cin_1x1, nC2, NT);
+        hipLaunchKernelGGL((pack_split_weight_k<MODE_F16X3, 1>), dim3(g1), dim3(256), 0, st, w_1x1, d1, wexp, Cout, Cin_1x1, nC2, NT);
         IDH_CHECK_LAUNCH();
     }
     return IDH_OK;

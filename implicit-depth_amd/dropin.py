@@ -78,7 +78,7 @@ def convert_binary_mlp(ref: nn.Module) -> nn.Module:
 
 def convert(model: nn.Module, math: str = None) -> nn.Module:
     """In-place: replace ``cost_volume``, ``cost_volume_net``, ``depth_decoder`` and (BDModel)
-    ``binary_mlp`` of a reference model.  Idempotent.  ``math``: None keeps the default (fp32 MFMA); "f16x3" / "bf16x6" select the split-precision
+    ``binary_mlp`` of a reference model.  Idempotent.  ``math``: None keeps the default (fp32 MFMA); "f16x3" selects the split-precision
     kernels for this model's convs (and, for "f16x3", its MLP feature volume and BinaryMLP)."""
     if not isinstance(model.cost_volume, cv.CostVolumeManager):
         model.cost_volume = convert_cost_volume(model.cost_volume)

@@ -147,7 +147,7 @@ def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
     return dst
 
 
-SPLIT_CODE = {"bf16x6": 10, "f16x3": 11}  # IDH_SPLIT_* of include/idh_ops.h == the op's tile_m
+SPLIT_CODE = {"f16x3": 11}  # IDH_SPLIT_F16X3 of include/idh_ops.h == the op's tile_m
 
 
 def split_packed_weight(conv: nn.Conv2d, math: str, proj: Optional[nn.Conv2d] = None) -> torch.Tensor:
@@ -183,11 +183,10 @@ def split_packed_weight(conv: nn.Conv2d, math: str, proj: Optional[nn.Conv2d] = 
 
 
 # Arithmetic of the 3x3 stride-1 convs: "fp32" = v_mfma_f32_16x16x4_f32 everywhere (default);
-# "bf16x6" / "f16x3" = the layers of the split_eligible() family run on the 16-bit matrix cores
-# with every fp32 operand expanded into 3 bf16 / 2 scaled f16 pieces and the 6 / 3 significant
-# cross products accumulated in fp32 (csrc/conv_split.hip) — fp32-equivalent results at 6/16 resp.
-# 3/16 of the fp32-MFMA cost.
-MATH_MODES = ("fp32", "bf16x6", "f16x3")
+# "f16x3" (opt-in) = the layers of the split_eligible() family run on the f16 matrix cores with every fp32 operand
+# expanded into 2 scaled f16 pieces and the 3 significant cross products accumulated in fp32
+# (csrc/conv_split.hip) — fp32-equivalent results at 3/16 of the fp32-MFMA cost.
+MATH_MODES = ("fp32", "f16x3")
 DEFAULT_MATH = "fp32"  # process-wide default; per-plan: Plan(math=...) / the module's ``conv_math`` attribute
 SPLIT_MIN_BLOCKS = 256  # fewer 8x16x64 tiles than CUs: the fp32 kernels' finer tiles win
 

@@ -38,7 +38,7 @@ class HotPath(nn.Module):
                  binary_mlp: Optional[nn.Module] = None, min_depth: float = 0.25, max_depth: float = 5.0,
                  conv_math: Optional[str] = None, matching_model: Optional[nn.Module] = None):
         super().__init__()
-        self.conv_math = conv_math  # None = nhwc.DEFAULT_MATH ("fp32"); "bf16x6" / "f16x3": see nhwc.MATH_MODES
+        self.conv_math = conv_math  # None = nhwc.DEFAULT_MATH ("fp32"); "f16x3": see nhwc.MATH_MODES
         self.cost_volume = cost_volume
         self.cost_volume_net = cost_volume_net
         self.depth_decoder = depth_decoder

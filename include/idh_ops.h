@@ -69,7 +69,7 @@ typedef struct idh_op {
     int32_t split_k;      /* 1 = no split */
     int32_t tile_m, tile_n; /* direct kernel: wave tile in 16-wide MFMA sub-tiles (1,2,4), 0 = auto;
                                tile_m = 8 / 9 selects the LDS-staged kernel with 8- / 4-row tiles;
-                               tile_m = IDH_SPLIT_BF16X6 / IDH_SPLIT_F16X3 selects the split-precision
+                               tile_m = IDH_SPLIT_F16X3 selects the split-precision
                                kernel (3x3 stride 1, one source, Cout % 64 == 0; src[0].w =
                                idh_pack_conv_weight_split output of the same mode); there tile_n = 8
                                selects 8-row instead of 16-row tiles */
@@ -83,10 +83,9 @@ typedef struct idh_op {
 size_t idh_packed_weight_floats(int Cout, int Cin, int ks);
 int idh_pack_conv_weight(const float *w_oihw, float *dst, int Cout, int Cin, int ks, void *stream);
 
-/* Split-precision convolution (csrc/conv_split.hip): fp32 operands expanded into 16-bit pieces,
- * cross products accumulated in fp32 on the bf16 / f16 matrix cores — fp32-equivalent results
- * (error ~4e-7 of the output scale, like an fp32 FMA chain) at 6/16 resp. 3/16 of the fp32-MFMA cost.
- *   IDH_SPLIT_BF16X6: x = x0+x1+x2 exactly (3 bf16 pieces, no scaling), 6 products.
+/* Split-precision convolution (csrc/conv_split.hip), opt-in: fp32 operands expanded into 16-bit pieces,
+ * cross products accumulated in fp32 on the f16 matrix cores — fp32-equivalent results
+ * (error ~4e-7 of the output scale, like an fp32 FMA chain) at 3/16 of the fp32-MFMA cost.
  *   IDH_SPLIT_F16X3:  x/s = x0+x1 (2 f16 pieces, power-of-two scaling per output channel for the
  *                     weights and per halo chunk for the activations), 3 products.
  * Packed weights: [Cin_pad/16][tap row 3][Cout/64][tap in row 3][piece][ci half 2][co 64][8] 16-bit,
@@ -95,7 +94,6 @@ int idh_pack_conv_weight(const float *w_oihw, float *dst, int Cout, int Cin, int
  * A fused 1x1 second source (src[1]: BasicBlock's downsample(x)) is packed into the same blob
  * (w_1x1 = (Cout, Cin_1x1) row-major or NULL / 0): [3x3 panels][1x1 panels: Cin_1x1_pad/16 x Cout/64 x
  * piece x half x 64 x 8][scales]; src[1].w is then ignored by the kernel. */
-#define IDH_SPLIT_BF16X6 10
 #define IDH_SPLIT_F16X3 11
 size_t idh_packed_split_weight_bytes(int Cout, int Cin, int Cin_1x1, int mode);
 int idh_pack_conv_weight_split(const float *w_oihw, const float *w_1x1, void *dst, int Cout, int Cin, int Cin_1x1, int mode,

@@ -1,8 +1,6 @@
 """The arithmetic claims behind the split-precision kernels (csrc/conv_split.hip, csrc/split_f16.h),
 checked in numpy without a GPU:
 
-* bf16x6: three truncated bf16 pieces reproduce an fp32 value EXACTLY, and the six products with
-  piece-index sum <= 2, accumulated in fp32, are as close to fp64 as an fp32 FMA chain;
 * f16x3: two round-to-nearest f16 pieces of a power-of-two-scaled value leave <= 2^-22 relative
   error, and the three products x0w0 + x0w1 + x1w0 are again fp32-chain accurate — including
   operands whose magnitudes span many binades below the scale group's maximum.
@@ -10,18 +8,6 @@ Plus the host-side tile planner of the split conv (pure Python).
 """
 import numpy as np
 import pytest
-
-
-def _bf16_trunc(x):
-    return (x.astype(np.float32).view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
-
-
-def _split_bf16(x):
-    p0 = _bf16_trunc(x)
-    r1 = (x - p0).astype(np.float32)
-    p1 = _bf16_trunc(r1)
-    p2 = (r1 - p1).astype(np.float32)
-    return p0, p1, p2
 
 
 def _split_f16(x, scale_exp):
@@ -43,27 +29,6 @@ def _blocked_sum(terms, K, blk):
         for a, b in terms:
             acc = (acc.astype(np.float64) + a[:, k0:k0 + blk].astype(np.float64) @ b[k0:k0 + blk].astype(np.float64)).astype(np.float32)
     return acc
-
-
-def test_bf16_pieces_are_exact_and_six_products_match_fp32_chain():
-    rng = np.random.default_rng(0)
-    K, M, N = 576, 128, 64
-    a = (rng.standard_normal((M, K)) * np.exp2(rng.integers(-30, 30, (M, K)))).astype(np.float32)
-    p = _split_bf16(a)
-    assert np.array_equal((p[0].astype(np.float64) + p[1] + p[2]).astype(np.float32), a)
-    assert all(np.array_equal(_bf16_trunc(q), q) for q in p)          # every piece is a bf16 value
-    a = rng.standard_normal((M, K)).astype(np.float32)
-    b = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
-    ref = a.astype(np.float64) @ b.astype(np.float64)
-    A, Bp = _split_bf16(a), _split_bf16(b)
-    terms = [(A[i], Bp[j]) for (i, j) in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))]
-    got = _blocked_sum(terms, K, 16)
-    chain = np.zeros((M, N), np.float32)
-    for k in range(K):
-        chain = (chain + a[:, k:k + 1] * b[k:k + 1, :]).astype(np.float32)
-    scale = np.abs(ref).max()
-    e_split, e_chain = np.abs(got - ref).max() / scale, np.abs(chain - ref).max() / scale
-    assert e_split < 1e-6 and e_split < 2 * e_chain, (e_split, e_chain)
 
 
 @pytest.mark.parametrize("spread", [0, 12, 24])

@@ -10,7 +10,6 @@ for m in fp32 f16x3; do
   $B --math $m --planes 96 --steps 20 | tail -1 > $OUT/hot_path_mlp_k7_d96_gb32_$m.json
   for b in 1 4 8 16 32; do $B --math $m --batch $b --steps 20 | tail -1 > $OUT/hot_path_mlp_k7_gb${b}_$m.json; done
 done
-$B --math bf16x6 --steps 20 | tail -1 > $OUT/hot_path_mlp_k7_gb32_bf16x6.json
 for f in $OUT/*.json; do python - "$f" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read()); r=d["roofline"]

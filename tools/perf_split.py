@@ -17,7 +17,7 @@ for cin, cout, H, W in shapes:
     x = torch.randn(N, H, W, cin, device=dev)
     row = []
     outs = []
-    for math in ("fp32", "bf16x6", "f16x3"):
+    for math in ("fp32", "f16x3"):
         p = nhwc.Plan(dev, math=math)
         xin = nhwc.View(x, 0, cin)
         out = p.buffer(N, H, W, cout)
@@ -37,4 +37,4 @@ for cin, cout, H, W in shapes:
         row.append((ms, p.flops / ms / 1e9, p.ops[0].tile_m))
         outs.append(out.dense().clone())
     err = [float((outs[0] - o).abs().max() / outs[0].abs().max()) for o in outs[1:]]
-    print(f"N={N} {cin:4d}->{cout:4d} @{H}x{W}: fp32 {row[0][0]:6.3f} ms {row[0][1]:5.1f} TF | bf16x6 {row[1][0]:6.3f} ms {row[1][1]:5.1f} x{row[0][0]/row[1][0]:.2f} d={err[0]:.1e} | f16x3 {row[2][0]:6.3f} ms {row[2][1]:5.1f} x{row[0][0]/row[2][0]:.2f} d={err[1]:.1e}")
+    print(f"N={N} {cin:4d}->{cout:4d} @{H}x{W}: fp32 {row[0][0]:6.3f} ms {row[0][1]:5.1f} TF | f16x3 {row[1][0]:6.3f} ms {row[1][1]:5.1f} x{row[0][0]/row[1][0]:.2f} d={err[0]:.1e}")
