@@ -78,17 +78,21 @@ struct BinArgs {
     const float *sw2;     // F16 kernel: per-row scale of the f16-packed W2 (w2 then points to idh_pack_mlp_weight_f16 output)
 };
 
-// Persistent 512-thread workgroups (one per CU): W2 (64 KiB) and, when it fits, the feature part
+// Persistent 512- / 768-thread workgroups (one per CU): W2 (64 KiB) and, when it fits, the feature part
 // of W1 (8 KiB per 16 input channels) are staged once into LDS in MFMA fragment order and shared
 // by the 8 waves; each wave then streams 16-pixel tiles.
-constexpr int kBinThreads = 512, kBinWaves = kBinThreads / 64;
+// 8 waves (2 per SIMD) for the split-precision variant (183 VGPRs); 12 waves (3 per SIMD) for the fp32 kernel, whose 142
+// VGPRs allow it: a third wave per SIMD gives the MFMA pipe something to do while the other two evaluate ELUs
+// (measured: see DESIGN.md 4.3).
+constexpr int bin_threads(bool f16) { return f16 ? 512 : 768; }
 constexpr int kW1LdsMaxBlocks = 4;  // Cf <= 64 -> W1f in LDS (32 KiB); wider scales read it via L1/L2
 
 // F16 = true: layer 2 (the per-plane 128x128 GEMM, ~95 % of the flops) runs in "f16x3" split precision
 // on v_mfma_f32_16x16x32_f16 (csrc/split_f16.h): W2 in LDS as two f16 pieces (same 64 KiB), the hidden
 // vector of each pixel scaled by its own power of two, 96 MFMAs per plane instead of 256 fp32 ones.
 template <int TM, bool F16>
-__global__ __launch_bounds__(kBinThreads) void binary_mlp_k(const BinArgs a) {
+__global__ __launch_bounds__(bin_threads(F16)) void binary_mlp_k(const BinArgs a) {
+    constexpr int kBinThreads = bin_threads(F16), kBinWaves = kBinThreads / 64;
     static_assert(!F16 || TM == 1, "split-precision path is written for one pixel sub-tile per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4 *sW2 = reinterpret_cast<f32x4 *>(smem_raw);
@@ -514,7 +518,8 @@ static int binary_mlp_launch(BinArgs a, int B, void *stream, bool f16) {
     const long long M = a.M;
     constexpr int TM = 1;
     const int tiles = (int)((M + 16 * TM - 1) / (16 * TM));
-    int grid = (tiles + kBinWaves - 1) / kBinWaves;
+    const int waves = bin_threads(f16) / 64;
+    int grid = (tiles + waves - 1) / waves;
     if (grid > 256) grid = 256;  // persistent: one workgroup per CU (LDS-resident weights)
     (void)B;
     const int cblocks = (a.Cf + 15) >> 4;
@@ -531,9 +536,9 @@ static int binary_mlp_launch(BinArgs a, int B, void *stream, bool f16) {
     }
     if (f16) {
         a.sw2 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.w2) + (size_t)4 * kNS * 2 * 64 * 16);
-        hipLaunchKernelGGL((binary_mlp_k<TM, true>), dim3(grid), dim3(kBinThreads), lds, idh_stream(stream), a);
+        hipLaunchKernelGGL((binary_mlp_k<TM, true>), dim3(grid), dim3(bin_threads(true)), lds, idh_stream(stream), a);
     } else
-        hipLaunchKernelGGL((binary_mlp_k<TM, false>), dim3(grid), dim3(kBinThreads), lds, idh_stream(stream), a);
+        hipLaunchKernelGGL((binary_mlp_k<TM, false>), dim3(grid), dim3(bin_threads(false)), lds, idh_stream(stream), a);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }

@@ -13,7 +13,7 @@ fs = glob.glob("$OUT/sq/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"[A-Za-z_0-9:]+(<[0-9, ]+>)?", name); return m.group(0) if m else name[:40]
+    m = re.match(r"[A-Za-z_0-9:]+(<[0-9a-z, ]+>)?", name); return m.group(0) if m else name[:40]
 for r in csv.DictReader(open(fs[0])):
     k = short(r["Kernel_Name"]); acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE": n[k] += 1

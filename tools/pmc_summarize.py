@@ -4,7 +4,7 @@ out = sys.argv[1]
 res = collections.defaultdict(lambda: {"calls": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"[A-Za-z_0-9:]+(<[0-9, ]+>)?", name)
+    m = re.match(r"[A-Za-z_0-9:]+(<[0-9a-z, ]+>)?", name)
     return m.group(0) if m else name[:40]
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     fs = glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True)
