@@ -127,6 +127,16 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+def param_version(t) -> int:
+    """Version counter of a parameter (bumped by in-place updates: the packed-weight caches key on it).  Tensors
+    created under torch.inference_mode() do not track one — they cannot be modified in place outside inference mode
+    either, so a constant is a valid key for them."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 def require_cuda_f32(*tensors):
     for t in tensors:
         if t is None:

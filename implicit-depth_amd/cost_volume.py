@@ -235,7 +235,7 @@ class FeatureVolumeManager(CostVolumeManager):
     def _packed(self):
         lins = [self.mlp.net[0], self.mlp.net[2], self.mlp.net[4]]
         math = self._math()
-        key = (math,) + tuple((p.data_ptr(), p._version) for p in self.mlp.parameters())
+        key = (math,) + tuple((p.data_ptr(), _lib.param_version(p)) for p in self.mlp.parameters())
         c = self.__dict__.get("_idh_fv")
         if c is not None and c[0] == key:
             return c[1]

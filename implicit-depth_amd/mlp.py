@@ -29,7 +29,7 @@ def mlp_math_of(net) -> str:
 def _prepared(seq: nn.Sequential, n_feat: int, use_prior: bool, math: str = "fp32"):
     """Fragment-ordered copies of one scale's three Linear layers, cached on the module."""
     l1, l2, l3 = seq[0], seq[2], seq[4]
-    key = (math,) + tuple((p.data_ptr(), p._version) for p in seq.parameters())
+    key = (math,) + tuple((p.data_ptr(), _lib.param_version(p)) for p in seq.parameters())
     c = seq.__dict__.get("_idh_mlp")
     if c is not None and c[0] == key:
         return c[1]

@@ -130,7 +130,7 @@ def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
     """[tap][ci/4][co][ci%4] copy of a Conv2d weight, cached on the module and refreshed when
     the parameter is modified in place or moved."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(w.device))
+    key = (w.data_ptr(), _lib.param_version(w), str(w.device))
     cached = getattr(conv, "_idh_packed", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -156,7 +156,7 @@ def split_packed_weight(conv: nn.Conv2d, math: str, proj: Optional[nn.Conv2d] = 
     cached like ``packed_weight``."""
     w = conv.weight
     w1 = proj.weight if proj is not None else None
-    key = (w.data_ptr(), w._version, str(w.device), math) + ((w1.data_ptr(), w1._version) if w1 is not None else ())
+    key = (w.data_ptr(), _lib.param_version(w), str(w.device), math) + ((w1.data_ptr(), _lib.param_version(w1)) if w1 is not None else ())
     cached = getattr(conv, "_idh_packed_split", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -580,7 +580,7 @@ def _plan_cache(module: nn.Module) -> Dict:
 
 
 def _param_key(module: nn.Module):
-    return (math_of(module),) + tuple((p.data_ptr(), p._version) for p in module.parameters())
+    return (math_of(module),) + tuple((p.data_ptr(), _lib.param_version(p)) for p in module.parameters())
 
 
 def _check_in(*ts):

@@ -137,3 +137,18 @@ def test_temporal_sequence_with_prior_d96():
                     rendered_depth=rd.cuda(), prior_inputs=pin)
         assert rel_err(out["pred_0"].cpu(), logits_ref) < 2 * TOL
         prev_pred_ref, prev_pred, prev_pose = torch.sigmoid(logits_ref), torch.sigmoid(out["pred_0"]), cur_world_T_cam
+
+
+def test_model_built_under_inference_mode():
+    """Parameters created inside torch.inference_mode() have no version counter: the packed-weight / plan caches must
+    still work (regression: RuntimeError 'Inference tensors do not track version counter')."""
+    B, K, H, W, D, P = 1, 2, 16, 24, 8, 2
+    with torch.inference_mode():
+        model, inp, pyr, rd = _build(B, K, H, W, D, P)
+        model.cuda()
+        d = {k: v.cuda() for k, v in inp.items()}
+        out = model(d["cur_feats"], d["src_feats"], [t.cuda() for t in pyr], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
+                    rendered_depth=rd.cuda())
+        out2 = model(d["cur_feats"], d["src_feats"], [t.cuda() for t in pyr], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
+                     rendered_depth=rd.cuda())
+    assert torch.equal(out["pred_0"], out2["pred_0"]) and bool(torch.isfinite(out["pred_0"]).all())
