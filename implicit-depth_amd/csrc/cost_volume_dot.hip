@@ -810,7 +810,7 @@ static void cv_win_split(int B, int K, int H, int W, int D, int *psplit, int *un
 // 0 = automatic; otherwise the caller's choice when that kernel covers the shape (else -1)
 static int cv_pick_kernel(int forced, int B, int K, int H, int W, int D) {
     const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;  // 32-bit tap offsets within one (b,k) image
-    const bool win_ok = quad_ok && W >= kWW && H >= kWH && W < 65536 && H < 32768 && K <= kMaxPairs;
+    const bool win_ok = quad_ok && W >= kWW && H >= kWH && W < 32768 && H < 32768 && K <= kMaxPairs;  // PlaneBox / WinEntry pack coordinates in 15 / 16 bits
     (void)D;
     // measured (tools/perf_dot.py, 96x128 map, K=8, D=64): window 25 us/frame at B=32, 35 at B=8, 42 at B=4, 71 at B=1;
     // quad 51 / 57 / 57 / 59 -> a single frame (48 tiles) cannot fill 256 CUs with whole tiles and stays on the quad kernel

@@ -251,6 +251,7 @@ def lds_subtiles(cout: int) -> int:
 # Measured (tools/perf_levels.py <B> <threshold>, conv stage of the hot path): B=1 3.31 -> 3.04 ms, B=2 5.06 -> 4.88 ms,
 # B=4 and B=8 unchanged with 400; 800 / 1600 cost 1-1.5 % at B=4.
 NARROW_TILE_BELOW = 400
+NARROWEST_TILE_BELOW = 0  # below this many 64-channel workgroups use 16-channel tiles (0 = never)
 
 
 def choose_lds_tile(N: int, Ho: int, Wo: int, cout: int, chunks: int):
@@ -364,9 +365,10 @@ class Plan:
             if tm == 8 and FUSED_UP_ROWS == 4 and any(isinstance(v, CatView) for v, _ in srcs):
                 tm = 9
             tn = lds_subtiles(conv.out_channels)
-            if (tn == 4 and tm == 9 and NARROW_TILE_BELOW and not any(isinstance(v, CatView) for v, _ in srcs)
-                    and out.N * (-(-out.H // 4)) * (-(-out.W // 16)) * (conv.out_channels // 64) * split < NARROW_TILE_BELOW):
-                tn = 2
+            if tn == 4 and tm == 9 and NARROW_TILE_BELOW and not any(isinstance(v, CatView) for v, _ in srcs):
+                blocks64 = out.N * (-(-out.H // 4)) * (-(-out.W // 16)) * (conv.out_channels // 64) * split
+                if blocks64 < NARROW_TILE_BELOW:
+                    tn = 1 if blocks64 < NARROWEST_TILE_BELOW else 2
             tn = 0 if tn == 4 else tn
         else:
             tm, tn, split = choose_tiles(M, conv.out_channels, steps)

@@ -8,6 +8,7 @@ from bench import HotPathWorkload
 import argparse
 a = argparse.Namespace(batch=int(sys.argv[1]) if len(sys.argv) > 1 else 4, views=7, planes=64, height=384, width=512, volume="mlp")
 if len(sys.argv) > 2: nhwc.NARROW_TILE_BELOW = int(sys.argv[2])  # narrow (32-channel) tiles below this many workgroups
+if len(sys.argv) > 3: nhwc.NARROWEST_TILE_BELOW = int(sys.argv[3])  # 16-channel tiles below this many
 wl = HotPathWorkload(a, torch.device("cuda"), 0)
 for _ in range(2): wl.step()
 torch.cuda.synchronize()
