@@ -8,6 +8,7 @@ assigns it over the attribute.  ``BDModel.forward`` / ``DepthModel.forward`` the
 """
 from __future__ import annotations
 
+import torch
 from torch import nn
 
 from . import cost_volume as cv
@@ -115,3 +116,56 @@ def hot_path_of(model: nn.Module, min_depth: float = 0.25, max_depth: float = 5.
                   conv_math=getattr(model.cost_volume_net, "conv_math", None), matching_model=mm)
     hot.thresholder = getattr(model, "thresholder", None)  # test_bd.py:103 sets it on the model for the infer_depth search
     return hot
+
+
+def fused_forward(model: nn.Module, math: str = None):
+    """A replacement for ``BDModel.forward`` / ``DepthModel.forward`` at inference time (bd_model.py:175-311,
+    depth_model.py:280-440): same arguments, same output dictionary, but everything between the third-party backbones
+    and the outputs runs as ONE fused pass of ``HotPath`` (matching-encoder head, volume, CVEncoder, decoder, occlusion
+    MLP / depth heads) instead of module by module.  The third-party image encoder and ResNet18 stem still run as the
+    model's own torch modules.  ``model.forward = fused_forward(model)`` installs it; the model's config / checkpoint
+    surface is untouched (the hot-path modules are converted in place and share their parameters with the pipeline)."""
+    from . import _lib
+
+    hot = hot_path_of(model, math=math)
+    is_bd = hasattr(model, "binary_mlp")
+    opts = model.run_opts
+    if getattr(opts, "matching_scale", 1) != 1:
+        raise _lib.IdhError("the fused forward covers matching_scale = 1 (every shipped configuration)")
+
+    def forward(phase, cur_data, src_data, unbatched_matching_encoder_forward=False, return_mask=False, infer_depth=False, infer_res=None):
+        if phase == "train":
+            raise _lib.IdhError("the fused forward is an inference path (no autograd, no flip augmentation)")
+        del infer_res  # unused by the reference as well
+        ms = opts.matching_scale
+        cur_image, src_image = cur_data["image_b3hw"], src_data["image_b3hw"]
+        src_K, cur_invK = src_data[f"K_s{ms}_b44"], cur_data[f"invK_s{ms}_b44"]
+        # relative poses, bd_model.py:196-204
+        src_cam_T_cur_cam = src_data["cam_T_world_b44"] @ cur_data["world_T_cam_b44"].unsqueeze(1)
+        cur_cam_T_src_cam = cur_data["cam_T_world_b44"].unsqueeze(1) @ src_data["world_T_cam_b44"]
+        hot.thresholder = getattr(model, "thresholder", None)
+        with torch.inference_mode():
+            cur_feats = list(model.encoder(cur_image))  # third-party image encoder (strong image prior), bd_model.py:218
+            kw = {}
+            mc = msrc = None
+            if hot.matching_model is not None:
+                # third-party stem on frame b's current image followed by its K source images (bd_model.py:149-160);
+                # the encoder head runs inside the pipeline
+                frames = torch.cat([cur_image.unsqueeze(1), src_image], 1)
+                stem = model.matching_model.net[:5]
+                flat = frames.flatten(0, 1)
+                l1 = torch.cat([stem(f) for f in flat.split(1, 0)], 0) if unbatched_matching_encoder_forward else stem(flat)
+                kw["matching_layer1"] = l1.unflatten(0, frames.shape[:2])
+            else:
+                mc, msrc = model.compute_matching_feats(cur_image, src_image, unbatched_matching_encoder_forward)
+            if is_bd:
+                kw["rendered_depth"] = cur_data["rendered_depth"]
+                kw["infer_depth"] = infer_depth
+                if getattr(opts, "use_prior", False) and cur_data.get("prior_prediction", None) is not None:
+                    kw["prior_inputs"] = {k: cur_data[k] for k in ("prior_prediction", "world_T_cam_b44", "prior_cam_T_world", "K_s0_b44", "invK_s0_b44")}
+            out = hot(mc, msrc, cur_feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK, return_mask=return_mask, **kw)
+        if "prior_mask" in out:
+            cur_data["prior_mask"] = out.pop("prior_mask")  # run_mlp_val stores it on the inputs (bd_model.py:431)
+        return out
+
+    return forward

@@ -208,3 +208,83 @@ def test_full_size_depthmodel_forward_golden():
             np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g[nm + "_chk"][1:], rtol=1e-3)
     assert ((out["lowest_cost_bhw"].cpu()[:, ::3, ::4] - torch.as_tensor(g["lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3
     assert (out["overall_mask_bhw"].cpu()[:, ::3, ::4] != torch.as_tensor(g["mask_slice"])).float().mean().item() < 2e-3
+
+
+# ---- forward-level drop-in: from RAW IMAGES, through stand-in backbones with the weights the reference run used ------------
+class _RunOpts:
+    matching_scale = 1
+    min_matching_depth = 0.25
+    max_matching_depth = 5.0
+    use_prior = False
+
+
+def _standin_model(K, volume, decoder="bd"):
+    """An object with the attribute tree of the reference BDModel / DepthModel (same names -> syn.fill_state_dict gives
+    the tensors gen_golden.py gave the reference model): stub image encoder + stub ResNet stem (as in the golden run),
+    drop-in hot-path modules."""
+    from implicit_depth_amd import cost_volume as cv
+    from implicit_depth_amd import networks as net
+
+    m = nn.Module()
+    m.encoder = syn.StubImageEncoder()
+    H, W, D = 24, 32, 16
+    m.cost_volume = cv.FeatureVolumeManager(H, W, D, num_source_views=K) if volume == "mlp" else cv.CostVolumeManager(H, W, D)
+    stem = syn.StubResnetStem()
+    m.matching_model = net.ResnetMatchingEncoder([stem.conv1, stem.bn1, stem.relu, stem.maxpool, stem.layer1], 16)
+    m.cost_volume_net = net.CVEncoder(D, [48, 64, 160, 256], [64, 128, 256, 384])
+    if decoder == "bd":
+        m.depth_decoder = net.BDDecoderPP([24] + m.cost_volume_net.num_ch_enc)
+        m.binary_mlp = net.BinaryMLPNetwork(m.depth_decoder.num_ch_dec, mlp_size=128, use_prior=False)
+    else:
+        m.depth_decoder = net.DepthDecoderPP([24] + m.cost_volume_net.num_ch_enc)
+    m.run_opts = _RunOpts()
+    m.thresholder = None
+    return m
+
+
+@pytest.mark.parametrize("unbatched", [True, False])
+@pytest.mark.parametrize("volume", ["dot", "mlp"])
+def test_fused_forward_from_raw_images_matches_reference_bdmodel(volume, unbatched):
+    """dropin.fused_forward(model)("test", cur_data, src_data, ...) — BDModel.forward's own signature — starting at the
+    images: stub backbones in torch, everything else in one HotPath pass; golden G5 = the reference's BDModel.forward on
+    the same tuple with the same (name-keyed) weights."""
+    from implicit_depth_amd.dropin import fused_forward
+
+    g = load_golden(f"g5_bdmodel_{volume}")
+    K = int(g["K"])
+    m = _standin_model(K, volume)
+    syn.fill_state_dict(m, seed=30)
+    m.cuda().eval()
+    cur, src = syn.frame_tuple(1, K, 96, 128, seed=31, P=3)
+    cur = {k: v.cuda() for k, v in cur.items()}
+    src = {k: v.cuda() for k, v in src.items()}
+    fwd = fused_forward(m)
+    out = fwd("test", cur, src, unbatched_matching_encoder_forward=unbatched, return_mask=True)
+    assert rel_err(out["pred_0"].cpu(), g["pred_0"]) < TOL
+    assert ((out["lowest_cost_bhw"].cpu() - torch.as_tensor(g["lowest_cost"])).abs() > 1e-5).float().mean().item() < 5e-3
+    if volume == "mlp":
+        assert (out["overall_mask_bhw"].cpu() != torch.as_tensor(g["overall_mask"])).float().mean().item() < 2e-3
+        o2 = fwd("test", cur, src, unbatched_matching_encoder_forward=unbatched, infer_depth=True)
+        from hot_helpers import search_agrees
+
+        search_agrees(o2["search_depths"], g["search_depths"], g["search_margin"])
+    with pytest.raises(Exception):
+        fwd("train", cur, src)
+
+
+def test_fused_forward_from_raw_images_matches_reference_depthmodel():
+    from implicit_depth_amd.dropin import fused_forward
+
+    g = load_golden("g9_depthmodel")
+    K = int(g["K"])
+    m = _standin_model(K, "mlp", decoder="depth")
+    syn.fill_state_dict(m, seed=33)
+    m.cuda().eval()
+    cur, src = syn.frame_tuple(1, K, 96, 128, seed=34, P=1)
+    cur = {k: v.cuda() for k, v in cur.items()}
+    src = {k: v.cuda() for k, v in src.items()}
+    out = fused_forward(m)("test", cur, src, unbatched_matching_encoder_forward=True, return_mask=True)
+    for i in range(4):
+        assert rel_err(out[f"log_depth_pred_s{i}_b1hw"].cpu(), g[f"log_depth_pred_s{i}_b1hw"]) < TOL
+        assert rel_err(out[f"depth_pred_s{i}_b1hw"].cpu(), g[f"depth_pred_s{i}_b1hw"]) < 5 * TOL
+    assert sorted(k for k in out if "depth_pred" in k) == sorted(k for k in g if "depth_pred" in k)
