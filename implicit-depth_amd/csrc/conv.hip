@@ -245,6 +245,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 15, h = lane >> 4;
 
+
     // block -> (split, image, tile_y, tile_x, channel tile); channel tile fastest so the blocks
     // sharing an input tile are neighbours (same XCD after the remap -> L2 hits on the halo)
     unsigned blk = idh_xcd_remap(blk_in, nblk);
