@@ -28,6 +28,7 @@
 //     residual + LeakyReLU are applied on the accumulators before the single store;
 //   * layers with too few tiles to fill 256 CUs (12x16 / 24x32 maps) split K over `split_k`
 //     waves that write raw partials; a reduce kernel applies the epilogue (deterministic, no atomics).
+#include <algorithm>
 #include "conv_args.h"
 #include "../../include/idh_ops.h"
 
@@ -39,15 +40,29 @@ namespace {
 // so the K loop is branch-free.  Must cover the widest Cin_pad (host-checked).
 __device__ float g_zero_page[kZeroFloats];
 
+// idh_count_launches() replays idh_run_ops' launch decisions without launching anything
+thread_local bool t_dry_run = false;
+thread_local int t_launches = 0;
+#undef IDH_CHECK_LAUNCH
+#define IDH_CHECK_LAUNCH()                                              \
+    do {                                                                \
+        if (!t_dry_run && hipGetLastError() != hipSuccess) return IDH_ELAUNCH; \
+    } while (0)
+#define IDH_LAUNCH(...)                         \
+    do {                                        \
+        if (t_dry_run) ++t_launches;            \
+        else hipLaunchKernelGGL(__VA_ARGS__);   \
+    } while (0)
+
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, unsigned blk_in, unsigned nblk) {
     const int lane = threadIdx.x & 63;
     // readfirstlane: tell the compiler the wave index is uniform, so the tile / split / step
     // bookkeeping below lives in SGPRs and the K loop uses scalar branches
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ln = lane & 15, h = lane >> 4;
 
-    const unsigned blk = idh_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned blk = idh_xcd_remap(blk_in, nblk);
     const long long wg = (long long)blk * 4 + wave;
     const long long total = (long long)a.MT * a.NT * a.S;
     if (wg >= total) return;
@@ -193,6 +208,11 @@ __global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
     }
 }
 
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void conv_mfma_k(const ConvArgs a) {
+    conv_mfma_body<TM, TN>(a, blockIdx.x, gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------
 // LDS-staged variant for the layers that carry ~95% of the flops: 3x3, stride 1, zero padding,
 // Cout % 64 == 0, optionally fused with a 1x1 projection of a second tensor.
@@ -228,17 +248,22 @@ struct LdsConvArgs {
 // NJ = 16-channel output sub-tiles per workgroup: 4 (64 channels, the default), 2 or 1 — narrow layers (the matching
 // encoder's 128 -> 16 conv) and small maps at small batch (twice / four times the workgroups) use the narrower tiles;
 // the staged halo is then amortised over fewer MFMAs but still feeds all 9 taps from one HBM/L2 read.
+// LDS image sizes (float4): halo of one 16-channel chunk / its 9-tap weight panel (36 KiB at NJ = 4)
+constexpr int lds_a_slots(int RW) { return (4 * RW + 2) * 4 * kHaloW; }  // 720 (RW=2) / 432 (RW=1)
+constexpr int lds_b_slots(int NJ) { return 9 * 4 * 16 * NJ; }
+
+// sA / sB: the workgroup's LDS images (declared by the kernel so that a kernel hosting several instantiations
+// of this body — level_k — allocates them once)
 template <int RW, bool UP, int NJ>
-__device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned blk_in, unsigned nblk) {
+__device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned blk_in, unsigned nblk, f32x4 *__restrict__ sA,
+                                                 f32x4 *__restrict__ sB) {
     constexpr int kN = 16 * NJ;                  // output channels per workgroup
-    constexpr int kBSlots3 = 9 * 4 * kN;         // weight panel of one 16-channel chunk, float4
+    constexpr int kBSlots3 = lds_b_slots(NJ);    // weight panel of one 16-channel chunk, float4
     constexpr int kBLoads = (kBSlots3 + 255) / 256;
-    constexpr int kLT_H = 4 * RW, kHaloH = kLT_H + 2;
-    constexpr int kASlots = kHaloH * 4 * kHaloW;  // 720 (RW=2) / 432 (RW=1) float4
+    constexpr int kLT_H = 4 * RW;
+    constexpr int kASlots = lds_a_slots(RW);  // (kLT_H + 2)-row halo
     constexpr int kALoads = (kASlots + 255) / 256;
     constexpr int kCLoads = (kLT_H * kLT_W * 4) / 256;  // centre pixels for the 1x1 source
-    __shared__ f32x4 sA[kASlots];
-    __shared__ f32x4 sB[kBSlots3];  // 36 KiB at NJ = 4
     const ConvArgs &a = la.c;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -480,12 +505,16 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
 
 template <int RW, bool UP, int NJ = 4>
 __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
-    conv3x3_lds_body<RW, UP, NJ>(la, blockIdx.x, gridDim.x);
+    __shared__ f32x4 sA[lds_a_slots(RW)];
+    __shared__ f32x4 sB[lds_b_slots(NJ)];
+    conv3x3_lds_body<RW, UP, NJ>(la, blockIdx.x, gridDim.x, sA, sB);
 }
 // fused-upsample variants: keep 3 workgroups / CU (what the LDS footprint allows) although the 4x prefetch wants ~180 VGPRs
 template <int RW>
 __global__ __launch_bounds__(256, 3) void conv3x3_lds_up_k(const LdsConvArgs la) {
-    conv3x3_lds_body<RW, true, 4>(la, blockIdx.x, gridDim.x);
+    __shared__ f32x4 sA[lds_a_slots(RW)];
+    __shared__ f32x4 sB[lds_b_slots(4)];
+    conv3x3_lds_body<RW, true, 4>(la, blockIdx.x, gridDim.x, sA, sB);
 }
 
 // Grouped launch: up to kMaxGroup INDEPENDENT convolutions (same dependency level of a plan, see
@@ -501,10 +530,12 @@ struct LdsGroupArgs {
 
 template <int RW, bool UP, int NJ = 4>
 __global__ __launch_bounds__(256) void conv3x3_lds_group_k(const LdsGroupArgs g) {
+    __shared__ f32x4 sA[lds_a_slots(RW)];
+    __shared__ f32x4 sB[lds_b_slots(NJ)];
     int idx = 0;
     for (int i = 1; i < g.n; ++i)
         if (blockIdx.x >= g.start[i]) idx = i;
-    conv3x3_lds_body<RW, UP, NJ>(g.op[idx], blockIdx.x - g.start[idx], g.start[idx + 1] - g.start[idx]);
+    conv3x3_lds_body<RW, UP, NJ>(g.op[idx], blockIdx.x - g.start[idx], g.start[idx + 1] - g.start[idx], sA, sB);
 }
 
 struct ReduceDesc {
@@ -574,12 +605,12 @@ __global__ __launch_bounds__(256) void pack_weight_k(const float *__restrict__ w
 
 // bilinear x2 (align_corners=False): out[2i] = .25 in[i-1] + .75 in[i], out[2i+1] = .75 in[i] + .25 in[i+1],
 // indices clamped at the border; evaluated as h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11).
-__global__ __launch_bounds__(256) void upsample2_k(const float *__restrict__ in, float *__restrict__ out, int N, int H,
-                                                   int W, int C, int in_cs, int out_cs) {
+__device__ __forceinline__ void upsample2_body(const float *__restrict__ in, float *__restrict__ out, int N, int H, int W, int C,
+                                               int in_cs, int out_cs, unsigned blk, unsigned nblk) {
     const int cq = C >> 2;
     const int Ho = 2 * H, Wo = 2 * W;
     const long long total = (long long)N * Ho * Wo * cq;
-    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
+    for (long long t = blk * 256ll + threadIdx.x; t < total; t += nblk * 256ll) {
         const int q = (int)(t % cq);
         long long p = t / cq;
         const int x = (int)(p % Wo);
@@ -605,6 +636,11 @@ __global__ __launch_bounds__(256) void upsample2_k(const float *__restrict__ in,
         o.w = hy0 * (wx0 * p00.w + wx1 * p01.w) + hy1 * (wx0 * p10.w + wx1 * p11.w);
         *reinterpret_cast<float4 *>(out + (((size_t)n * Ho + y) * Wo + x) * out_cs + 4 * q) = o;
     }
+}
+
+__global__ __launch_bounds__(256) void upsample2_k(const float *__restrict__ in, float *__restrict__ out, int N, int H,
+                                                   int W, int C, int in_cs, int out_cs) {
+    upsample2_body(in, out, N, H, W, C, in_cs, out_cs, blockIdx.x, gridDim.x);
 }
 
 // nearest x2 (F.interpolate(scale_factor=2, mode="nearest"), networks_fast.py:43): out[y,x] = in[y>>1, x>>1]
@@ -759,6 +795,38 @@ __global__ __launch_bounds__(256) void instnorm_apply_k(const float *__restrict_
     }
 }
 
+// One launch for a whole dependency level at small batch.  At one frame every level of the plan costs 10-35 us almost
+// regardless of its flops (launch, ramp, one K-loop latency chain, drain), and a level of the UNet++ grid holds up to
+// four different kinds of work — 4-row LDS convs with 64- and 32-channel tiles, a stride-2 direct conv, a bilinear
+// upsample feeding the next level's concat — that the homogeneous group kernel above cannot mix.  level_k hosts those
+// bodies behind one grid: blockIdx ranges select the member, so its independent ops fill the chip side by side.
+// (A persistent kernel with device-wide dependency counters was measured first and rejected: 768 workgroups
+// arriving at one agent-scope counter cost 33 us per round, 80 us with the release/acquire fences the non-coherent
+// per-XCD L2s need, against 10 us for a kernel boundary — tools/micro/flow_sync.hip.)
+enum { LV_LDS4 = 0, LV_LDS2 = 1, LV_MFMA14 = 2, LV_UP2 = 3 };
+struct LevelArgs {
+    int n;
+    unsigned start[kMaxGroup + 1];
+    int kind[kMaxGroup];
+    LdsConvArgs op[kMaxGroup];  // LV_UP2 uses c.s[0].{in, H, W, Cin, cs}, c.out, c.out_cs and c.M (= images)
+};
+
+__global__ __launch_bounds__(256) void level_k(const LevelArgs g) {
+    __shared__ f32x4 sA[lds_a_slots(1)];
+    __shared__ f32x4 sB[lds_b_slots(4)];
+    int idx = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (blockIdx.x >= g.start[i]) idx = i;
+    const unsigned blk = blockIdx.x - g.start[idx], nblk = g.start[idx + 1] - g.start[idx];
+    const LdsConvArgs &la = g.op[idx];
+    switch (g.kind[idx]) {
+        case LV_LDS4: conv3x3_lds_body<1, false, 4>(la, blk, nblk, sA, sB); break;
+        case LV_LDS2: conv3x3_lds_body<1, false, 2>(la, blk, nblk, sA, sB); break;
+        case LV_MFMA14: conv_mfma_body<1, 4>(la.c, blk, nblk); break;
+        default: upsample2_body(la.c.s[0].in, la.c.out, la.c.M, la.c.s[0].H, la.c.s[0].W, la.c.s[0].Cin, la.c.s[0].cs, la.c.out_cs, blk, nblk); break;
+    }
+}
+
 inline int ceil16(int v) { return (v + 15) & ~15; }
 
 // A validated conv op, ready to launch: either the LDS-staged kernel (lds_rows = 8 / 4) or the
@@ -873,18 +941,21 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
 }
 
 int launch_conv(const PreparedConv &pc, hipStream_t st) {
-    if (pc.lds_rows == 16) return launch_conv_split(pc.a, pc.n_img, pc.tm, pc.tn, st);
-    if (pc.lds_rows == 8 && pc.up) hipLaunchKernelGGL(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
-    else if (pc.lds_rows == 8 && pc.nj == 2) hipLaunchKernelGGL((conv3x3_lds_k<2, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
-    else if (pc.lds_rows == 8 && pc.nj == 1) hipLaunchKernelGGL((conv3x3_lds_k<2, false, 1>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
-    else if (pc.lds_rows == 4 && pc.nj == 2) hipLaunchKernelGGL((conv3x3_lds_k<1, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
-    else if (pc.lds_rows == 4 && pc.nj == 1) hipLaunchKernelGGL((conv3x3_lds_k<1, false, 1>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
-    else if (pc.lds_rows == 8) hipLaunchKernelGGL((conv3x3_lds_k<2, false>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
-    else if (pc.lds_rows == 4 && pc.up) hipLaunchKernelGGL(conv3x3_lds_up_k<1>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
-    else if (pc.lds_rows == 4) hipLaunchKernelGGL((conv3x3_lds_k<1, false>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    if (pc.lds_rows == 16) {
+        if (t_dry_run) { ++t_launches; return IDH_OK; }
+        return launch_conv_split(pc.a, pc.n_img, pc.tm, pc.tn, st);
+    }
+    if (pc.lds_rows == 8 && pc.up) IDH_LAUNCH(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8 && pc.nj == 2) IDH_LAUNCH((conv3x3_lds_k<2, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8 && pc.nj == 1) IDH_LAUNCH((conv3x3_lds_k<2, false, 1>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.nj == 2) IDH_LAUNCH((conv3x3_lds_k<1, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.nj == 1) IDH_LAUNCH((conv3x3_lds_k<1, false, 1>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8) IDH_LAUNCH((conv3x3_lds_k<2, false>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.up) IDH_LAUNCH(conv3x3_lds_up_k<1>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4) IDH_LAUNCH((conv3x3_lds_k<1, false>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else {
 #define IDH_CASE(TM_, TN_) \
-    if (pc.tm == TM_ && pc.tn == TN_) hipLaunchKernelGGL((conv_mfma_k<TM_, TN_>), dim3(pc.blocks), dim3(256), 0, st, pc.a);
+    if (pc.tm == TM_ && pc.tn == TN_) IDH_LAUNCH((conv_mfma_k<TM_, TN_>), dim3(pc.blocks), dim3(256), 0, st, pc.a);
         IDH_CASE(4, 4) IDH_CASE(2, 4) IDH_CASE(1, 4) IDH_CASE(4, 2) IDH_CASE(2, 2) IDH_CASE(1, 2) IDH_CASE(4, 1)
         IDH_CASE(2, 1) IDH_CASE(1, 1)
 #undef IDH_CASE
@@ -905,7 +976,7 @@ int launch_reduces(const PreparedConv *pcs, int n, hipStream_t st) {
     }
     if (g.n == 0) return IDH_OK;
     g.start[g.n] = cursor;
-    hipLaunchKernelGGL(splitk_reduce_group_k, dim3(cursor), dim3(256), 0, st, g);
+    IDH_LAUNCH(splitk_reduce_group_k, dim3(cursor), dim3(256), 0, st, g);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }
@@ -923,13 +994,51 @@ int launch_group(const PreparedConv *pcs, int n, hipStream_t st) {
     g.start[n] = cursor;
     bool any_up = false;
     for (int i = 0; i < n; ++i) any_up = any_up || pcs[i].up;
-    if (any_up) hipLaunchKernelGGL((conv3x3_lds_group_k<1, true>), dim3(cursor), dim3(256), 0, st, g);
-    else if (pcs[0].nj == 2) hipLaunchKernelGGL((conv3x3_lds_group_k<1, false, 2>), dim3(cursor), dim3(256), 0, st, g);
-    else if (pcs[0].nj == 1) hipLaunchKernelGGL((conv3x3_lds_group_k<1, false, 1>), dim3(cursor), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((conv3x3_lds_group_k<1, false>), dim3(cursor), dim3(256), 0, st, g);
+    if (any_up) IDH_LAUNCH((conv3x3_lds_group_k<1, true>), dim3(cursor), dim3(256), 0, st, g);
+    else if (pcs[0].nj == 2) IDH_LAUNCH((conv3x3_lds_group_k<1, false, 2>), dim3(cursor), dim3(256), 0, st, g);
+    else if (pcs[0].nj == 1) IDH_LAUNCH((conv3x3_lds_group_k<1, false, 1>), dim3(cursor), dim3(256), 0, st, g);
+    else IDH_LAUNCH((conv3x3_lds_group_k<1, false>), dim3(cursor), dim3(256), 0, st, g);
     IDH_CHECK_LAUNCH();
     return launch_reduces(pcs, n, st);
 }
+
+// Launch a heterogeneous level (see level_k): kinds[i] = LV_*, pcs[i] prepared (LV_UP2: only la.c's upsample fields).
+int launch_level(const PreparedConv *pcs, const int *kinds, int n, hipStream_t st) {
+    LevelArgs g{};
+    unsigned cursor = 0;
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        g.start[i] = cursor;
+        g.kind[i] = kinds[i];
+        g.op[i] = pcs[i].la;
+        if (kinds[i] == LV_MFMA14) g.op[i].c = pcs[i].a;  // prep_conv fills la for the LDS kernels only
+        cursor += pcs[i].blocks;
+    }
+    g.start[n] = cursor;
+    IDH_LAUNCH(level_k, dim3(cursor), dim3(256), 0, st, g);
+    IDH_CHECK_LAUNCH();
+    return launch_reduces(pcs, n, st);
+}
+
+// Level-launch member kind of a prepared conv, or -1
+int level_kind(const PreparedConv &pc) {
+    if (pc.up) return -1;
+    if (pc.lds_rows == 4 && pc.nj == 4) return LV_LDS4;
+    if (pc.lds_rows == 4 && pc.nj == 2) return LV_LDS2;
+    if (pc.lds_rows == 0 && pc.tm == 1 && pc.tn == 4) return LV_MFMA14;
+    return -1;
+}
+
+int check_upsample(const idh_op &op) {
+    const idh_conv_src &s = op.src[0];
+    if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0) return IDH_EINVAL;
+    return IDH_OK;
+}
+
+// Members of a level launch are small by construction (one frame / low-resolution maps): a member that fills the chip
+// for several rounds on its own gains nothing from sharing a grid and keeps its specialised kernel.
+constexpr unsigned kLevelMaxBlocks = 1024;
+constexpr unsigned kLevelUpsampleBlocks = 512;
 
 }  // namespace
 
@@ -958,51 +1067,85 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
         const idh_op &op = ops[i];
         const idh_conv_src &s = op.src[0];
         switch (op.kind) {
-            case IDH_OP_CONV: {
-                // gather the run of consecutive convs that share a (non-zero) group id: the host
-                // scheduler guarantees they are mutually independent
+            case IDH_OP_CONV:
+            case IDH_OP_UPSAMPLE2: {
+                // gather the run of consecutive ops that share a (non-zero) group id: the host scheduler guarantees they
+                // are mutually independent (same dependency level).  [i, i+cnt) = the homogeneous prefix of 4-row LDS convs
+                // (one conv3x3_lds_group_k grid); [i, i+run) = the mixed run level_k can host when every member is small.
                 PreparedConv pcs[kMaxGroup];
-                int cnt = 0;
-                int rc = prep_conv(op, pcs[0]);
-                if (rc != IDH_OK) return rc;
-                cnt = 1;
-                if (op.group != 0 && pcs[0].lds_rows == 4) {
-                    while (i + cnt < n && cnt < kMaxGroup && ops[i + cnt].kind == IDH_OP_CONV && ops[i + cnt].group == op.group) {
-                        rc = prep_conv(ops[i + cnt], pcs[cnt]);
+                int kinds[kMaxGroup];
+                int run = 0;
+                for (int j = i; j < n && run < kMaxGroup; ++j) {
+                    const idh_op &o = ops[j];
+                    if (j > i && (op.group == 0 || o.group != op.group)) break;
+                    PreparedConv &pc = pcs[run];
+                    if (o.kind == IDH_OP_CONV) {
+                        const int rc = prep_conv(o, pc);
                         if (rc != IDH_OK) return rc;
-                        if (pcs[cnt].lds_rows != 4 || pcs[cnt].nj != pcs[0].nj || (pcs[cnt].up && pcs[0].nj != 4)) break;
-                        ++cnt;
+                        kinds[run] = level_kind(pc);
+                    } else if (o.kind == IDH_OP_UPSAMPLE2) {
+                        const int rc = check_upsample(o);
+                        if (rc != IDH_OK) return rc;
+                        const idh_conv_src &us = o.src[0];
+                        pc = PreparedConv{};
+                        ConvArgs &c = pc.la.c;
+                        c.s[0].in = us.in; c.s[0].H = us.H; c.s[0].W = us.W; c.s[0].Cin = us.Cin; c.s[0].cs = us.cs;
+                        c.out = o.out; c.out_cs = o.out_cs; c.M = o.N; c.S = 1;
+                        pc.a = c;
+                        const long long tot = (long long)o.N * 4 * us.H * us.W * (us.Cin >> 2);
+                        pc.blocks = (unsigned)std::min<long long>(idh_cdiv(tot, 256), kLevelUpsampleBlocks);
+                        kinds[run] = LV_UP2;
+                    } else {
+                        break;
                     }
+                    ++run;
                 }
-                if (cnt > 1) {
+                int cnt = 0;  // homogeneous prefix
+                if (op.kind == IDH_OP_CONV && pcs[0].lds_rows == 4) {
+                    cnt = 1;
+                    while (cnt < run && ops[i + cnt].kind == IDH_OP_CONV && pcs[cnt].lds_rows == 4 && pcs[cnt].nj == pcs[0].nj &&
+                           (!pcs[cnt].up || pcs[0].nj == 4))
+                        ++cnt;
+                }
+                int mix = 0;  // mixed prefix of small members
+                while (mix < run && kinds[mix] >= 0 && pcs[mix].blocks <= kLevelMaxBlocks) ++mix;
+                int rc, used;
+                if (mix > cnt && mix > 1) {
+                    rc = launch_level(pcs, kinds, mix, st);
+                    used = mix;
+                } else if (cnt > 1) {
                     rc = launch_group(pcs, cnt, st);
-                } else {
+                    used = cnt;
+                } else if (op.kind == IDH_OP_CONV) {
                     rc = launch_conv(pcs[0], st);
                     if (rc == IDH_OK) rc = launch_reduces(pcs, 1, st);
+                    used = 1;
+                } else {
+                    const long long tot = (long long)op.N * 4 * s.H * s.W * (s.Cin >> 2);
+                    int grid = idh_cdiv(tot, 256);
+                    if (grid > 8192) grid = 8192;
+                    IDH_LAUNCH(upsample2_k, dim3(grid), dim3(256), 0, st, s.in, op.out, op.N, s.H, s.W, s.Cin, s.cs, op.out_cs);
+                    IDH_CHECK_LAUNCH();
+                    rc = IDH_OK;
+                    used = 1;
                 }
                 if (rc != IDH_OK) return rc;
-                i += cnt - 1;
+                i += used - 1;
                 break;
             }
-            case IDH_OP_UPSAMPLE2:
             case IDH_OP_UPSAMPLE2_NEAREST: {
                 if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0) return IDH_EINVAL;
                 const long long tot = (long long)op.N * 4 * s.H * s.W * (s.Cin >> 2);
                 int grid = idh_cdiv(tot, 256);
                 if (grid > 8192) grid = 8192;
-                if (op.kind == IDH_OP_UPSAMPLE2)
-                    hipLaunchKernelGGL(upsample2_k, dim3(grid), dim3(256), 0, st, s.in, op.out, op.N, s.H, s.W, s.Cin, s.cs,
-                                       op.out_cs);
-                else
-                    hipLaunchKernelGGL(upsample2_nearest_k, dim3(grid), dim3(256), 0, st, s.in, op.out, op.N, s.H, s.W, s.Cin,
-                                       s.cs, op.out_cs);
+                IDH_LAUNCH(upsample2_nearest_k, dim3(grid), dim3(256), 0, st, s.in, op.out, op.N, s.H, s.W, s.Cin, s.cs, op.out_cs);
                 IDH_CHECK_LAUNCH();
                 break;
             }
             case IDH_OP_NCHW_TO_NHWC: {
                 if (!s.in || !op.out || op.N <= 0 || op.N > 65535) return IDH_EINVAL;
                 const int HW = s.H * s.W;
-                hipLaunchKernelGGL(import_nchw_k, dim3(idh_cdiv(HW, 64), idh_cdiv(s.Cin, 32), op.N), dim3(256), 0, st, s.in,
+                IDH_LAUNCH(import_nchw_k, dim3(idh_cdiv(HW, 64), idh_cdiv(s.Cin, 32), op.N), dim3(256), 0, st, s.in,
                                    op.out, s.Cin, HW, op.out_cs);
                 IDH_CHECK_LAUNCH();
                 break;
@@ -1010,7 +1153,7 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
             case IDH_OP_NHWC_TO_NCHW: {
                 if (!s.in || !op.out || op.N <= 0 || op.N > 65535) return IDH_EINVAL;
                 const int HW = s.H * s.W;
-                hipLaunchKernelGGL(export_nchw_k, dim3(idh_cdiv(HW, 64), idh_cdiv(s.Cin, 32), op.N), dim3(256), 0, st, s.in,
+                IDH_LAUNCH(export_nchw_k, dim3(idh_cdiv(HW, 64), idh_cdiv(s.Cin, 32), op.N), dim3(256), 0, st, s.in,
                                    op.out, s.Cin, HW, s.cs);
                 IDH_CHECK_LAUNCH();
                 break;
@@ -1020,7 +1163,7 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 const long long M = (long long)op.N * s.H * s.W;
                 int grid = idh_cdiv(M, 256);
                 if (grid > 8192) grid = 8192;
-                hipLaunchKernelGGL(pointwise_head_k, dim3(grid), dim3(256), 0, st, s.in, s.w, op.bias, op.out, op.ws, M, s.Cin,
+                IDH_LAUNCH(pointwise_head_k, dim3(grid), dim3(256), 0, st, s.in, s.w, op.bias, op.out, op.ws, M, s.Cin,
                                    s.cs);
                 IDH_CHECK_LAUNCH();
                 break;
@@ -1030,7 +1173,7 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 const long long npix = (long long)op.N * s.H * s.W;
                 int grid = idh_cdiv(npix * (s.Cin >> 2), 256);
                 if (grid > 8192) grid = 8192;
-                hipLaunchKernelGGL(copy_nhwc_k, dim3(grid), dim3(256), 0, st, s.in, op.out, npix, s.Cin, s.cs, op.out_cs);
+                IDH_LAUNCH(copy_nhwc_k, dim3(grid), dim3(256), 0, st, s.in, op.out, npix, s.Cin, s.cs, op.out_cs);
                 IDH_CHECK_LAUNCH();
                 break;
             }
@@ -1040,16 +1183,16 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                     op.N <= 0 || op.N > 65535)
                     return IDH_EINVAL;
                 const int nchunks = idh_cdiv(HW, kInChunk);
-                hipLaunchKernelGGL(instnorm_stats_k, dim3(nchunks, op.N), dim3(256), 256 * 8 * sizeof(float), st, s.in, s.cs, C, HW,
+                IDH_LAUNCH(instnorm_stats_k, dim3(nchunks, op.N), dim3(256), 256 * 8 * sizeof(float), st, s.in, s.cs, C, HW,
                                    nchunks, op.ws);
                 IDH_CHECK_LAUNCH();
                 float *stats = op.ws + (size_t)op.N * nchunks * 2 * C;
-                hipLaunchKernelGGL(instnorm_finalize_k, dim3(op.N), dim3(256), 0, st, op.ws, C, HW, nchunks, stats);
+                IDH_LAUNCH(instnorm_finalize_k, dim3(op.N), dim3(256), 0, st, op.ws, C, HW, nchunks, stats);
                 IDH_CHECK_LAUNCH();
                 const long long total = (long long)op.N * HW * (C >> 2);
                 int gx = idh_cdiv(total, 256 * 4);  // ~4 float4 per thread
                 if (gx > 16384) gx = 16384;
-                hipLaunchKernelGGL(instnorm_apply_k, dim3(gx), dim3(256), 0, st, s.in, s.cs, op.out, op.out_cs, C, HW, total, stats, op.act,
+                IDH_LAUNCH(instnorm_apply_k, dim3(gx), dim3(256), 0, st, s.in, s.cs, op.out, op.out_cs, C, HW, total, stats, op.act,
                                    op.slope);
                 IDH_CHECK_LAUNCH();
                 break;
@@ -1059,4 +1202,12 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
         }
     }
     return IDH_OK;
+}
+
+extern "C" int idh_count_launches(const idh_op *ops, int n) {
+    t_dry_run = true;
+    t_launches = 0;
+    const int rc = idh_run_ops(ops, n, nullptr);
+    t_dry_run = false;
+    return rc == IDH_OK ? t_launches : rc;
 }

@@ -276,6 +276,21 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
                 }
+                if constexpr (KT > 0) {
+                    // Scheduling hint (unrolled view loop = one scheduling region): ask for "1 MFMA, 2 VALU" groups instead
+                    // of a ~100-instruction vector block followed by 32 back-to-back matrix ops.  The machine scheduler
+                    // only partly honours it, but more of the next view's projection issues under this view's MFMAs:
+                    // 17.81 -> 17.32 ms per 32 frames (K=7, D=64).  Measured and rejected (profiles/r02/README.md): 3 or 4
+                    // VALU per MFMA (17.4-17.5), a plain sched_barrier per view (17.29, same), and hand-made three-stage
+                    // pipelines (MFMAs of view k next to the blend of k+1 and the projection of k+2) left to the scheduler
+                    // (18.29), fenced in groups of 4 MFMAs (17.69) or fenced per MFMA (18.10): with two waves per SIMD the
+                    // other wave's vector work already fills most of the gaps.
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                }
                 cur = nxt;
             }
             // rays / ray angles of this lane's two views (cost_volume.py:630-659)

@@ -222,6 +222,10 @@ def choose_split_rows(N: int, Ho: int, Wo: int, cout: int) -> int:
 FUSE_UPSAMPLE = False
 FUSED_UP_ROWS = 4
 
+# One launch per dependency level where its members are small (one frame, low-resolution maps): idh_run_ops merges the
+# consecutive ops of a level that carry its group id into one ``level_k`` grid when each has <= 1024 workgroups.
+MERGE_LEVELS = True
+
 TARGET_WAVES = 2048  # ~2 waves per SIMD over 256 CUs x 4 SIMDs
 MIN_WAVES = 1024
 
@@ -254,6 +258,10 @@ NARROW_TILE_BELOW = 400
 NARROWEST_TILE_BELOW = 0  # below this many 64-channel workgroups use 16-channel tiles (0 = never)
 
 
+SPLIT_MIN_CHUNKS = 6
+SPLIT_MAX = 16
+
+
 def choose_lds_tile(N: int, Ho: int, Wo: int, cout: int, chunks: int):
     """(tile code, split): 8-row tiles (code 8) when they already give one full round of
     256 CUs x 3 resident workgroups, else 4-row tiles (code 9); split K only when the grid still
@@ -264,7 +272,7 @@ def choose_lds_tile(N: int, Ho: int, Wo: int, cout: int, chunks: int):
     if per_row_tiles * (-(-Ho // 8)) < 768:
         code, rows = 9, 4
     blocks = per_row_tiles * (-(-Ho // rows))
-    return code, max(1, min(-(-768 // blocks), chunks // 6, 16))
+    return code, max(1, min(-(-768 // blocks), chunks // SPLIT_MIN_CHUNKS, SPLIT_MAX))
 
 
 def choose_tiles(M: int, cout: int, steps: int):
@@ -507,6 +515,20 @@ class Plan:
         — the reference executes them strictly one after another."""
         self.schedule_segments(0)
 
+    @staticmethod
+    def _launch_rank(op) -> tuple:
+        """Order of the ops of one dependency level, and which of them carry the level's group id (rank < 3):
+        4-row LDS convs first, by channel tile (one ``conv3x3_lds_group_k`` grid per run of equal tiles); then, with
+        ``MERGE_LEVELS``, the other members a mixed ``level_k`` launch can host (csrc/conv.hip: the stride-2 /
+        1x1 direct conv with 16x64 wave tiles, bilinear x2 upsampling); everything else runs on its own."""
+        if op.kind == OP_CONV and op.tile_m == 9:
+            return (0, op.tile_n)
+        if MERGE_LEVELS and op.kind == OP_CONV and op.tile_m == 1 and op.tile_n == 4:
+            return (1, 0)
+        if MERGE_LEVELS and op.kind == OP_UPSAMPLE2:
+            return (2, 0)
+        return (3, 0)
+
     def schedule_segments(self, n_first: int) -> int:
         """``schedule()`` for a plan that is replayed in two pieces — ops [0, n_first) then the rest — because a
         kernel outside the plan (the fused cost volume) consumes the first piece's output and produces the second
@@ -522,10 +544,9 @@ class Plan:
                     mi = self.meta[i]
                     if _overlap(mi["writes"], mj["reads"]) or _overlap(mi["writes"], mj["writes"]) or _overlap(mi["reads"], mj["writes"]):
                         level[j] = max(level[j], level[i] + 1)
-            groupable = lambda k: self.ops[k].kind == OP_CONV and self.ops[k].tile_m == 9
-            order += sorted(range(lo, hi), key=lambda k: (level[k], 0 if groupable(k) else 1, self.ops[k].tile_n if groupable(k) else 0, k))
+            order += sorted(range(lo, hi), key=lambda k: (level[k],) + self._launch_rank(self.ops[k]) + (k,))
         for k in range(n):
-            self.ops[k].group = level[k] + 1 if (self.ops[k].kind == OP_CONV and self.ops[k].tile_m == 9) else 0
+            self.ops[k].group = level[k] + 1 if self._launch_rank(self.ops[k])[0] < 3 else 0
         self.ops = [self.ops[k] for k in order]
         self.meta = [self.meta[k] for k in order]
         self.levels = [level[k] for k in order]
@@ -554,6 +575,18 @@ class Plan:
             return
         base = C.addressof(arr) + start * C.sizeof(Op)
         _lib.check(L.idh_run_ops(C.c_void_p(base), end - start, _lib.stream_ptr()), "idh_run_ops")
+
+    def count_launches(self, start: int = 0, end: Optional[int] = None) -> int:
+        """Kernel launches ``run(start, end)`` issues (``idh_count_launches``: same decisions, nothing launched)."""
+        L = _bind()
+        arr = self._array()
+        end = len(self.ops) if end is None else end
+        if end <= start:
+            return 0
+        n = L.idh_count_launches(C.c_void_p(C.addressof(arr) + start * C.sizeof(Op)), end - start)
+        if n < 0:
+            _lib.check(n, "idh_count_launches")
+        return n
 
     def set_in(self, idx: int, t: torch.Tensor):
         """idx = op index returned at build time (stable across schedule())."""

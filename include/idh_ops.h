@@ -4,7 +4,8 @@
  * The reference runs CVEncoder / BDDecoderPP / DepthDecoderPP (modules/networks.py:20-215)
  * as ~150 nn.Conv2d + F.interpolate + torch.cat calls.  Here a network pass is a flat array
  * of idh_op descriptors, built once per (module, shape) by the host and submitted with ONE
- * call, idh_run_ops(); every op is one gfx950 kernel launch on the given stream.
+ * call, idh_run_ops(); an op is one gfx950 kernel launch on the given stream, or shares a launch with the other
+ * independent ops of its dependency level (idh_op.group).
  * All activations are NHWC fp32.  "cs" = channel stride = floats between consecutive pixels
  * (>= channel count), which is how torch.cat along channels is eliminated: producers write
  * straight into a channel slice of the consumer's input buffer.
@@ -73,8 +74,11 @@ typedef struct idh_op {
                                kernel (3x3 stride 1, one source, Cout % 64 == 0; src[0].w =
                                idh_pack_conv_weight_split output of the same mode); there tile_n = 8
                                selects 8-row instead of 16-row tiles */
-    int32_t group;        /* != 0: consecutive conv ops with the same id are mutually independent and
-                               may be launched as ONE grid (see Plan.schedule in nhwc.py) */
+    int32_t group;        /* != 0: consecutive CONV / UPSAMPLE2 ops with the same id are mutually independent (one
+                               dependency level of the plan, see Plan.schedule in nhwc.py) and may be launched as
+                               ONE grid: runs of 4-row LDS convs with equal channel tiles always are; a mixed run
+                               (4-row LDS convs with 64- / 32-channel tiles, the 16x64-tile direct conv, bilinear
+                               upsampling) is when each member has <= 1024 workgroups, i.e. at small batch */
 } idh_op;
 
 /* Repack OIHW conv weights (reference nn.Conv2d layout) for the MFMA B-fragment loads:
@@ -104,6 +108,10 @@ size_t idh_sizeof_op(void);
 
 /* Launch n ops in order on `stream`. `ops_host` is HOST memory (pointers inside are device). */
 int idh_run_ops(const idh_op *ops_host, int n, void *stream);
+
+/* Number of kernel launches idh_run_ops() would issue for these ops (same validation and grouping decisions, nothing
+ * is launched; usable without a GPU), or a negative IDH_E* code. */
+int idh_count_launches(const idh_op *ops_host, int n);
 
 #ifdef __cplusplus
 }

@@ -64,3 +64,49 @@ def test_op_descriptor_layout_matches_library():
     assert ctypes.sizeof(nhwc.Op) == _lib.lib().idh_sizeof_op()
     assert _lib.lib().idh_packed_weight_floats(40, 24, 3) == 9 * 32 * 48
     assert _lib.lib().idh_run_ops(None, 0, None) == 0
+
+
+def _conv_op(nhwc, N, H, W, cin, cout, tile_m, tile_n, group, split_k=1, stride=1):
+    op = nhwc.Op()
+    op.kind, op.N = nhwc.OP_CONV, N
+    s = op.src[0]
+    s.in_, s.w, s.cs, s.H, s.W, s.Cin, s.ks, s.stride = 0x1000, 0x2000, cin, H, W, cin, 3, stride
+    op.out, op.out_cs, op.Ho, op.Wo, op.Cout = 0x3000, cout, H // stride, W // stride, cout
+    op.ws = 0x4000 if split_k > 1 else None
+    op.split_k, op.tile_m, op.tile_n, op.group = split_k, tile_m, tile_n, group
+    return op
+
+
+def test_launch_grouping_decisions_without_a_gpu():
+    """idh_count_launches replays idh_run_ops' decisions (include/idh_ops.h, idh_op.group): ops of one dependency level
+    share a launch when they are equal-tile 4-row LDS convs (any size) or a mixed run of small members."""
+    import ctypes as C
+
+    from implicit_depth_amd import _lib, nhwc
+
+    L = _lib.lib()
+
+    def count(ops):
+        arr = (nhwc.Op * len(ops))(*ops)
+        return L.idh_count_launches(C.cast(arr, C.c_void_p), len(ops))
+
+    up = nhwc.Op()
+    up.kind, up.N, up.group = nhwc.OP_UPSAMPLE2, 1, 5
+    up.src[0].in_, up.src[0].cs, up.src[0].H, up.src[0].W, up.src[0].Cin = 0x1000, 64, 48, 64, 64
+    up.out, up.out_cs = 0x3000, 64
+    lds64 = lambda N, g: _conv_op(nhwc, N, 96, 128, 64, 64, 9, 0, g)
+    lds32 = lambda N, g: _conv_op(nhwc, N, 96, 128, 64, 64, 9, 2, g)
+    down = lambda N, g, sk=1: _conv_op(nhwc, N, 96, 128, 64, 128, 1, 4, g, split_k=sk, stride=2)
+    # one frame: four kinds of work of one level -> one level_k launch; without the group id one launch each
+    assert count([lds64(1, 5), lds32(1, 5), down(1, 5), up]) == 1
+    assert count([lds64(1, 0), lds32(1, 0), down(1, 0)]) == 3
+    # a split-K member adds the (grouped) reduce launch
+    assert count([lds64(1, 5), down(1, 5, sk=3), up]) == 2
+    # different levels never merge
+    assert count([lds64(1, 5), lds32(1, 6)]) == 2
+    # 32 frames: members fill the chip on their own -> equal-tile LDS convs still share a grid, the rest run alone
+    assert count([lds64(32, 5), lds64(32, 5), lds32(32, 5), down(32, 5)]) == 3
+    # validation still applies in the dry run
+    bad = lds64(1, 0)
+    bad.out = None
+    assert count([bad]) == -1

@@ -188,3 +188,38 @@ def test_fused_upsample_concat_is_bit_identical_to_materialised():
     for key in ((True, 8), (True, 4)):
         for k, v in outs[(False, 8)].items():
             assert torch.equal(outs[key][k], v), (key, k)
+
+
+@pytest.mark.gpu
+def test_level_merged_launches_are_bit_identical_and_fewer():
+    """nhwc.MERGE_LEVELS: at one frame the independent ops of a dependency level (4-row LDS convs with 64- and 32-channel
+    tiles, the stride-2 direct conv, bilinear upsampling) share one level_k grid.  Same tile bodies, same arithmetic:
+    outputs bit-identical to the one-kernel-per-kind schedule, with fewer launches (idh_count_launches)."""
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd import nhwc
+
+    cve = net.CVEncoder(64, [48, 64, 160, 256], [64, 128, 256, 384])
+    dec = net.BDDecoderPP([24, 64, 128, 256, 384])
+    syn.fill_state_dict(cve, seed=31)
+    syn.fill_state_dict(dec, seed=32)
+    cve.cuda(), dec.cuda()
+    pyr = [t.cuda() for t in syn.encoder_pyramid(1, 384, 512, seed=6)]
+    vol = torch.randn(1, 64, 96, 128, generator=torch.Generator().manual_seed(3)).cuda()
+    old = nhwc.MERGE_LEVELS
+    outs, launches = {}, {}
+    try:
+        for merge in (False, True):
+            nhwc.MERGE_LEVELS = merge
+            for m in (cve, dec):
+                m.__dict__.pop("_idh_plans", None)
+            enc = cve(vol, pyr[1:])
+            o = dec([pyr[0]] + list(enc))
+            outs[merge] = [e.clone() for e in enc] + [o[k].clone() for k in sorted(o)]
+            launches[merge] = sum(next(iter(m.__dict__["_idh_plans"].values()))[0].count_launches() for m in (cve, dec))
+    finally:
+        nhwc.MERGE_LEVELS = old
+        for m in (cve, dec):
+            m.__dict__.pop("_idh_plans", None)
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    assert launches[True] < launches[False] - 10, launches

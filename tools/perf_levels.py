@@ -8,17 +8,20 @@ from bench import HotPathWorkload
 import argparse
 a = argparse.Namespace(batch=int(sys.argv[1]) if len(sys.argv) > 1 else 4, views=7, planes=64, height=384, width=512, volume="mlp")
 if len(sys.argv) > 2: nhwc.NARROW_TILE_BELOW = int(sys.argv[2])  # narrow (32-channel) tiles below this many workgroups
+if len(sys.argv) > 5: nhwc.SPLIT_MIN_CHUNKS = int(sys.argv[5])
+if len(sys.argv) > 6: nhwc.SPLIT_MAX = int(sys.argv[6])
+if len(sys.argv) > 4: nhwc.MERGE_LEVELS = bool(int(sys.argv[4]))
 if len(sys.argv) > 3: nhwc.NARROWEST_TILE_BELOW = int(sys.argv[3])  # 16-channel tiles below this many
 wl = HotPathWorkload(a, torch.device("cuda"), 0)
 for _ in range(2): wl.step()
 torch.cuda.synchronize()
-p = next(iter(wl.model._plans.values()))["plan"]
+ent = next(iter(wl.model._plans.values()))
+p, n_head = ent["plan"], ent["n_head_ops"]
 L = _lib.lib()
 units, i = [], 0
-while i < len(p.ops):
-    op = p.ops[i]; j = i + 1
-    if op.kind == 1 and op.group != 0 and op.tile_m == 9:
-        while j < len(p.ops) and j - i < 12 and p.ops[j].kind == 1 and p.ops[j].group == op.group and p.ops[j].tile_m == 9 and p.ops[j].tile_n == op.tile_n: j += 1
+while i < len(p.ops):  # one unit per dependency level (idh_run_ops decides how many launches that is)
+    j = i + 1
+    while j < len(p.ops) and p.levels[j] == p.levels[i] and (i >= n_head) == (j >= n_head): j += 1
     units.append((i, j)); i = j
 def flops(op): return sum(2 * op.N * op.Ho * op.Wo * op.Cout * s.Cin * s.ks * s.ks for s in op.src if s.in_) if op.kind == 1 else 0
 rows = []
@@ -35,5 +38,6 @@ for (i, j) in units:
     rows.append((ms, fl, p.levels[i], j - i, desc))
 tot = sum(r[0] for r in rows)
 print(f"B={a.batch} units={len(rows)} ops={len(p.ops)} total {tot:.3f} ms  conv TF={sum(r[1] for r in rows)/tot/1e9:.1f}")
-for ms, fl, lv, n, desc in sorted(rows, key=lambda r: -r[0])[:45]:
+order = rows if os.environ.get("IDH_LEVELS_ORDER") == "plan" else sorted(rows, key=lambda r: -r[0])[:45]
+for ms, fl, lv, n, desc in order:
     print(f"{ms*1e3:7.1f} us {100*ms/tot:4.1f}% L{lv:<3d} n={n:<2d} {fl/ms/1e9 if ms else 0:6.1f} TF  {desc[:150]}")
