@@ -254,7 +254,9 @@ constexpr int lds_b_slots(int NJ) { return 9 * 4 * 16 * NJ; }
 
 // sA / sB: the workgroup's LDS images (declared by the kernel so that a kernel hosting several instantiations
 // of this body — level_k — allocates them once)
-template <int RW, bool UP, int NJ>
+// NORM: source 0 is read through a per-(image, channel) normalisation + activation (idh_conv_src.norm): the statistics
+// of the chunk's channels are prefetched with the halo and applied when the halo is committed to LDS.
+template <int RW, bool UP, int NJ, bool NORM = false>
 __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned blk_in, unsigned nblk, f32x4 *__restrict__ sA,
                                                  f32x4 *__restrict__ sB) {
     constexpr int kN = 16 * NJ;                  // output channels per workgroup
@@ -300,6 +302,8 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     // A slots are enumerated (hy, hx, q) with q fastest so that 4 consecutive lanes read the 64
     // contiguous bytes of one pixel; the LDS image is [hy][q][hx].
     f32x4 pa[(UP ? 4 : 1) * kALoads], pb[kBLoads];
+    f32x4 pmean[NORM ? kALoads : 1], prstd[NORM ? kALoads : 1];
+    unsigned in_image = 0;  // NORM: bit k = halo slot k is a real pixel (a zero-padded tap stays 0 after normalisation)
     // low-resolution neighbours + weights of hi-res pixel (iy, ix) under x2 bilinear, align_corners=False
     auto up_taps = [&](const ConvSrc &s, int c, int iy, int ix, int q, bool ok, const float *(&tp)[4]) {
         const int rel = 16 * c - s.up_c0;
@@ -349,6 +353,12 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             if (replicate) { iy = min(max(iy, 0), s.H - 1); ix = min(max(ix, 0), s.W - 1); ok = slot < kASlots; }
             const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
             pa[(UP ? 4 : 1) * k] = *reinterpret_cast<const f32x4 *>(p);
+            if (NORM) {
+                const float *st = s.norm + (size_t)n * 2 * s.Cin + 16 * c + 4 * q;
+                pmean[k] = *reinterpret_cast<const f32x4 *>(st);
+                prstd[k] = *reinterpret_cast<const f32x4 *>(st + s.Cin);
+                in_image = ok ? (in_image | (1u << k)) : (in_image & ~(1u << k));
+            }
         }
         }
         const float *wb = s.w + ((size_t)(4 * c) * a.Cout_pad + n0) * 4;
@@ -370,6 +380,11 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
             f32x4 v = pa[(UP ? 4 : 1) * k];
             if (UP && up) v = up_blend(y0 + hy - 1, x0 + hx - 1, pa[4 * k], pa[4 * k + 1], pa[4 * k + 2], pa[4 * k + 3]);
+            if (NORM) {  // == instnorm_apply_k
+                const bool real = (in_image >> k) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = real ? act_apply((v[e] - pmean[k][e]) * prstd[k][e], a.s[0].norm_act, a.s[0].norm_slope) : 0.f;
+            }
             if (slot < kASlots) sA[(hy * 4 + q) * kHaloW + hx] = v;
         }
 #pragma unroll
@@ -503,11 +518,11 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     }
 }
 
-template <int RW, bool UP, int NJ = 4>
+template <int RW, bool UP, int NJ = 4, bool NORM = false>
 __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
     __shared__ f32x4 sA[lds_a_slots(RW)];
     __shared__ f32x4 sB[lds_b_slots(NJ)];
-    conv3x3_lds_body<RW, UP, NJ>(la, blockIdx.x, gridDim.x, sA, sB);
+    conv3x3_lds_body<RW, UP, NJ, NORM>(la, blockIdx.x, gridDim.x, sA, sB);
 }
 // fused-upsample variants: keep 3 workgroups / CU (what the LDS footprint allows) although the 4x prefetch wants ~180 VGPRs
 template <int RW>
@@ -710,6 +725,97 @@ __global__ __launch_bounds__(256) void export_nchw_k(const float *__restrict__ s
     }
 }
 
+// 1x1 convolution straight from an NCHW tensor into an NHWC slice: the first layer of the matching-encoder head
+// (nn.Conv2d(64, 128, 1) on the ResNet layer1 map, reference modules/networks.py:279) without the layout-import pass
+// in front of it.  HBM-bound (256 B in, 512 B out per pixel against 16 KFLOP): the point is to touch every byte once.
+//   * D^T = W . X^T as in the kernels above: the weights are the A operand (whole packed matrix LDS-resident, 32 KiB
+//     for 64 -> 128), the B operand of lane (ln, h) is channels 16c+4h..+3 of pixel ln — in NCHW four dword loads,
+//     each a 64-byte run of 16 consecutive pixels of one channel plane;
+//   * a wave owns 16 consecutive pixels x 128 channels (8 accumulators), a workgroup 64 pixels; persistent
+//     grid-stride loop over tiles with the next tile's 16 input dwords prefetched under the current 128 MFMAs; 4
+//     workgroups per CU keep ~50 KB of loads in flight per CU;
+//   * epilogue: + bias, one 16-byte store per accumulator (4 consecutive channels of a pixel).
+// Cin == 64 and Cout == 128 only (every ResNet-18/34 matching encoder); other widths keep import_nchw_k + conv_mfma_k.
+constexpr int kPwCin = 64, kPwCout = 128, kPwTile = 64;  // pixels per workgroup
+struct PwNchwArgs {
+    const float *in, *w, *bias;
+    float *out;
+    int HW, out_cs, tiles_per_img;
+    long long tiles;
+};
+
+__global__ __launch_bounds__(256, 4) void pointwise_nchw_k(const PwNchwArgs a) {
+    constexpr int C16 = kPwCin / 16, NT = kPwCout / 16;
+    __shared__ f32x4 sW[(kPwCin / 4) * kPwCout];  // [ci / 4][co] float4 = the packed layout of idh_pack_conv_weight(ks = 1)
+    {
+        const f32x4 *g = reinterpret_cast<const f32x4 *>(a.w);
+        for (int i = threadIdx.x; i < (kPwCin / 4) * kPwCout; i += 256) sW[i] = g[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ln = lane & 15, h = lane >> 4;
+
+    // buffer loads: one lane offset (VGPR) + a scalar channel offset per load instead of 16 64-bit addresses; pixels
+    // past the end of the image are out of the descriptor's range and read as 0
+    const unsigned img_bytes = (unsigned)kPwCin * (unsigned)a.HW * 4u;
+    auto load = [&](long long tile, f32x4 (&x)[C16]) {
+        const int n = (int)(tile / a.tiles_per_img);
+        const int p = (int)(tile - (long long)n * a.tiles_per_img) * kPwTile + 16 * wave + ln;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + (size_t)n * kPwCin * a.HW), 0, img_bytes, 0x00020000);
+        const int voff = p < a.HW ? (4 * h * a.HW + p) * 4 : (int)0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < C16; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                x[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (16 * c + e) * a.HW * 4, 0));
+    };
+    auto compute = [&](long long tile, const f32x4 (&x)[C16]) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the weight fragments are the same for every tile: without this opaque zero the compiler hoists all 32 LDS
+        // reads out of the tile loop (128 VGPRs) and spills
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const f32x4 *sWt = sW + opaque;
+#pragma unroll
+        for (int c = 0; c < C16; ++c)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 A = sWt[(4 * c + h) * kPwCout + 16 * j + ln];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], x[c][kk], acc[j], 0, 0, 0);
+            }
+        const int n = (int)(tile / a.tiles_per_img);
+        const int p = (int)(tile - (long long)n * a.tiles_per_img) * kPwTile + 16 * wave + ln;
+        if (p < a.HW) {
+            float *o = a.out + ((size_t)n * a.HW + p) * a.out_cs + 4 * h;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4 v = acc[j];
+                if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + 16 * j + 4 * h);
+                *reinterpret_cast<f32x4 *>(o + 16 * j) = v;
+            }
+        }
+    };
+    f32x4 xa[C16], xb[C16];
+    long long t = blockIdx.x;
+    if (t >= a.tiles) return;
+    load(t, xa);
+    for (;;) {
+        const long long t1 = t + gridDim.x;
+        if (t1 < a.tiles) load(t1, xb);
+        compute(t, xa);
+        if (t1 >= a.tiles) break;
+        const long long t2 = t1 + gridDim.x;
+        if (t2 < a.tiles) load(t2, xa);
+        compute(t1, xb);
+        if (t2 >= a.tiles) break;
+        t = t2;
+    }
+}
+
 // 1x1 conv to a single channel: one thread per pixel
 __global__ __launch_bounds__(256) void pointwise_head_k(const float *__restrict__ in, const float *__restrict__ w,
                                                         const float *__restrict__ bias, float *__restrict__ out,
@@ -838,6 +944,7 @@ struct PreparedConv {
     int n_img;
     unsigned blocks;
     bool up;         // some source has fused x2-upsampled segments (LDS kernels only)
+    bool norm;       // source 0 is normalised on load (LDS kernels with 16-channel tiles only)
     int nj;          // LDS kernels: 16-channel output sub-tiles per workgroup (4, 2, 1)
     ReduceDesc red;  // valid when a.S > 1
 };
@@ -846,6 +953,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     ConvArgs &a = pc.a;
     a = ConvArgs{};
     pc.up = false;
+    pc.norm = op.src[0].norm != nullptr;
     pc.nj = 4;
     int steps = 0;
     for (int i = 0; i < 2; ++i) {
@@ -866,6 +974,8 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         d.pad_mode = s.pad_mode; d.cblocks = ceil16(s.Cin) / 16;
         d.up_in[0] = s.up_in[0]; d.up_in[1] = s.up_in[1]; d.up_cs[0] = s.up_cs[0]; d.up_cs[1] = s.up_cs[1];
         d.up_c0 = s.up_c0; d.up_C = s.up_C;
+        d.norm = s.norm; d.norm_slope = s.norm_slope; d.norm_act = s.norm_act;
+        if (s.norm && (i != 0 || s.up_in[0] || ((uintptr_t)s.norm & 15) || (s.Cin & 15))) return IDH_EUNSUPPORTED;
         if (s.up_in[0]) {
             const int nseg = s.up_in[1] ? 2 : 1;
             if (s.up_c0 < 0 || (s.up_c0 & 15) || s.up_C <= 0 || (s.up_C & 15) || s.up_c0 + nseg * s.up_C != s.Cin || (s.H & 1) || (s.W & 1) ||
@@ -933,6 +1043,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         pc.blocks = (unsigned)((waves + 3) / 4);
     }
     if (pc.up && ((pc.lds_rows != 8 && pc.lds_rows != 4) || pc.nj != 4)) return IDH_EUNSUPPORTED;  // fused upsampling lives in the 64-channel LDS loader
+    if (pc.norm && ((pc.lds_rows != 8 && pc.lds_rows != 4) || pc.nj != 1)) return IDH_EUNSUPPORTED;  // normalise-on-load: 16-channel LDS tiles
     if (a.S > 1) {
         if (!op.ws) return IDH_EWORKSPACE;
         pc.red = ReduceDesc{op.ws, op.bias, op.res, op.out, a.M, op.Cout, a.Cout_pad, a.S, op.res_cs, op.out_cs, op.act, op.slope};
@@ -946,6 +1057,8 @@ int launch_conv(const PreparedConv &pc, hipStream_t st) {
         return launch_conv_split(pc.a, pc.n_img, pc.tm, pc.tn, st);
     }
     if (pc.lds_rows == 8 && pc.up) IDH_LAUNCH(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8 && pc.norm) IDH_LAUNCH((conv3x3_lds_k<2, false, 1, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.norm) IDH_LAUNCH((conv3x3_lds_k<1, false, 1, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 8 && pc.nj == 2) IDH_LAUNCH((conv3x3_lds_k<2, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 8 && pc.nj == 1) IDH_LAUNCH((conv3x3_lds_k<2, false, 1>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 4 && pc.nj == 2) IDH_LAUNCH((conv3x3_lds_k<1, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
@@ -1022,7 +1135,7 @@ int launch_level(const PreparedConv *pcs, const int *kinds, int n, hipStream_t s
 
 // Level-launch member kind of a prepared conv, or -1
 int level_kind(const PreparedConv &pc) {
-    if (pc.up) return -1;
+    if (pc.up || pc.norm) return -1;
     if (pc.lds_rows == 4 && pc.nj == 4) return LV_LDS4;
     if (pc.lds_rows == 4 && pc.nj == 2) return LV_LDS2;
     if (pc.lds_rows == 0 && pc.tm == 1 && pc.tn == 4) return LV_MFMA14;
@@ -1101,10 +1214,10 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                     ++run;
                 }
                 int cnt = 0;  // homogeneous prefix
-                if (op.kind == IDH_OP_CONV && pcs[0].lds_rows == 4) {
+                if (op.kind == IDH_OP_CONV && pcs[0].lds_rows == 4 && !pcs[0].norm) {
                     cnt = 1;
                     while (cnt < run && ops[i + cnt].kind == IDH_OP_CONV && pcs[cnt].lds_rows == 4 && pcs[cnt].nj == pcs[0].nj &&
-                           (!pcs[cnt].up || pcs[0].nj == 4))
+                           (!pcs[cnt].up || pcs[0].nj == 4) && !pcs[cnt].norm)
                         ++cnt;
                 }
                 int mix = 0;  // mixed prefix of small members
@@ -1168,6 +1281,23 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 IDH_CHECK_LAUNCH();
                 break;
             }
+            case IDH_OP_POINTWISE_NCHW: {
+                // src[0].in = (N, 64, H, W) dense NCHW, src[0].w = idh_pack_conv_weight(128, 64, 1), out = NHWC slice
+                if (!s.in || !s.w || !op.out || op.N <= 0 || s.H <= 0 || s.W <= 0 || (op.out_cs & 3) || ((uintptr_t)op.out & 15) ||
+                    (op.bias && ((uintptr_t)op.bias & 15)))
+                    return IDH_EINVAL;
+                if (s.Cin != kPwCin || op.Cout != kPwCout || op.out_cs < kPwCout || (long long)s.H * s.W * kPwCin * 4 >= (1ll << 31))
+                    return IDH_EUNSUPPORTED;
+                PwNchwArgs pa{};
+                pa.in = s.in; pa.w = s.w; pa.bias = op.bias; pa.out = op.out;
+                pa.HW = s.H * s.W; pa.out_cs = op.out_cs;
+                pa.tiles_per_img = idh_cdiv(pa.HW, kPwTile);
+                pa.tiles = (long long)op.N * pa.tiles_per_img;
+                const int grid = (int)std::min<long long>(pa.tiles, 256 * 4 * 4);
+                IDH_LAUNCH(pointwise_nchw_k, dim3(grid), dim3(256), 0, st, pa);
+                IDH_CHECK_LAUNCH();
+                break;
+            }
             case IDH_OP_COPY: {
                 if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0) return IDH_EINVAL;
                 const long long npix = (long long)op.N * s.H * s.W;
@@ -1179,7 +1309,7 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
             }
             case IDH_OP_INSTNORM: {
                 const int C = s.Cin, HW = s.H * s.W;
-                if (!s.in || !op.out || !op.ws || C <= 0 || (C & 3) || 256 % (C >> 2) || (s.cs & 3) || (op.out_cs & 3) ||
+                if (!s.in || !op.ws || C <= 0 || (C & 3) || 256 % (C >> 2) || (s.cs & 3) || (op.out && (op.out_cs & 3)) ||
                     op.N <= 0 || op.N > 65535)
                     return IDH_EINVAL;
                 const int nchunks = idh_cdiv(HW, kInChunk);
@@ -1189,6 +1319,7 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 float *stats = op.ws + (size_t)op.N * nchunks * 2 * C;
                 IDH_LAUNCH(instnorm_finalize_k, dim3(op.N), dim3(256), 0, st, op.ws, C, HW, nchunks, stats);
                 IDH_CHECK_LAUNCH();
+                if (!op.out) break;  // statistics only: the consumer conv normalises on load (idh_conv_src.norm)
                 const long long total = (long long)op.N * HW * (C >> 2);
                 int gx = idh_cdiv(total, 256 * 4);  // ~4 float4 per thread
                 if (gx > 16384) gx = 16384;

@@ -16,6 +16,10 @@ struct ConvSrc {
     const float *up_in[2];
     int up_cs[2];
     int up_c0, up_C;
+    // normalise-on-load (idh_conv_src.norm): stats[n][2][Cin], activation applied after (x - mean) * rstd
+    const float *norm;
+    float norm_slope;
+    int norm_act;
 };
 
 struct ConvArgs {

@@ -25,7 +25,7 @@ from torch import nn
 from . import _lib
 
 # --- ctypes mirrors of include/idh_ops.h -------------------------------------------------
-OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD, OP_INSTNORM, OP_UPSAMPLE2_NEAREST, OP_COPY = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD, OP_INSTNORM, OP_UPSAMPLE2_NEAREST, OP_COPY, OP_POINTWISE_NCHW = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 ACT_NONE, ACT_LRELU, ACT_ELU = 0, 1, 2
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 
@@ -33,7 +33,8 @@ PAD_ZEROS, PAD_REPLICATE = 0, 1
 class ConvSrc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("w", C.c_void_p), ("cs", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Cin", C.c_int32), ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("_r", C.c_int32),
-                ("up_in", C.c_void_p * 2), ("up_cs", C.c_int32 * 2), ("up_c0", C.c_int32), ("up_C", C.c_int32)]
+                ("up_in", C.c_void_p * 2), ("up_cs", C.c_int32 * 2), ("up_c0", C.c_int32), ("up_C", C.c_int32),
+                ("norm", C.c_void_p), ("norm_slope", C.c_float), ("norm_act", C.c_int32)]
 
 
 class Op(C.Structure):
@@ -225,6 +226,12 @@ FUSED_UP_ROWS = 4
 # One launch per dependency level where its members are small (one frame, low-resolution maps): idh_run_ops merges the
 # consecutive ops of a level that carry its group id into one ``level_k`` grid when each has <= 1024 workgroups.
 MERGE_LEVELS = True
+# Matching-encoder head: InstanceNorm2d(128) + LeakyReLU applied by the following 3x3 conv while it stages its halo
+# (idh_conv_src.norm) instead of a normalised copy of the tensor; False = materialise (bit-identical, tests compare).
+FUSE_HEAD_NORM = True
+# ... and its first 1x1 conv reading the backbone's NCHW map in place (IDH_OP_POINTWISE_NCHW) instead of after a
+# layout-import pass; False = import_nchw + the generic conv (bit-identical).
+FUSE_HEAD_IMPORT = True
 
 TARGET_WAVES = 2048  # ~2 waves per SIMD over 256 CUs x 4 SIMDs
 MIN_WAVES = 1024
@@ -317,7 +324,9 @@ class Plan:
 
     # ops -----------------------------------------------------------------------------
     def conv(self, x: View, conv: nn.Conv2d, out: View, act=ACT_NONE, slope=0.2, res: Optional[View] = None,
-             x2: Optional[View] = None, conv2: Optional[nn.Conv2d] = None, pad_mode=PAD_ZEROS):
+             x2: Optional[View] = None, conv2: Optional[nn.Conv2d] = None, pad_mode=PAD_ZEROS, norm=None):
+        """``norm`` = (stats, act, slope): read ``x`` through act((x - mean) * rstd) with the (N, 2, C) statistics of
+        ``instance_norm(x, None)`` (``norm_on_load_eligible`` layers only)."""
         op = Op()
         op.kind = OP_CONV
         op.N = x.N
@@ -381,12 +390,17 @@ class Plan:
         else:
             tm, tn, split = choose_tiles(M, conv.out_channels, steps)
         op.tile_m, op.tile_n, op.split_k = tm, tn, split
+        if norm is not None:
+            stats, n_act, n_slope = norm
+            if tm not in (8, 9) or tn != 1 or x2 is not None or isinstance(x, CatView) or tuple(stats.shape) != (x.N, 2, x.C):
+                raise _lib.IdhError("normalise-on-load needs the LDS-staged fp32 conv with 16-channel tiles and one source")
+            op.src[0].norm, op.src[0].norm_act, op.src[0].norm_slope = stats.data_ptr(), n_act, n_slope
         if split > 1:
             ws = torch.empty(split * M * ceil16(conv.out_channels), device=self.device, dtype=torch.float32)
             self.keep.append(ws)
             op.ws = ws.data_ptr()
         self.ops.append(op)
-        reads = ([_region(res)] if res is not None else [])
+        reads = ([_region(res)] if res is not None else []) + ([(norm[0].data_ptr(), 0, 1)] if norm is not None else [])
         for v, _ in srcs:
             if isinstance(v, CatView):
                 reads += [_region(v.direct)] + [_region(u) for u in v.ups]
@@ -407,22 +421,27 @@ class Plan:
         self._arr = None
         return out
 
-    def instance_norm(self, x: View, out: View, act=ACT_NONE, slope=0.2):
-        """nn.InstanceNorm2d(C) (no affine, eps 1e-5) optionally followed by LeakyReLU."""
+    def instance_norm(self, x: View, out: Optional[View], act=ACT_NONE, slope=0.2):
+        """nn.InstanceNorm2d(C) (no affine, eps 1e-5) optionally followed by LeakyReLU.  ``out=None``: statistics only —
+        returns the (N, 2, C) mean / rstd tensor for a consumer conv that normalises on load (``conv(..., norm=...)``)."""
         if x.C % 4 or 256 % (x.C // 4):
             raise _lib.IdhError(f"instance-norm kernel needs C/4 to divide 256 (C={x.C})")
         op = Op()
         op.kind, op.N = OP_INSTNORM, x.N
         s = op.src[0]
         s.in_, s.cs, s.H, s.W, s.Cin = x.ptr, x.cs, x.H, x.W, x.C
-        op.out, op.out_cs, op.act, op.slope = out.ptr, out.cs, act, slope
-        ws = torch.empty(x.N * (-(-(x.H * x.W) // 1024) + 1) * 2 * x.C, device=self.device, dtype=torch.float32)
+        op.act, op.slope = act, slope
+        if out is not None:
+            op.out, op.out_cs = out.ptr, out.cs
+        nchunks = -(-(x.H * x.W) // 1024)
+        ws = torch.empty(x.N * (nchunks + 1) * 2 * x.C, device=self.device, dtype=torch.float32)
         self.keep.append(ws)
         op.ws = ws.data_ptr()
         self.ops.append(op)
-        self.meta.append({"reads": [_region(x)], "writes": [_region(out)]})
+        stats = ws[x.N * nchunks * 2 * x.C:].view(x.N, 2, x.C)
+        self.meta.append({"reads": [_region(x)], "writes": [_region(out)] if out is not None else [(stats.data_ptr(), 0, 1)]})
         self._arr = None
-        return out
+        return out if out is not None else stats
 
     def copy(self, x: View, out: View):
         """NHWC view -> NHWC view (e.g. an existing feature map into a slice of a concat buffer)."""
@@ -449,6 +468,35 @@ class Plan:
         s = op.src[0]
         s.H, s.W, s.Cin = H, W, Cc
         op.out, op.out_cs = out.ptr, out.cs
+        self.ops.append(op)
+        self.meta.append({"reads": [], "writes": [_region(out)]})
+        self._arr = None
+        return len(self.ops) - 1
+
+    @staticmethod
+    def pointwise_nchw_eligible(conv: nn.Conv2d) -> bool:
+        """Shape family of csrc/conv.hip pointwise_nchw_k: the matching head's nn.Conv2d(64, 128, 1)."""
+        return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.in_channels == 64 and conv.out_channels == 128
+                and conv.groups == 1)
+
+    def pointwise_nchw(self, shape_nchw, conv: nn.Conv2d, out: View) -> int:
+        """1x1 conv read straight from a dense (N,C,H,W) tensor into an NHWC view (IDH_OP_POINTWISE_NCHW): layout
+        import and convolution in one pass.  The source pointer is patched per call with ``set_in``; returns the op index."""
+        N, Cc, H, W = [int(v) for v in shape_nchw]
+        if (N, H, W) != (out.N, out.H, out.W) or Cc != conv.in_channels or out.C != conv.out_channels or not self.pointwise_nchw_eligible(conv):
+            raise _lib.IdhError(f"pointwise_nchw: {tuple(shape_nchw)} with {conv} into a view of {(out.N, out.C, out.H, out.W)}")
+        op = Op()
+        op.kind, op.N = OP_POINTWISE_NCHW, N
+        s = op.src[0]
+        w = packed_weight(conv)
+        self.keep.append(w)
+        s.w, s.H, s.W, s.Cin, s.ks, s.stride = w.data_ptr(), H, W, Cc, 1, 1
+        if conv.bias is not None:
+            bias = conv.bias.detach().contiguous()
+            self.keep.append(bias)
+            op.bias = bias.data_ptr()
+        op.out, op.out_cs, op.Ho, op.Wo, op.Cout = out.ptr, out.cs, H, W, conv.out_channels
+        self.flops += 2 * N * H * W * conv.out_channels * conv.in_channels
         self.ops.append(op)
         self.meta.append({"reads": [], "writes": [_region(out)]})
         self._arr = None
@@ -794,17 +842,39 @@ def binary_mlp_forward(net, inputs, max_scale_only):
 
 
 # --- matching-encoder head (reference networks.py:279-283) ---------------------------------
-def build_matching_head(p: Plan, enc, x: View) -> View:
+def norm_on_load_eligible(p: Plan, x: View, conv: nn.Conv2d, pad_mode: int) -> bool:
+    """Can ``conv`` read ``x`` through a fused InstanceNorm (idh_conv_src.norm)?  LDS-staged fp32 3x3 kernel, 16-channel
+    output tiles, whole 16-channel input blocks."""
+    return (p.math == "fp32" and x.C % 16 == 0 and lds_subtiles(conv.out_channels) == 1 and
+            lds_eligible([(x, conv)], conv.out_channels, x.W, pad_mode))
+
+
+def build_matching_head(p: Plan, enc, x: Optional[View], nchw_shape=None):
+    """Head of ResnetMatchingEncoder (reference modules/networks.py:279-283) on an NHWC view ``x`` — or, with
+    ``nchw_shape`` = (N, C, H, W) and ``x`` = None, directly on the backbone's dense NCHW tensor: the first 1x1 conv then
+    reads it in place (``Plan.pointwise_nchw``) and the index of that op is returned next to the output view so the caller
+    can patch the source pointer."""
     c1, c2 = enc.net[5], enc.net[8]
-    h = p.buffer(x.N, x.H, x.W, c1.out_channels)
-    p.conv(x, c1, h)
-    hn = p.buffer(x.N, x.H, x.W, c1.out_channels)
-    p.instance_norm(h, hn, act=ACT_LRELU, slope=0.2)
+    if nchw_shape is not None:
+        N, _, H, W = [int(v) for v in nchw_shape]
+        h = p.buffer(N, H, W, c1.out_channels)
+        i_in = p.pointwise_nchw(nchw_shape, c1, h)
+        x = h  # dims only
+    else:
+        h = p.buffer(x.N, x.H, x.W, c1.out_channels)
+        p.conv(x, c1, h)
     y = p.buffer(x.N, x.H, x.W, c2.out_channels)
-    p.conv(hn, c2, y, pad_mode=PAD_REPLICATE)
+    if FUSE_HEAD_NORM and norm_on_load_eligible(p, h, c2, PAD_REPLICATE):
+        # InstanceNorm2d(128) + LeakyReLU: one statistics pass; the 3x3 conv normalises while staging its halo
+        stats = p.instance_norm(h, None)
+        p.conv(h, c2, y, pad_mode=PAD_REPLICATE, norm=(stats, ACT_LRELU, 0.2))
+    else:
+        hn = p.buffer(x.N, x.H, x.W, c1.out_channels)
+        p.instance_norm(h, hn, act=ACT_LRELU, slope=0.2)
+        p.conv(hn, c2, y, pad_mode=PAD_REPLICATE)
     out = p.buffer(x.N, x.H, x.W, c2.out_channels)
     p.instance_norm(y, out)
-    return out
+    return out if nchw_shape is None else (out, i_in)
 
 
 def matching_head_forward(enc, feat_nchw: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
@@ -817,9 +887,12 @@ def matching_head_forward(enc, feat_nchw: torch.Tensor, channels_last: bool = Fa
         cache.clear()
         p = Plan(x.device, math=math_of(enc))
         N, Cc, H, W = x.shape
-        xin = p.buffer(N, H, W, Cc)
-        i_in = p.import_nchw(x.shape, xin)
-        y = build_matching_head(p, enc, xin)
+        if FUSE_HEAD_IMPORT and Plan.pointwise_nchw_eligible(enc.net[5]):
+            y, i_in = build_matching_head(p, enc, None, nchw_shape=x.shape)
+        else:
+            xin = p.buffer(N, H, W, Cc)
+            i_in = p.import_nchw(x.shape, xin)
+            y = build_matching_head(p, enc, xin)
         i_out = None if channels_last else p.export_nchw(y)
         p.schedule()
         ent = (p, i_in, i_out, y)

@@ -73,14 +73,17 @@ class HotPath(nn.Module):
             # current view then its K source views, so the result is ONE (B, K+1, H, W, C) buffer that the volume
             # kernel addresses with batch strides.
             M = B * (K + 1)
-            if head == "nchw":
+            n0 = len(p.ops)
+            if head == "nchw" and nhwc.FUSE_HEAD_IMPORT and nhwc.Plan.pointwise_nchw_eligible(self.matching_model.net[5]):
+                # the first 1x1 conv reads the backbone's NCHW map in place: no layout-import pass
+                y, ent["i_l1"] = nhwc.build_matching_head(p, self.matching_model, None, nchw_shape=(M, head_ch, H, W))
+            elif head == "nchw":
                 x = p.buffer(M, H, W, head_ch)
                 ent["i_l1"] = p.import_nchw((M, head_ch, H, W), x)
+                y = nhwc.build_matching_head(p, self.matching_model, x)
             else:  # channels-last producer: the first conv reads the caller's tensor in place (pointer patched per call)
                 x = nhwc.View(torch.empty(1, device=device).expand(M, H, W, head_ch), 0, head_ch)
-            n0 = len(p.ops)
-            y = nhwc.build_matching_head(p, self.matching_model, x)
-            if head == "nhwc":
+                y = nhwc.build_matching_head(p, self.matching_model, x)
                 ent["i_l1"] = n0  # the 1x1 conv added first by build_matching_head
             if y.C != C:
                 raise _lib.IdhError(f"matching head produces {y.C} channels, cost volume expects {C}")

@@ -29,8 +29,13 @@ enum {
                                  (N,1,H,W) output = exp(out), the depth map of depth_model.py:425-433 */
     IDH_OP_COPY = 9,        /* channel-strided NHWC -> NHWC slice copy */
     IDH_OP_UPSAMPLE2_NEAREST = 8, /* nearest x2 (SkipDecoder, networks_fast.py:43) */
+    IDH_OP_POINTWISE_NCHW = 10, /* 1x1 conv 64 -> 128 read straight from a dense (N,64,H,W) tensor into an NHWC slice: the first
+                                   layer of the matching-encoder head (networks.py:279) without a layout-import pass;
+                                   src[0].w = idh_pack_conv_weight(128, 64, 1); other widths: IDH_EUNSUPPORTED */
     IDH_OP_INSTNORM = 7     /* nn.InstanceNorm2d (no affine, eps 1e-5) [+ LeakyReLU] on NHWC; matching-encoder
-                               head networks.py:279-283.  ws: N*(ceil(HW/1024)+1)*2*C floats (chunk partials + mean/rstd) */
+                               head networks.py:279-283.  ws: N*(ceil(HW/1024)+1)*2*C floats (chunk partials + mean/rstd);
+                               out == NULL: statistics only — float[N][2][C] at ws + N*ceil(HW/1024)*2*C, for a
+                               consumer convolution that normalises on load (idh_conv_src.norm) */
 };
 
 #define IDH_PAD_ZEROS 0
@@ -53,6 +58,15 @@ typedef struct idh_conv_src {
     const float *up_in[2];
     int32_t up_cs[2];
     int32_t up_c0, up_C;
+    /* Normalise-on-load: norm != NULL -> the kernel reads x' = act((x - mean[n][c]) * rstd[n][c]) instead of x, with
+     * norm = the statistics an IDH_OP_INSTNORM left in its workspace (float[N][2][Cin]: means then 1/sqrt(var + eps)).
+     * nn.InstanceNorm2d + LeakyReLU between two convolutions of the matching-encoder head (networks.py:280-281) then
+     * cost one statistics pass and no normalised copy of the tensor.  Same expression as the materialising kernel
+     * (bit-identical); padding is applied after the normalisation (a zero-padded tap stays 0).  src[0] of the
+     * LDS-staged 3x3 kernel with 16-channel output tiles only (IDH_EUNSUPPORTED otherwise). */
+    const float *norm;
+    float norm_slope;
+    int32_t norm_act;  /* IDH_ACT_* */
 } idh_conv_src;
 
 typedef struct idh_op {

@@ -29,9 +29,11 @@ def test_basic_block_golden(tag):
 
 
 @pytest.mark.parametrize("shape", [(1, 16, 16, 9, 7, 1), (3, 64, 64, 33, 47, 1), (2, 112, 64, 24, 32, 1), (1, 64, 128, 31, 45, 2),
-                                   (2, 416, 256, 6, 8, 1), (1, 256, 384, 12, 16, 2), (4, 640, 384, 3, 4, 1), (1, 24, 64, 40, 52, 1)])
+                                   (2, 416, 256, 6, 8, 1), (1, 256, 384, 12, 16, 2), (4, 640, 384, 3, 4, 1), (1, 24, 64, 40, 52, 1),
+                                   (2, 64, 128, 32, 64, 2), (1, 128, 256, 24, 40, 2)])
 def test_basic_block_vs_oracle(shape):
-    """odd sizes, channel counts of every CVEncoder/decoder layer family, split-K (tiny maps)."""
+    """odd sizes, channel counts of every CVEncoder/decoder layer family, split-K (tiny maps), stride-2 blocks whose
+    conv2 + strided 1x1 projection runs in the LDS-staged kernel (output width >= 16) or the direct kernel."""
     from implicit_depth_amd.layers import BasicBlock
 
     N, cin, cout, H, W, stride = shape
@@ -223,3 +225,72 @@ def test_level_merged_launches_are_bit_identical_and_fewer():
     for a, b in zip(outs[False], outs[True]):
         assert torch.equal(a, b)
     assert launches[True] < launches[False] - 10, launches
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 24, 32), (2, 96, 128), (9, 17, 50)])
+def test_head_fusions_are_bit_identical_to_the_unfused_plan(shape):
+    """The matching head's two fusions — the first 1x1 conv reading the backbone's NCHW map in place
+    (IDH_OP_POINTWISE_NCHW) and InstanceNorm + LeakyReLU applied by the 3x3 conv while it stages its halo
+    (idh_conv_src.norm) — against the plan that imports the layout and materialises the normalised tensor: the
+    normalisation is the same expression (bit-identical); the 1x1 conv sums its 64 products in the same MFMA order."""
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd import nhwc
+
+    N, H, W = shape
+    enc = net.ResnetMatchingEncoder([torch.nn.Identity() for _ in range(5)], 16)
+    syn.fill_state_dict(enc, seed=44)
+    enc.cuda()
+    x = syn.randn((N, 64, H, W), 45, "mh_fuse").cuda()
+    ref = onet.matching_head(x.cpu().double(), {k: v.cpu().double() for k, v in enc.state_dict().items()})
+    old = nhwc.FUSE_HEAD_NORM, nhwc.FUSE_HEAD_IMPORT
+    outs = {}
+    try:
+        for fuse in (False, True):
+            nhwc.FUSE_HEAD_NORM = nhwc.FUSE_HEAD_IMPORT = fuse
+            enc.__dict__.pop("_idh_plans", None)
+            outs[fuse] = nhwc.matching_head_forward(enc, x).clone()
+            kinds = [op.kind for op in next(iter(enc.__dict__["_idh_plans"].values()))[0].ops]
+            assert (nhwc.OP_POINTWISE_NCHW in kinds) == fuse and (nhwc.OP_IMPORT in kinds) == (not fuse)
+    finally:
+        nhwc.FUSE_HEAD_NORM, nhwc.FUSE_HEAD_IMPORT = old
+        enc.__dict__.pop("_idh_plans", None)
+    assert rel_err(outs[True].cpu(), ref) < TOL
+    assert torch.equal(outs[True], outs[False])
+
+
+@pytest.mark.gpu
+def test_normalise_on_load_with_zero_padding():
+    """idh_conv_src.norm on a zero-padded conv: the padding is applied AFTER the normalisation (a padded tap is 0, not
+    act((0 - mean) * rstd)) — the reference's InstanceNorm2d -> LeakyReLU -> Conv2d(padding=1)."""
+    from implicit_depth_amd import nhwc
+
+    N, C, H, W, Co = 2, 32, 20, 33, 16
+    x = syn.randn((N, C, H, W), 46, "nz_x") * 3.0 + 1.5
+    conv = torch.nn.Conv2d(C, Co, 3, padding=1)
+    syn.fill_state_dict(conv, seed=47)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(x.double()), 0.2),
+                                     conv.weight.detach().double(), conv.bias.detach().double(), padding=1)
+    conv.cuda()
+    outs = []
+    for fuse in (True, False):
+        p = nhwc.Plan(torch.device("cuda"))
+        xin = p.buffer(N, H, W, C)
+        i_in = p.import_nchw(x.shape, xin)
+        y = p.buffer(N, H, W, Co)
+        if fuse:
+            assert nhwc.norm_on_load_eligible(p, xin, conv, nhwc.PAD_ZEROS)
+            p.conv(xin, conv, y, norm=(p.instance_norm(xin, None), nhwc.ACT_LRELU, 0.2))
+        else:
+            xn = p.buffer(N, H, W, C)
+            p.instance_norm(xin, xn, act=nhwc.ACT_LRELU, slope=0.2)
+            p.conv(xn, conv, y)
+        i_out = p.export_nchw(y)
+        p.schedule()
+        out = torch.empty(N, Co, H, W, device="cuda")
+        p.set_in(i_in, x.cuda())
+        p.set_out(i_out, out)
+        p.run()
+        outs.append(out.cpu())
+    assert rel_err(outs[0], ref) < TOL
+    assert torch.equal(outs[0], outs[1])

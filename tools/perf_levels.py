@@ -26,11 +26,11 @@ while i < len(p.ops):  # one unit per dependency level (idh_run_ops decides how 
 def flops(op): return sum(2 * op.N * op.Ho * op.Wo * op.Cout * s.Cin * s.ks * s.ks for s in op.src if s.in_) if op.kind == 1 else 0
 rows = []
 for (i, j) in units:
-    arr = (nhwc.Op * (j - i))(*p.ops[i:j])
-    for _ in range(2): L.idh_run_ops(C.cast(arr, C.c_void_p), j - i, _lib.stream_ptr())
+    arr = C.c_void_p(C.addressof(p._array()) + i * C.sizeof(nhwc.Op))  # the plan's own array: source pointers already patched
+    for _ in range(2): _lib.check(L.idh_run_ops(arr, j - i, _lib.stream_ptr()), 'idh_run_ops')
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5): L.idh_run_ops(C.cast(arr, C.c_void_p), j - i, _lib.stream_ptr())
+    for _ in range(5): _lib.check(L.idh_run_ops(arr, j - i, _lib.stream_ptr()), 'idh_run_ops')
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     fl = sum(flops(o) for o in p.ops[i:j])
