@@ -917,16 +917,21 @@ struct LevelArgs {
     LdsConvArgs op[kMaxGroup];  // LV_UP2 uses c.s[0].{in, H, W, Cin, cs}, c.out, c.out_cs and c.M (= images)
 };
 
+// WIDE = some member uses 64-channel tiles: without one the kernel keeps the 32-channel tile's LDS footprint (25 KiB,
+// 6 workgroups per CU instead of 3) and register count.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void level_k(const LevelArgs g) {
     __shared__ f32x4 sA[lds_a_slots(1)];
-    __shared__ f32x4 sB[lds_b_slots(4)];
+    __shared__ f32x4 sB[lds_b_slots(WIDE ? 4 : 2)];
     int idx = 0;
     for (int i = 1; i < g.n; ++i)
         if (blockIdx.x >= g.start[i]) idx = i;
     const unsigned blk = blockIdx.x - g.start[idx], nblk = g.start[idx + 1] - g.start[idx];
     const LdsConvArgs &la = g.op[idx];
     switch (g.kind[idx]) {
-        case LV_LDS4: conv3x3_lds_body<1, false, 4>(la, blk, nblk, sA, sB); break;
+        case LV_LDS4:
+            if constexpr (WIDE) conv3x3_lds_body<1, false, 4>(la, blk, nblk, sA, sB);
+            break;
         case LV_LDS2: conv3x3_lds_body<1, false, 2>(la, blk, nblk, sA, sB); break;
         case LV_MFMA14: conv_mfma_body<1, 4>(la.c, blk, nblk); break;
         default: upsample2_body(la.c.s[0].in, la.c.out, la.c.M, la.c.s[0].H, la.c.s[0].W, la.c.s[0].Cin, la.c.s[0].cs, la.c.out_cs, blk, nblk); break;
@@ -1128,7 +1133,10 @@ int launch_level(const PreparedConv *pcs, const int *kinds, int n, hipStream_t s
         cursor += pcs[i].blocks;
     }
     g.start[n] = cursor;
-    IDH_LAUNCH(level_k, dim3(cursor), dim3(256), 0, st, g);
+    bool wide = false;
+    for (int i = 0; i < n; ++i) wide = wide || kinds[i] == LV_LDS4;
+    if (wide) IDH_LAUNCH(level_k<true>, dim3(cursor), dim3(256), 0, st, g);
+    else IDH_LAUNCH(level_k<false>, dim3(cursor), dim3(256), 0, st, g);
     IDH_CHECK_LAUNCH();
     return launch_reduces(pcs, n, st);
 }
@@ -1150,7 +1158,7 @@ int check_upsample(const idh_op &op) {
 
 // Members of a level launch are small by construction (one frame / low-resolution maps): a member that fills the chip
 // for several rounds on its own gains nothing from sharing a grid and keeps its specialised kernel.
-constexpr unsigned kLevelMaxBlocks = 1024;
+constexpr unsigned kLevelMaxBlocks = 512;
 constexpr unsigned kLevelUpsampleBlocks = 512;
 
 }  // namespace

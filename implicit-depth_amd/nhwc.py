@@ -224,7 +224,7 @@ FUSE_UPSAMPLE = False
 FUSED_UP_ROWS = 4
 
 # One launch per dependency level where its members are small (one frame, low-resolution maps): idh_run_ops merges the
-# consecutive ops of a level that carry its group id into one ``level_k`` grid when each has <= 1024 workgroups.
+# consecutive ops of a level that carry its group id into one ``level_k`` grid when each has <= 512 workgroups.
 MERGE_LEVELS = True
 # Matching-encoder head: InstanceNorm2d(128) + LeakyReLU applied by the following 3x3 conv while it stages its halo
 # (idh_conv_src.norm) instead of a normalised copy of the tensor; False = materialise (bit-identical, tests compare).

@@ -92,7 +92,7 @@ typedef struct idh_op {
                                dependency level of the plan, see Plan.schedule in nhwc.py) and may be launched as
                                ONE grid: runs of 4-row LDS convs with equal channel tiles always are; a mixed run
                                (4-row LDS convs with 64- / 32-channel tiles, the 16x64-tile direct conv, bilinear
-                               upsampling) is when each member has <= 1024 workgroups, i.e. at small batch */
+                               upsampling) is when each member has <= 512 workgroups, i.e. at small batch */
 } idh_op;
 
 /* Repack OIHW conv weights (reference nn.Conv2d layout) for the MFMA B-fragment loads:

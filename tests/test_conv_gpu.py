@@ -193,10 +193,12 @@ def test_fused_upsample_concat_is_bit_identical_to_materialised():
 
 
 @pytest.mark.gpu
-def test_level_merged_launches_are_bit_identical_and_fewer():
+@pytest.mark.parametrize("batch", [1, 6])
+def test_level_merged_launches_are_bit_identical_and_fewer(batch):
     """nhwc.MERGE_LEVELS: at one frame the independent ops of a dependency level (4-row LDS convs with 64- and 32-channel
-    tiles, the stride-2 direct conv, bilinear upsampling) share one level_k grid.  Same tile bodies, same arithmetic:
-    outputs bit-identical to the one-kernel-per-kind schedule, with fewer launches (idh_count_launches)."""
+    tiles, the stride-2 direct conv, bilinear upsampling) share one level_k grid; at larger batch the level's upsamples
+    ride along with its 8-row conv tiles (ride_k).  Same tile bodies, same arithmetic: outputs bit-identical to the
+    one-kernel-per-kind schedule, with fewer launches (idh_count_launches)."""
     from implicit_depth_amd import networks as net
     from implicit_depth_amd import nhwc
 
@@ -205,8 +207,8 @@ def test_level_merged_launches_are_bit_identical_and_fewer():
     syn.fill_state_dict(cve, seed=31)
     syn.fill_state_dict(dec, seed=32)
     cve.cuda(), dec.cuda()
-    pyr = [t.cuda() for t in syn.encoder_pyramid(1, 384, 512, seed=6)]
-    vol = torch.randn(1, 64, 96, 128, generator=torch.Generator().manual_seed(3)).cuda()
+    pyr = [t.cuda() for t in syn.encoder_pyramid(batch, 384, 512, seed=6)]
+    vol = torch.randn(batch, 64, 96, 128, generator=torch.Generator().manual_seed(3)).cuda()
     old = nhwc.MERGE_LEVELS
     outs, launches = {}, {}
     try:
@@ -224,7 +226,7 @@ def test_level_merged_launches_are_bit_identical_and_fewer():
             m.__dict__.pop("_idh_plans", None)
     for a, b in zip(outs[False], outs[True]):
         assert torch.equal(a, b)
-    assert launches[True] < launches[False] - 10, launches
+    assert launches[True] < launches[False] - (10 if batch == 1 else 5), launches
 
 
 @pytest.mark.gpu
