@@ -250,13 +250,21 @@ struct LdsConvArgs {
 // the staged halo is then amortised over fewer MFMAs but still feeds all 9 taps from one HBM/L2 read.
 // LDS image sizes (float4): halo of one 16-channel chunk / its 9-tap weight panel (36 KiB at NJ = 4)
 constexpr int lds_a_slots(int RW) { return (4 * RW + 2) * 4 * kHaloW; }  // 720 (RW=2) / 432 (RW=1)
+// stride-2 3x3 second source (BasicBlock's strided projection): the halo of a (4*RW) x 16 output tile is (8*RW + 1) x 33
+// input pixels, kept de-interleaved by column parity — [hy][q][parity][17] float4 — so that a tap's fragment read is
+// again 16 consecutive float4 per quarter-wave
+constexpr int kHalo2W = 2 * kLT_W + 1, kHalo2Wh = kLT_W + 1;
+constexpr int lds_a2_slots(int RW) { return (8 * RW + 1) * 4 * 2 * kHalo2Wh; }  // 2312 (RW=2) / 1224 (RW=1)
+constexpr int lds_a_slots(int RW, bool S2) { return S2 ? (lds_a2_slots(RW) > lds_a_slots(RW) ? lds_a2_slots(RW) : lds_a_slots(RW)) : lds_a_slots(RW); }
 constexpr int lds_b_slots(int NJ) { return 9 * 4 * 16 * NJ; }
 
 // sA / sB: the workgroup's LDS images (declared by the kernel so that a kernel hosting several instantiations
 // of this body — level_k — allocates them once)
 // NORM: source 0 is read through a per-(image, channel) normalisation + activation (idh_conv_src.norm): the statistics
 // of the chunk's channels are prefetched with the halo and applied when the halo is committed to LDS.
-template <int RW, bool UP, int NJ, bool NORM = false>
+// S2: source 1 is a 3x3 stride-2 convolution of the block input (the projection of a stride-2 BasicBlock,
+// layers.py:71-74) instead of a 1x1: its (8*RW+1) x 33 halo is staged like source 0's, de-interleaved by column parity.
+template <int RW, bool UP, int NJ, bool NORM = false, bool S2 = false>
 __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned blk_in, unsigned nblk, f32x4 *__restrict__ sA,
                                                  f32x4 *__restrict__ sB) {
     constexpr int kN = 16 * NJ;                  // output channels per workgroup
@@ -301,7 +309,9 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     // ---- staging: global -> registers (prefetch) -> LDS -----------------------------------
     // A slots are enumerated (hy, hx, q) with q fastest so that 4 consecutive lanes read the 64
     // contiguous bytes of one pixel; the LDS image is [hy][q][hx].
-    f32x4 pa[(UP ? 4 : 1) * kALoads], pb[kBLoads];
+    constexpr int kA2Slots = (8 * RW + 1) * kHalo2W * 4;  // real halo slots of the stride-2 source (hy, hx, q)
+    constexpr int kA2Loads = (kA2Slots + 255) / 256;
+    f32x4 pa[S2 ? kA2Loads : (UP ? 4 : 1) * kALoads], pb[kBLoads];
     f32x4 pmean[NORM ? kALoads : 1], prstd[NORM ? kALoads : 1];
     unsigned in_image = 0;  // NORM: bit k = halo slot k is a real pixel (a zero-padded tap stays 0 after normalisation)
     // low-resolution neighbours + weights of hi-res pixel (iy, ix) under x2 bilinear, align_corners=False
@@ -462,6 +472,60 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
     };
 
+    // 3x3 stride-2 source 1 (S2): halo pixel (hy, hx) = input (2*y0 + hy - 1, 2*x0 + hx - 1); zero padding
+    auto issue2 = [&](int c) {
+        const ConvSrc &s = a.s[1];
+#pragma unroll
+        for (int k = 0; k < kA2Loads; ++k) {
+            const int slot = tid + 256 * k;
+            const int q = slot & 3, pix = slot >> 2;
+            const int hy = pix / kHalo2W, hx = pix - hy * kHalo2W;
+            const int iy = 2 * y0 + hy - 1, ix = 2 * x0 + hx - 1;
+            const bool ok = (slot < kA2Slots) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
+            pa[k] = *reinterpret_cast<const f32x4 *>(p);
+        }
+        const float *wb = s.w + ((size_t)(4 * c) * a.Cout_pad + n0) * 4;
+#pragma unroll
+        for (int k = 0; k < kBLoads; ++k) {
+            const int slot = tid + 256 * k;
+            const int co = slot % kN, tq = slot / kN;
+            const int tap = tq >> 2, q = tq & 3;
+            const float *p = (slot < kBSlots3) ? wb + ((size_t)(tap * s.cblocks * 4 + q) * a.Cout_pad + co) * 4 : g_zero_page;
+            pb[k] = *reinterpret_cast<const f32x4 *>(p);
+        }
+    };
+    auto commit2 = [&]() {
+#pragma unroll
+        for (int k = 0; k < kA2Loads; ++k) {
+            const int slot = tid + 256 * k;
+            const int q = slot & 3, pix = slot >> 2;
+            const int hy = pix / kHalo2W, hx = pix - hy * kHalo2W;
+            if (slot < kA2Slots) sA[((hy * 4 + q) * 2 + (hx & 1)) * kHalo2Wh + (hx >> 1)] = pa[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kBLoads; ++k)
+            if (tid + 256 * k < kBSlots3) sB[k * 256 + tid] = pb[k];
+    };
+    auto compute2 = [&]() {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            f32x4 A[RW], Bf[NJ];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) A[i] = sA[(((2 * (RW * wave + i) + dy) * 4 + h) * 2 + (dx & 1)) * kHalo2Wh + ln + (dx >> 1)];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) Bf[j] = sB[(tap * 4 + h) * kN + 16 * j + ln];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < RW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
+        }
+    };
+
     // ---- source 0 chunks ---------------------------------------------------------------------
     {
         const int lo = min(t0, nc0), hi = min(t1, nc0);
@@ -475,17 +539,29 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             compute3();
         }
     }
-    // ---- source 1 chunks (fused 1x1 projection) ------------------------------------------------
+    // ---- source 1 chunks (fused projection: 1x1, or 3x3 stride 2 with S2) -----------------------------
     if (nc1 > 0) {
         const int lo = max(t0 - nc0, 0), hi = max(t1 - nc0, 0);
-        if (lo < hi) issue1(lo);
+        if constexpr (S2) {
+            if (lo < hi) issue2(lo);
 #pragma unroll 1
-        for (int c = lo; c < hi; ++c) {
-            __syncthreads();
-            commit1(c);
-            __syncthreads();
-            if (c + 1 < hi) issue1(c + 1);
-            compute1();
+            for (int c = lo; c < hi; ++c) {
+                __syncthreads();
+                commit2();
+                __syncthreads();
+                if (c + 1 < hi) issue2(c + 1);
+                compute2();
+            }
+        } else {
+            if (lo < hi) issue1(lo);
+#pragma unroll 1
+            for (int c = lo; c < hi; ++c) {
+                __syncthreads();
+                commit1(c);
+                __syncthreads();
+                if (c + 1 < hi) issue1(c + 1);
+                compute1();
+            }
         }
     }
 
@@ -518,11 +594,11 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     }
 }
 
-template <int RW, bool UP, int NJ = 4, bool NORM = false>
+template <int RW, bool UP, int NJ = 4, bool NORM = false, bool S2 = false>
 __global__ __launch_bounds__(256) void conv3x3_lds_k(const LdsConvArgs la) {
-    __shared__ f32x4 sA[lds_a_slots(RW)];
+    __shared__ f32x4 sA[lds_a_slots(RW, S2)];
     __shared__ f32x4 sB[lds_b_slots(NJ)];
-    conv3x3_lds_body<RW, UP, NJ, NORM>(la, blockIdx.x, gridDim.x, sA, sB);
+    conv3x3_lds_body<RW, UP, NJ, NORM, S2>(la, blockIdx.x, gridDim.x, sA, sB);
 }
 // fused-upsample variants: keep 3 workgroups / CU (what the LDS footprint allows) although the 4x prefetch wants ~180 VGPRs
 template <int RW>
@@ -950,6 +1026,7 @@ struct PreparedConv {
     unsigned blocks;
     bool up;         // some source has fused x2-upsampled segments (LDS kernels only)
     bool norm;       // source 0 is normalised on load (LDS kernels with 16-channel tiles only)
+    bool s2;         // source 1 is a 3x3 stride-2 projection (LDS kernels with 64- / 32-channel tiles)
     int nj;          // LDS kernels: 16-channel output sub-tiles per workgroup (4, 2, 1)
     ReduceDesc red;  // valid when a.S > 1
 };
@@ -959,6 +1036,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     a = ConvArgs{};
     pc.up = false;
     pc.norm = op.src[0].norm != nullptr;
+    pc.s2 = false;
     pc.nj = 4;
     int steps = 0;
     for (int i = 0; i < 2; ++i) {
@@ -1010,7 +1088,10 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     const int nj = (op.tile_m == 8 || op.tile_m == 9 || op.tile_m == 0) ? (op.tile_n == 0 ? 4 : op.tile_n) : 4;
     const bool lds_ok = a.s[0].ks == 3 && a.s[0].stride == 1 && (nj == 4 || nj == 2 || nj == 1) && (op.Cout % (16 * nj)) == 0 &&
                         (a.s[0].pad_mode == IDH_PAD_ZEROS || (a.s[0].pad_mode == IDH_PAD_REPLICATE && !a.s[1].in)) &&
-                        (!a.s[1].in || (a.s[1].ks == 1 && a.s[1].stride == 1)) && op.Wo >= kLT_W;
+                        (!a.s[1].in || (a.s[1].ks == 1 && a.s[1].stride == 1) ||
+                         (a.s[1].ks == 3 && a.s[1].stride == 2 && a.s[1].pad_mode == IDH_PAD_ZEROS && !a.s[1].up_in[0] && !a.s[0].up_in[0] &&
+                          !op.src[0].norm && (nj == 4 || nj == 2))) &&
+                        op.Wo >= kLT_W;
     pc.lds_rows = 0;
     if (op.tile_m == IDH_SPLIT_F16X3) {
         // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
@@ -1033,6 +1114,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
         pc.blocks = (unsigned)blocks;
         pc.lds_rows = rows;
+        pc.s2 = a.s[1].in && a.s[1].ks == 3;
     } else {
         int tm = op.tile_m, tn = op.tile_n;
         if (tm == 8 || tm == 9) tm = 0;
@@ -1062,6 +1144,10 @@ int launch_conv(const PreparedConv &pc, hipStream_t st) {
         return launch_conv_split(pc.a, pc.n_img, pc.tm, pc.tn, st);
     }
     if (pc.lds_rows == 8 && pc.up) IDH_LAUNCH(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8 && pc.s2 && pc.nj == 4) IDH_LAUNCH((conv3x3_lds_k<2, false, 4, false, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 8 && pc.s2) IDH_LAUNCH((conv3x3_lds_k<2, false, 2, false, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.s2 && pc.nj == 4) IDH_LAUNCH((conv3x3_lds_k<1, false, 4, false, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
+    else if (pc.lds_rows == 4 && pc.s2) IDH_LAUNCH((conv3x3_lds_k<1, false, 2, false, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 8 && pc.norm) IDH_LAUNCH((conv3x3_lds_k<2, false, 1, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 4 && pc.norm) IDH_LAUNCH((conv3x3_lds_k<1, false, 1, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 8 && pc.nj == 2) IDH_LAUNCH((conv3x3_lds_k<2, false, 2>), dim3(pc.blocks), dim3(256), 0, st, pc.la);
@@ -1143,7 +1229,7 @@ int launch_level(const PreparedConv *pcs, const int *kinds, int n, hipStream_t s
 
 // Level-launch member kind of a prepared conv, or -1
 int level_kind(const PreparedConv &pc) {
-    if (pc.up || pc.norm) return -1;
+    if (pc.up || pc.norm || pc.s2) return -1;
     if (pc.lds_rows == 4 && pc.nj == 4) return LV_LDS4;
     if (pc.lds_rows == 4 && pc.nj == 2) return LV_LDS2;
     if (pc.lds_rows == 0 && pc.tm == 1 && pc.tn == 4) return LV_MFMA14;
@@ -1222,10 +1308,10 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                     ++run;
                 }
                 int cnt = 0;  // homogeneous prefix
-                if (op.kind == IDH_OP_CONV && pcs[0].lds_rows == 4 && !pcs[0].norm) {
+                if (op.kind == IDH_OP_CONV && pcs[0].lds_rows == 4 && !pcs[0].norm && !pcs[0].s2) {
                     cnt = 1;
                     while (cnt < run && ops[i + cnt].kind == IDH_OP_CONV && pcs[cnt].lds_rows == 4 && pcs[cnt].nj == pcs[0].nj &&
-                           (!pcs[cnt].up || pcs[0].nj == 4) && !pcs[cnt].norm)
+                           (!pcs[cnt].up || pcs[0].nj == 4) && !pcs[cnt].norm && !pcs[cnt].s2)
                         ++cnt;
                 }
                 int mix = 0;  // mixed prefix of small members

@@ -246,7 +246,8 @@ def lds_eligible(srcs, cout: int, Wo: int, pad_mode: int) -> bool:
         return False
     if len(srcs) > 1:
         (v1, c1) = srcs[1]
-        if c1.kernel_size[0] != 1 or c1.stride[0] != 1:
+        strided3 = c1.kernel_size[0] == 3 and c1.stride[0] == 2 and pad_mode == PAD_ZEROS and cout % 32 == 0 and not isinstance(v1, CatView)
+        if not strided3 and (c1.kernel_size[0] != 1 or c1.stride[0] != 1):  # BasicBlock's downsample(x): 1x1, or 3x3 stride 2
             return False
     return True
 
