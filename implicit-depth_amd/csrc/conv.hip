@@ -1246,6 +1246,7 @@ int check_upsample(const idh_op &op) {
 // for several rounds on its own gains nothing from sharing a grid and keeps its specialised kernel.
 constexpr unsigned kLevelMaxBlocks = 512;
 constexpr unsigned kLevelUpsampleBlocks = 512;
+constexpr long long kLevelUpsampleNatural = 4096;  // one frame's largest upsample (64 ch, 96x128 -> 192x256) is 3072
 
 }  // namespace
 
@@ -1300,8 +1301,11 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                         c.out = o.out; c.out_cs = o.out_cs; c.M = o.N; c.S = 1;
                         pc.a = c;
                         const long long tot = (long long)o.N * 4 * us.H * us.W * (us.Cin >> 2);
-                        pc.blocks = (unsigned)std::min<long long>(idh_cdiv(tot, 256), kLevelUpsampleBlocks);
-                        kinds[run] = LV_UP2;
+                        const long long natural = idh_cdiv(tot, 256);
+                        pc.blocks = (unsigned)std::min<long long>(natural, kLevelUpsampleBlocks);
+                        // a large upsample (batch >= 2 at the top resolutions) runs at HBM speed on its own grid of thousands
+                        // of blocks; squeezed into 512 grid-stride blocks it is slower than the launch it saves
+                        kinds[run] = natural <= kLevelUpsampleNatural ? LV_UP2 : -1;
                     } else {
                         break;
                     }
