@@ -281,7 +281,7 @@ class HotPathWorkload:
             ev[1].record()
 
     # roofline of the dominant kernel -------------------------------------------------------
-    dominant_kernel = "conv3x3_lds_k<2, false, 4, false>"  # as rocprofv3 --kernel-trace names it
+    dominant_kernel = "conv3x3_lds_k<2, false, 4, false, false>"  # as rocprofv3 --kernel-trace names it
 
     def _replay_ms(self, ops, iters=10, batches=3):
         """ms per pass of `ops` replayed alone between HIP events on the launch stream: median of
@@ -325,7 +325,7 @@ class HotPathWorkload:
             self.dominant_kernel = "conv3x3_split_k<4, 2, 1, *>"
         if not dom:  # small batches: every layer runs on the 4-row tile variant
             dom = [op for op in convs if op.tile_m == 9]
-            self.dominant_kernel = "conv3x3_lds_k<1, false, *, false> + conv3x3_lds_group_k<1, false, *> + level_k<*>"
+            self.dominant_kernel = "conv3x3_lds_k<1, false, *, false, *> + conv3x3_lds_group_k<1, false, *> + level_k<*>"
         dom_res = (self._replay_ms(dom, iters), len(dom), sum(self._conv_flops(o) for o in dom))
         all_res = (self._replay_ms(convs, iters), len(convs), sum(self._conv_flops(o) for o in convs))
         return dom_res, all_res
