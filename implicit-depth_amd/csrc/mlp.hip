@@ -27,17 +27,16 @@ using namespace idh_f16;
 constexpr int kHidden = 128;           // mlp_size (networks.py:88)
 constexpr int kNS = kHidden / 16;      // 8 sub-tiles of 16 hidden units
 
-// nn.ELU(alpha = 1), fp32 path.  exp(x) - 1 through v_exp_f32 (1 ulp) where the result is >= 0.06 in magnitude
-// (relative error < 2e-6, torch's own kernel forms exp(x) - 1 the same way) and a degree-5 Taylor polynomial on
-// (-1/16, 0] (truncation < 1e-10), instead of ocml's expm1f (~25 VALU per activation against 8 here): the 64
-// activations per pixel and plane were ~1000 vector instructions against 256 MFMAs.
+// nn.ELU(alpha = 1): x > 0 ? x : exp(x) - 1, formed exactly as torch's kernel forms it (exp, then subtract), with the
+// exponential through v_exp_f32 (1 ulp; exp(x) = exp2(x * log2 e): relative error < 1e-6 for the |x| < 10 that occur)
+// instead of ocml's expm1f (~25 VALU per activation against 5 here).  fp32 MFMA and VALU serialise on a SIMD (DESIGN
+// 4.3), and the 64 activations per pixel and plane were ~1000 vector instructions against 256 MFMAs: 4.63 -> 4.23 ms
+// with a polynomial near 0, -> this form.
 __device__ __forceinline__ float elu1(float x) {
 #ifdef IDH_ELU_OCML
     return x > 0.f ? x : expm1f(x);
 #else
-    const float p = x * fmaf(x, fmaf(x, fmaf(x, fmaf(x, 1.0f / 120.0f, 1.0f / 24.0f), 1.0f / 6.0f), 0.5f), 1.0f);
-    const float e = __expf(x) - 1.0f;
-    return x > 0.f ? x : (x > -0.0625f ? p : e);
+    return x > 0.f ? x : __expf(x) - 1.0f;
 #endif
 }
 // ELU of the split-precision kernel: exp via v_exp_f32 (2 ulp of a value near 1 -> |err| ~1e-7
