@@ -294,11 +294,17 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     const int n0 = nt * kN;
     const bool replicate = a.s[0].pad_mode == IDH_PAD_REPLICATE;  // nn.Conv2d(padding_mode="replicate"): clamp instead of the zero page
 
+    // the accumulators start from the bias (when this workgroup writes final values, i.e. no split-K): the 16-byte bias
+    // loads replace the zero moves and the epilogue's adds — fp32 MFMA and VALU share the SIMD's datapath,
+    // every vector instruction outside the K loop is paid in MFMA time
     f32x4 acc[RW][NJ];
+    const bool bias_first = a.bias != nullptr && a.S == 1;
 #pragma unroll
-    for (int i = 0; i < RW; ++i)
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 b4 = bias_first ? *reinterpret_cast<const f32x4 *>(a.bias + n0 + 16 * j + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < RW; ++i) acc[i][j] = b4;
+    }
 
     // chunk list = [source-0 chunks][source-1 chunks]; this block's split owns [t0,t1)
     const int nc0 = a.s[0].cblocks;
@@ -582,8 +588,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int co = n0 + 16 * j + 4 * h;
-            f32x4 v = acc[i][j];
-            if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
+            f32x4 v = acc[i][j];  // bias already inside (bias_first)
             if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
             if (a.act != IDH_ACT_NONE) {
 #pragma unroll

@@ -38,7 +38,7 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
-    if (act == IDH_ACT_LRELU) return v < 0.f ? v * slope : v;
+    if (act == IDH_ACT_LRELU) return (slope >= 0.f && slope <= 1.f) ? fmaxf(v, v * slope) : (v < 0.f ? v * slope : v);  // max: one instruction less, same value
     if (act == IDH_ACT_ELU) return v > 0.f ? v : expm1f(v);  // nn.ELU(alpha=1), networks_fast.py:17
     return v;
 }

@@ -9,17 +9,18 @@ run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv 
 ARGS="$*"
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_WAVES
 run sq2 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE
+run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_SALU
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TA_BUSY_avr
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run fetch FETCH_SIZE
 python - <<PY
 import csv, glob, collections
-for name in ["sq1","sq2","tcp","tcc","fetch"]:
+for name in ["sq1","sq2","lds","tcp","tcc","fetch"]:
     fs = glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True)
     if not fs: print(name, "no csv"); continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "conv_mfma_k" in r["Kernel_Name"]:
+        if "conv" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         print(f"{name:6s} {k:34s} n={len(v)} last={v[-1]:.4g}")
