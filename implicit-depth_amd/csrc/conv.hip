@@ -320,6 +320,36 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     f32x4 pa[S2 ? kA2Loads : (UP ? 4 : 1) * kALoads], pb[kBLoads];
     f32x4 pmean[NORM ? kALoads : 1], prstd[NORM ? kALoads : 1];
     unsigned in_image = 0;  // NORM: bit k = halo slot k is a real pixel (a zero-padded tap stays 0 after normalisation)
+    // Plain (not upsample-fused) source 0: buffer loads.  The byte offset of every halo / weight slot of this lane is
+    // computed ONCE (one VGPR each); the chunk only moves the scalar offset, and padding is the descriptor's range check
+    // (an out-of-image slot gets an offset past the image and reads 0).  The K loop then spends no vector instructions
+    // on addresses — they would be paid in MFMA time.
+    constexpr int kOob = 0x7fffffff;
+    int voffA[UP ? 1 : kALoads], voffB[UP ? 1 : kBLoads];
+    __amdgpu_buffer_rsrc_t rsA, rsW;
+    if constexpr (!UP) {
+        const ConvSrc &s = a.s[0];
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)n * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
+        rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, 9 * s.cblocks * 4 * a.Cout_pad * 16, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < kALoads; ++k) {
+            const int slot = tid + 256 * k;
+            const int q = slot & 3, pix = slot >> 2;
+            const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
+            int iy = y0 + hy - 1, ix = x0 + hx - 1;
+            bool ok = (slot < kASlots) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            if (replicate) { iy = min(max(iy, 0), s.H - 1); ix = min(max(ix, 0), s.W - 1); ok = slot < kASlots; }
+            voffA[k] = ok ? ((iy * s.W + ix) * s.cs + 4 * q) * 4 : kOob;
+            if (NORM) in_image = ok ? (in_image | (1u << k)) : in_image;
+        }
+#pragma unroll
+        for (int k = 0; k < kBLoads; ++k) {  // slot = ((tap * 4 + q) * kN + co); NJ = 4: tap k, q = tid >> 6, co = tid & 63
+            const int slot = tid + 256 * k;
+            const int co = slot % kN, tq = slot / kN;
+            const int tap = tq >> 2, q = tq & 3;
+            voffB[k] = (slot < kBSlots3) ? ((tap * s.cblocks * 4 + q) * a.Cout_pad + co + n0) * 16 : kOob;
+        }
+    }
     // low-resolution neighbours + weights of hi-res pixel (iy, ix) under x2 bilinear, align_corners=False
     auto up_taps = [&](const ConvSrc &s, int c, int iy, int ix, int q, bool ok, const float *(&tp)[4]) {
         const int rel = 16 * c - s.up_c0;
@@ -358,6 +388,21 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pa[(UP ? 4 : 1) * k + (UP ? e : 0)] = *reinterpret_cast<const f32x4 *>(tp[e]);
             }
+        } else if constexpr (!UP) {
+#pragma unroll
+            for (int k = 0; k < kALoads; ++k) {
+                pa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[k], 64 * c, 0));
+                if (NORM) {
+                    const int q = (tid + 256 * k) & 3;
+                    const float *st = s.norm + (size_t)n * 2 * s.Cin + 16 * c + 4 * q;
+                    pmean[k] = *reinterpret_cast<const f32x4 *>(st);
+                    prstd[k] = *reinterpret_cast<const f32x4 *>(st + s.Cin);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kBLoads; ++k)
+                pb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffB[k], c * 4 * a.Cout_pad * 16, 0));
+            return;
         } else {
 #pragma unroll
         for (int k = 0; k < kALoads; ++k) {
@@ -369,12 +414,6 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             if (replicate) { iy = min(max(iy, 0), s.H - 1); ix = min(max(ix, 0), s.W - 1); ok = slot < kASlots; }
             const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
             pa[(UP ? 4 : 1) * k] = *reinterpret_cast<const f32x4 *>(p);
-            if (NORM) {
-                const float *st = s.norm + (size_t)n * 2 * s.Cin + 16 * c + 4 * q;
-                pmean[k] = *reinterpret_cast<const f32x4 *>(st);
-                prstd[k] = *reinterpret_cast<const f32x4 *>(st + s.Cin);
-                in_image = ok ? (in_image | (1u << k)) : (in_image & ~(1u << k));
-            }
         }
         }
         const float *wb = s.w + ((size_t)(4 * c) * a.Cout_pad + n0) * 4;
@@ -1098,6 +1137,8 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
                           !op.src[0].norm && (nj == 4 || nj == 2))) &&
                         op.Wo >= kLT_W;
     pc.lds_rows = 0;
+    // the LDS kernels address source 0 with 32-bit byte offsets inside one image / the packed weights
+    const bool lds_fits = (long long)a.s[0].H * a.s[0].W * a.s[0].cs * 4 < (1ll << 31) && 9ll * a.s[0].cblocks * 4 * a.Cout_pad * 16 < (1ll << 31);
     if (op.tile_m == IDH_SPLIT_F16X3) {
         // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
         if (!lds_ok || a.s[0].pad_mode != IDH_PAD_ZEROS || (op.Cout % 64) || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1 || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16))
@@ -1108,7 +1149,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         pc.tn = op.tile_n == 8 ? 8 : 16;  // tile rows
         pc.n_img = op.N;
         pc.blocks = 0;
-    } else if (lds_ok && (op.tile_m == 8 || op.tile_m == 0 || op.tile_m == 9)) {
+    } else if (lds_ok && lds_fits && (op.tile_m == 8 || op.tile_m == 0 || op.tile_m == 9)) {
         const int rows = op.tile_m == 9 ? 4 : 8;
         const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
         if (a.S > chunks) a.S = chunks;
