@@ -465,8 +465,32 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
         }
     };
     // 1x1 source 1: A = the centre pixels of the tile (kCLoads float4 per thread), B = 4 x 64 float4
+    // (plain variant: offsets computed once, as for source 0)
+    int voffC[(UP || S2) ? 1 : kCLoads], voffB1 = kOob;
+    __amdgpu_buffer_rsrc_t rsC, rsW1;
+    if constexpr (!UP && !S2) {
+        const ConvSrc &s = a.s[1];
+        if (nc1 > 0) {
+            rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)n * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
+            rsW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, s.cblocks * 4 * a.Cout_pad * 16, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < kCLoads; ++k) {
+                const int slot = tid + 256 * k;
+                const int q = slot & 3, pix = slot >> 2;
+                const int iy = y0 + (pix >> 4), ix = x0 + (pix & 15);
+                voffC[k] = ((iy < s.H) & (ix < s.W)) ? ((iy * s.W + ix) * s.cs + 4 * q) * 4 : kOob;
+            }
+            voffB1 = (tid < 4 * kN) ? ((tid / kN) * a.Cout_pad + n0 + (tid % kN)) * 16 : kOob;
+        }
+    }
     auto issue1 = [&](int c) {
         const ConvSrc &s = a.s[1];
+        if constexpr (!UP && !S2) {
+#pragma unroll
+            for (int k = 0; k < kCLoads; ++k) pa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsC, voffC[k], 64 * c, 0));
+            pb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW1, voffB1, c * 4 * a.Cout_pad * 16, 0));
+            return;
+        }
         const bool up = UP && s.up_in[0] != nullptr && 16 * c >= s.up_c0;
 #pragma unroll
         for (int k = 0; k < kCLoads; ++k) {
@@ -518,8 +542,12 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     };
 
     // 3x3 stride-2 source 1 (S2): halo pixel (hy, hx) = input (2*y0 + hy - 1, 2*x0 + hx - 1); zero padding
-    auto issue2 = [&](int c) {
+    int voffA2[S2 ? kA2Loads : 1], voffB2[S2 ? kBLoads : 1];
+    __amdgpu_buffer_rsrc_t rsA2, rsW2;
+    if constexpr (S2) {
         const ConvSrc &s = a.s[1];
+        rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)n * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
+        rsW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, 9 * s.cblocks * 4 * a.Cout_pad * 16, 0x00020000);
 #pragma unroll
         for (int k = 0; k < kA2Loads; ++k) {
             const int slot = tid + 256 * k;
@@ -527,17 +555,22 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
             const int hy = pix / kHalo2W, hx = pix - hy * kHalo2W;
             const int iy = 2 * y0 + hy - 1, ix = 2 * x0 + hx - 1;
             const bool ok = (slot < kA2Slots) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
-            const float *p = ok ? s.in + ((size_t)(n * s.H + iy) * s.W + ix) * s.cs + 16 * c + 4 * q : g_zero_page;
-            pa[k] = *reinterpret_cast<const f32x4 *>(p);
+            voffA2[k] = ok ? ((iy * s.W + ix) * s.cs + 4 * q) * 4 : kOob;
         }
-        const float *wb = s.w + ((size_t)(4 * c) * a.Cout_pad + n0) * 4;
 #pragma unroll
         for (int k = 0; k < kBLoads; ++k) {
             const int slot = tid + 256 * k;
             const int co = slot % kN, tq = slot / kN;
             const int tap = tq >> 2, q = tq & 3;
-            const float *p = (slot < kBSlots3) ? wb + ((size_t)(tap * s.cblocks * 4 + q) * a.Cout_pad + co) * 4 : g_zero_page;
-            pb[k] = *reinterpret_cast<const f32x4 *>(p);
+            voffB2[k] = (slot < kBSlots3) ? ((tap * s.cblocks * 4 + q) * a.Cout_pad + co + n0) * 16 : kOob;
+        }
+    }
+    auto issue2 = [&](int c) {
+        if constexpr (S2) {
+#pragma unroll
+            for (int k = 0; k < kA2Loads; ++k) pa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA2, voffA2[k], 64 * c, 0));
+#pragma unroll
+            for (int k = 0; k < kBLoads; ++k) pb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW2, voffB2[k], c * 4 * a.Cout_pad * 16, 0));
         }
     };
     auto commit2 = [&]() {
@@ -611,31 +644,55 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     }
 
     // ---- epilogue (same transposed C/D layout as above: 4 consecutive channels per lane) -------
+    // buffer stores / residual loads: one byte offset per tile row of the lane, the channel sub-tile is the instruction's
+    // immediate offset; rows and columns past the image are out of the descriptor's range (dropped / read as 0)
+    if (a.S > 1) {
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int oy = y0 + RW * wave + i, ox = x0 + ln;
-        if (oy >= a.Ho || ox >= a.Wo) continue;
-        const size_t m = ((size_t)n * a.Ho + oy) * a.Wo + ox;
-        if (a.S > 1) {
+        for (int i = 0; i < RW; ++i) {
+            const int oy = y0 + RW * wave + i, ox = x0 + ln;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const size_t m = ((size_t)n * a.Ho + oy) * a.Wo + ox;
             float *o = a.ws + ((size_t)sp * a.M + m) * a.Cout_pad + n0 + 4 * h;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4 *>(o + 16 * j) = acc[i][j];
-            continue;
         }
-        float *o = a.out + m * a.out_cs;
-        const float *rp = a.res ? a.res + m * a.res_cs : nullptr;
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)n * a.Ho * a.Wo * a.out_cs, 0, a.Ho * a.Wo * a.out_cs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)n * a.Ho * a.Wo * a.res_cs : a.out), 0,
+                                                                          a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    int voffO[RW], voffR[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int oy = y0 + RW * wave + i, ox = x0 + ln;
+        const bool ok = (oy < a.Ho) & (ox < a.Wo);
+        const int pixel = oy * a.Wo + ox;
+        voffO[i] = ok ? (pixel * a.out_cs + n0 + 4 * h) * 4 : kOob;
+        voffR[i] = ok ? (pixel * a.res_cs + n0 + 4 * h) * 4 : kOob;
+    }
+    if (a.res) {  // all residual loads of the tile in flight before the first add
+        f32x4 rv[RW][NJ];
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rv[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voffR[i] + 64 * j, 0, 0));
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] += rv[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int co = n0 + 16 * j + 4 * h;
             f32x4 v = acc[i][j];  // bias already inside (bias_first)
-            if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
             if (a.act != IDH_ACT_NONE) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, a.slope);
             }
-            *reinterpret_cast<f32x4 *>(o + co) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsO, voffO[i] + 64 * j, 0, 0);
         }
-    }
 }
 
 template <int RW, bool UP, int NJ = 4, bool NORM = false, bool S2 = false>
@@ -1138,7 +1195,9 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
                         op.Wo >= kLT_W;
     pc.lds_rows = 0;
     // the LDS kernels address source 0 with 32-bit byte offsets inside one image / the packed weights
-    const bool lds_fits = (long long)a.s[0].H * a.s[0].W * a.s[0].cs * 4 < (1ll << 31) && 9ll * a.s[0].cblocks * 4 * a.Cout_pad * 16 < (1ll << 31);
+    const bool lds_fits = (long long)a.s[0].H * a.s[0].W * a.s[0].cs * 4 < (1ll << 31) && 9ll * a.s[0].cblocks * 4 * a.Cout_pad * 16 < (1ll << 31) &&
+                          (!a.s[1].in || ((long long)a.s[1].H * a.s[1].W * a.s[1].cs * 4 < (1ll << 31) && 9ll * a.s[1].cblocks * 4 * a.Cout_pad * 16 < (1ll << 31))) &&
+                          (long long)op.Ho * op.Wo * op.out_cs * 4 < (1ll << 31) && (!op.res || (long long)op.Ho * op.Wo * op.res_cs * 4 < (1ll << 31));
     if (op.tile_m == IDH_SPLIT_F16X3) {
         // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
         if (!lds_ok || a.s[0].pad_mode != IDH_PAD_ZEROS || (op.Cout % 64) || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1 || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16))
