@@ -326,9 +326,10 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     // on addresses — they would be paid in MFMA time.
     constexpr int kOob = 0x7fffffff;
     int voffA[UP ? 1 : kALoads], voffB[UP ? 1 : kBLoads];
-    __amdgpu_buffer_rsrc_t rsA, rsW;
+    __amdgpu_buffer_rsrc_t rsA, rsW, rsN;
     if constexpr (!UP) {
         const ConvSrc &s = a.s[0];
+        if constexpr (NORM) rsN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.norm + (size_t)n * 2 * s.Cin), 0, 2 * s.Cin * 4, 0x00020000);
         rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)n * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
         rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, 9 * s.cblocks * 4 * a.Cout_pad * 16, 0x00020000);
 #pragma unroll
@@ -392,11 +393,9 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
 #pragma unroll
             for (int k = 0; k < kALoads; ++k) {
                 pa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[k], 64 * c, 0));
-                if (NORM) {
-                    const int q = (tid + 256 * k) & 3;
-                    const float *st = s.norm + (size_t)n * 2 * s.Cin + 16 * c + 4 * q;
-                    pmean[k] = *reinterpret_cast<const f32x4 *>(st);
-                    prstd[k] = *reinterpret_cast<const f32x4 *>(st + s.Cin);
+                if (NORM) {  // statistics of this slot's channel quad: offset 16 q bytes (tid & 3 == slot & 3), chunk and mean / rstd in the scalar offset
+                    pmean[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsN, (tid & 3) * 16, 64 * c, 0));
+                    prstd[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsN, (tid & 3) * 16, 64 * c + s.Cin * 4, 0));
                 }
             }
 #pragma unroll
