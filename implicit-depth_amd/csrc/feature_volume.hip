@@ -209,12 +209,11 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
             // metadata registers of this lane: [0..6] view q, [7..13] view q+4, [14] plane depth
             float m0 = 0.f, m1 = 0.f, m2 = 0.f, m7 = 0.f, m8 = 0.f, m9 = 0.f;
-            bool any_inb = false, any_front = false;
             // Software-pipelined view loop: the projection + 4 tap loads of view k+1 are issued
             // before the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work.
             struct Tap {
                 f32x4 t00, t01, t10, t11;
-                float w00, w01, w10, w11, z, u, v;
+                float w00, w01, w10, w11, z;
             };
             auto issue = [&](int k) {
                 Tap t;
@@ -228,10 +227,9 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 t.z = fmaxf(cz, 1e-5f);
                 float r = __builtin_amdgcn_rcpf(t.z);
                 r = r * fmaf(-t.z, r, 2.0f);
-                t.u = cx * r;
-                t.v = cy * r;
-                const float sx = fminf(fmaxf(t.u - 0.5f, -1.0f), Wf);
-                const float sy = fminf(fmaxf(t.v - 0.5f, -1.0f), Hf);
+                const float su = cx * r, sv = cy * r;
+                const float sx = fminf(fmaxf(su - 0.5f, -1.0f), Wf);
+                const float sy = fminf(fmaxf(sv - 0.5f, -1.0f), Hf);
                 const float x0f = floorf(sx), y0f = floorf(sy);
                 const float fx = sx - x0f, fy = sy - y0f;
                 const int x0 = (int)x0f, y0 = (int)y0f;
@@ -253,10 +251,8 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 #pragma clang loop unroll_count(KT > 0 ? KT : 1)
             for (int k = 0; k < K; ++k) {
                 const Tap nxt = issue(min(k + 1, K - 1));  // unconditional: counted vmcnt waits
-                any_inb |= (cur.u > 2.f) & (cur.u < Wf - 2.f) & (cur.v > 2.f) & (cur.v < Hf - 2.f);
                 const float z = cur.z;
                 const float maskv = z > 0.f ? 1.f : 0.f;
-                any_front |= z > 0.f;
                 f32x4 wv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -277,18 +273,17 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                     for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
                 }
                 if constexpr (KT > 0) {
-                    // Scheduling hint (unrolled view loop = one scheduling region): ask for "1 MFMA, 2 VALU" groups instead
-                    // of a ~100-instruction vector block followed by 32 back-to-back matrix ops.  The machine scheduler
-                    // only partly honours it, but more of the next view's projection issues under this view's MFMAs:
-                    // 17.81 -> 17.32 ms per 32 frames (K=7, D=64).  Measured and rejected (profiles/r02/README.md): 3 or 4
-                    // VALU per MFMA (17.4-17.5), a plain sched_barrier per view (17.29, same), and hand-made three-stage
-                    // pipelines (MFMAs of view k next to the blend of k+1 and the projection of k+2) left to the scheduler
-                    // (18.29), fenced in groups of 4 MFMAs (17.69) or fenced per MFMA (18.10): with two waves per SIMD the
-                    // other wave's vector work already fills most of the gaps.
+                    // Scheduling hint (unrolled view loop = one scheduling region): ask for small alternating groups of MFMAs and
+                    // vector instructions instead of a ~90-instruction vector block followed by 32 back-to-back matrix ops.
+                    // fp32 MFMA and VALU do not overlap on a SIMD, so this only trims dependency stalls — and the
+                    // best pattern follows the vector-instruction count of a view: "1 MFMA, 2 VALU" x 32 was best with the
+                    // mask tracked in this loop (17.81 -> 17.33 ms per 32 frames, K=7, D=64); with the mask moved out of the
+                    // loop that pattern costs 17.58, no hint 17.33, a plain sched_barrier per view 17.21 and "2 MFMA, 3 VALU"
+                    // x 16: 17.19.  Hand-made pipelines across views were all slower (profiles/r02/experiments.md).
 #pragma unroll
-                    for (int r = 0; r < 32; ++r) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    for (int r = 0; r < 16; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                     }
                 }
                 cur = nxt;
@@ -369,7 +364,27 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 a.vol[((size_t)b * a.D + d) * N + p] = val;
             }
             // overall mask: the reference overwrites it every plane, the LAST plane survives
-            if (q == 0 && live && a.mask != nullptr && d == a.D - 1) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
+            // (only the last plane's mask is ever visible, so it is not tracked in the view loop — 10 vector instructions per
+            // view and plane — but recomputed here from the same projection expressions, once per pixel tile)
+            if (a.mask != nullptr && d == a.D - 1) {
+                bool any_inb = false, any_front = false;
+                for (int k = 0; k < K; ++k) {
+                    const float *hm = pb + kWsHom + 12 * k;
+                    const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+                    const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+                    const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+                    const float cx = fmaf(depth, qx, hm[9]);
+                    const float cy = fmaf(depth, qy, hm[10]);
+                    const float cz = fmaf(depth, qz, hm[11]);
+                    const float z = fmaxf(cz, 1e-5f);
+                    float r = __builtin_amdgcn_rcpf(z);
+                    r = r * fmaf(-z, r, 2.0f);
+                    const float u = cx * r, v = cy * r;
+                    any_inb |= (u > 2.f) & (u < Wf - 2.f) & (v > 2.f) & (v < Hf - 2.f);
+                    any_front |= z > 0.f;
+                }
+                if (q == 0 && live) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
+            }
         }
     }
 }
