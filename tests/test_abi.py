@@ -106,6 +106,8 @@ def test_launch_grouping_decisions_without_a_gpu():
     assert count([lds64(1, 5), lds32(1, 6)]) == 2
     # 32 frames: members fill the chip on their own -> equal-tile LDS convs still share a grid, the rest run alone
     assert count([lds64(32, 5), lds64(32, 5), lds32(32, 5), down(32, 5)]) == 3
+    # an image too large for the LDS kernels' 32-bit byte offsets (H*W*cs*4 >= 2 GiB) falls back to the direct kernel
+    assert count([_conv_op(nhwc, 1, 16384, 16384, 64, 64, 8, 0, 0)]) == 1
     # validation still applies in the dry run
     bad = lds64(1, 0)
     bad.out = None
