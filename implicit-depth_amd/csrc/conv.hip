@@ -1121,7 +1121,7 @@ inline int ceil16(int v) { return (v + 15) & ~15; }
 struct PreparedConv {
     ConvArgs a;
     LdsConvArgs la;
-    int lds_rows, tm, tn;  // lds_rows = 16: split-precision kernel, tm = IDH_SPLIT_* mode
+    int lds_rows, tm, tn;  // lds_rows = 16: split-precision kernel, tm = IDH_SPLIT_* mode; 32: Winograd kernel, tn = tile rows
     int n_img;
     unsigned blocks;
     bool up;         // some source has fused x2-upsampled segments (LDS kernels only)
@@ -1197,7 +1197,15 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     const bool lds_fits = (long long)a.s[0].H * a.s[0].W * a.s[0].cs * 4 < (1ll << 31) && 9ll * a.s[0].cblocks * 4 * a.Cout_pad * 16 < (1ll << 31) &&
                           (!a.s[1].in || ((long long)a.s[1].H * a.s[1].W * a.s[1].cs * 4 < (1ll << 31) && 9ll * a.s[1].cblocks * 4 * a.Cout_pad * 16 < (1ll << 31))) &&
                           (long long)op.Ho * op.Wo * op.out_cs * 4 < (1ll << 31) && (!op.res || (long long)op.Ho * op.Wo * op.res_cs * 4 < (1ll << 31));
-    if (op.tile_m == IDH_SPLIT_F16X3) {
+    if (op.tile_m == IDH_TILE_WINO) {
+        // Winograd F(2x2,3x3) kernel (conv_wino.hip): src[0].w holds idh_pack_conv_weight_wino output
+        if (!wino_supported(a) || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16)) return IDH_EUNSUPPORTED;
+        pc.lds_rows = 32;
+        pc.tm = op.tile_m;
+        pc.tn = op.tile_n == 8 ? 8 : 16;  // tile rows
+        pc.n_img = op.N;
+        pc.blocks = 0;
+    } else if (op.tile_m == IDH_SPLIT_F16X3) {
         // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
         if (!lds_ok || a.s[0].pad_mode != IDH_PAD_ZEROS || (op.Cout % 64) || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1 || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16))
             return IDH_EUNSUPPORTED;
@@ -1246,6 +1254,10 @@ int launch_conv(const PreparedConv &pc, hipStream_t st) {
     if (pc.lds_rows == 16) {
         if (t_dry_run) { ++t_launches; return IDH_OK; }
         return launch_conv_split(pc.a, pc.n_img, pc.tm, pc.tn, st);
+    }
+    if (pc.lds_rows == 32) {
+        if (t_dry_run) { ++t_launches; return IDH_OK; }
+        return launch_conv_wino(pc.a, pc.n_img, pc.tn, st);
     }
     if (pc.lds_rows == 8 && pc.up) IDH_LAUNCH(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 8 && pc.s2 && pc.nj == 4) IDH_LAUNCH((conv3x3_lds_k<2, false, 4, false, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);

@@ -49,4 +49,8 @@ constexpr int kZeroFloats = 4096;
 constexpr int kSplitTile = 16;  // 16x16 output pixels x 64 channels per workgroup
 int launch_conv_split(const ConvArgs &a, int N, int mode, int rows, hipStream_t st);  // mode = IDH_SPLIT_*, rows = 16 | 8
 
+// conv_wino.hip: Winograd F(2x2,3x3) on the fp32 matrix cores (3x3 stride 1, zero padding, one source, Cout % 32 == 0)
+bool wino_supported(const ConvArgs &a);
+int launch_conv_wino(const ConvArgs &a, int N, int rows, hipStream_t st);  // rows = 16 | 8 (tile rows per workgroup)
+
 }  // namespace idh_conv
