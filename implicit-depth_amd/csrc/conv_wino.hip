@@ -44,14 +44,17 @@ constexpr int wino_plane(int WAVES) { return (2 * WAVES + 2) * 2 * kWinoHalf; } 
 constexpr int wino_qs(int WAVES) { return (wino_plane(WAVES) + 63) / 64 * 64; }             // q-plane pitch
 constexpr int wino_stage(int WAVES, int NCO) { return 4 * wino_qs(WAVES) + NCO * 1024; }    // float4 slots per stage
 
-// OIHW 3x3 -> U = G g G^T in fragment order: dst[chunk c][co block][pos][h][m][e] = U[pos][co = 16 cb + m][ci = 16 c + 4 h + e]
-__global__ __launch_bounds__(256) void pack_wino_weight_k(const float *__restrict__ w, float *__restrict__ dst, int Cout, int Cin, int nC, int nCB) {
-    const long long total = (long long)nC * nCB * 16 * 256;
+// OIHW 3x3 -> U = G g G^T in fragment order: dst[step c][co block][pos][h][m][e] = U[pos][co = 16 cb + m][ci = CH c + KS h + e],
+// KS = CH / 4 consecutive channels per lane (CH = input channels per K step: 16 or 8)
+__global__ __launch_bounds__(256) void pack_wino_weight_k(const float *__restrict__ w, float *__restrict__ dst, int Cout, int Cin, int nS, int nCB, int KS) {
+    const long long total = (long long)nS * nCB * 16 * 64 * KS;
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
-        const int e = (int)(t & 3), m = (int)((t >> 2) & 15), h = (int)((t >> 6) & 3), pos = (int)((t >> 8) & 15);
-        const long long r = t >> 12;
+        const int e = (int)(t % KS);
+        long long r = t / KS;
+        const int m = (int)(r & 15), h = (int)((r >> 4) & 3), pos = (int)((r >> 6) & 15);
+        r >>= 10;
         const int cb = (int)(r % nCB), c = (int)(r / nCB);
-        const int co = 16 * cb + m, ci = 16 * c + 4 * h + e;
+        const int co = 16 * cb + m, ci = 4 * KS * c + KS * h + e;
         double u = 0.0;
         if (co < Cout && ci < Cin) {
             const float *g = w + ((size_t)co * Cin + ci) * 9;
@@ -77,17 +80,28 @@ struct WinoArgs {
     int tiles_x, tiles_y;
 };
 
-template <int WAVES, int NCO>
-__global__ __launch_bounds__(64 * WAVES) void conv3x3_wino_k(const WinoArgs wa) {
+template <int WAVES, int NCO, int CH>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs wa) {
+    constexpr int KS = CH / 4;   // MFMA k-steps per K step = consecutive channels per lane
+    constexpr int NP = CH / 4;   // 4-channel planes of the halo per K step
+    typedef float vec __attribute__((ext_vector_type(KS)));
     constexpr int kRows = 2 * WAVES;
     constexpr int kPlane = wino_plane(WAVES);
     constexpr int kQS = wino_qs(WAVES);
-    constexpr int kHaloInstr = 4 * (kQS / 64);   // 1 KiB DMA pieces of the halo
-    constexpr int kPanelInstr = NCO * 16;        // ... of the weight panel
-    constexpr int kTasks = kHaloInstr + kPanelInstr;
-    constexpr int kTPW = (kTasks + WAVES - 1) / WAVES;  // DMA pieces per wave and chunk
-    constexpr int kHalo = 4 * kQS;
-    constexpr int kStage = wino_stage(WAVES, NCO);
+    // LDS-DMA pieces (1 KiB each) of one K step, per wave: a plane of the halo is kJ pieces long; wave w copies piece
+    // j = f*WAVES + w of all NP planes (kFull rounds), its share of the kRem remaining j's (kExtra pieces of one j) and
+    // kPanel pieces of the weight panel -> one offset VGPR per distinct j plus one for the panel
+    constexpr int kJ = kQS / 64;
+    constexpr int kFull = kJ / WAVES, kRem = kJ % WAVES;
+    constexpr int kExtra = NP * kRem / WAVES;
+    static_assert(NP * kRem % WAVES == 0 && (kExtra == 0 || NP % kExtra == 0), "halo pieces must split evenly over the waves");
+    constexpr int kPanelPieces = NCO * 4 * KS;
+    static_assert(kPanelPieces % WAVES == 0, "panel pieces must split evenly over the waves");
+    constexpr int kPanel = kPanelPieces / WAVES;
+    constexpr int kTPW = NP * kFull + kExtra + kPanel;  // DMA pieces per wave and K step
+    static_assert(kTPW <= 16, "one DMA piece per position group");
+    constexpr int kHalo = NP * kQS;
+    constexpr int kStage = kHalo + 64 * kPanelPieces;   // float4 slots per stage
     __shared__ f32x4 lds[2 * kStage];
 
     const ConvArgs &a = wa.c;
@@ -104,42 +118,41 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_wino_k(const WinoArgs wa) 
     const int y0 = ty * kRows, x0 = tx * kWinoTileW;
     const int cb0 = nt * NCO;       // first 16-channel output block of this workgroup
     const int n0 = 16 * cb0;
-    const int nC = s.cblocks;
+    const int nS = s.cblocks * (16 / CH);  // K steps
     const int nCB = a.Cout_pad / 16;
 
-    // ---- LDS-DMA descriptors: this wave's kTPW pieces of every chunk ----------------------------------------------
+    // ---- LDS-DMA descriptors: this wave's kTPW pieces of every K step ---------------------------------------------
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, nC * nCB * 16384, 0x00020000);
-    int voff[kTPW];     // per-lane byte offset (halo: texel of this lane's slot, out of range = zero padding; panel: 16 * lane)
-    int soff0[kTPW];    // wave-uniform byte offset at chunk 0
-    int ldsoff[kTPW];   // wave-uniform float4 slot inside a stage
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, s.cblocks * nCB * 16384, 0x00020000);
+    auto halo_voff = [&](int j) {  // byte offset of this lane's texel in piece j of a plane: slot L of [row][17]
+        const int L = 64 * j + lane;
+        const int row = L / kWinoHalf, hxh = L - row * kWinoHalf;
+        const int iy = y0 - 1 + (row >> 1), ix = x0 - 1 + 2 * hxh + (row & 1);
+        const bool ok = (L < kPlane) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+        return ok ? (iy * s.W + ix) * s.cs * 4 : kOob;  // out of the descriptor's range = zero padding
+    };
+    int voffF[kFull > 0 ? kFull : 1];
 #pragma unroll
-    for (int k = 0; k < kTPW; ++k) {
-        const int t = wave * kTPW + k;
-        if (t < kHaloInstr) {
-            const int q = t & 3, j = t >> 2;
-            const int L = 64 * j + lane;            // slot inside the q plane: [row][17]
-            const int row = L / kWinoHalf, hxh = L - row * kWinoHalf;
-            const int iy = y0 - 1 + (row >> 1), ix = x0 - 1 + 2 * hxh + (row & 1);
-            const bool ok = (L < kPlane) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
-            voff[k] = ok ? (iy * s.W + ix) * s.cs * 4 : kOob;
-            soff0[k] = 16 * q;
-            ldsoff[k] = q * kQS + 64 * j;
+    for (int f = 0; f < kFull; ++f) voffF[f] = halo_voff(f * WAVES + wave);
+    const int jx = kFull * WAVES + (wave * kExtra) / NP, qx = (wave * kExtra) % NP;  // this wave's share of the remaining j's
+    const int voffX = kExtra ? halo_voff(jx) : 0;
+    const int voffP = 16 * lane;
+    // k-th DMA piece of this wave for K step c into `stage`; wave-uniform operands forced into SGPRs
+    auto issue_one = [&](int k, int c, int stage) {
+        int so, lo, vo;
+        bool halo = true;
+        if (k < NP * kFull) {
+            const int f = k / NP, q = k % NP;
+            vo = voffF[f]; so = 16 * q + 4 * CH * c; lo = q * kQS + 64 * (f * WAVES + wave);
+        } else if (k < NP * kFull + kExtra) {
+            const int q = qx + (k - NP * kFull);
+            vo = voffX; so = 16 * q + 4 * CH * c; lo = q * kQS + 64 * jx;
         } else {
-            const int i = t - kHaloInstr;
-            voff[k] = t < kTasks ? 16 * lane : kOob;
-            soff0[k] = (cb0 * 16 + i) * 1024;
-            ldsoff[k] = kHalo + 64 * i;
+            const int i = wave * kPanel + (k - NP * kFull - kExtra);
+            halo = false;
+            vo = voffP; so = ((c * nCB + cb0) * (4 * KS) + i) * 1024; lo = kHalo + 64 * i;
         }
-    }
-    auto issue = [&](int c, int stage) {
-#pragma unroll
-        for (int k = 0; k < kTPW; ++k) {
-            const int t = wave * kTPW + k;
-            if (kTasks % WAVES != 0 && t >= kTasks) break;  // (uniform) the last wave may own fewer pieces
-            const bool halo = t < kHaloInstr;
-            dma16(halo ? rsA : rsW, lds + stage * kStage + ldsoff[k], voff[k], soff0[k] + (halo ? 64 : nCB * 16384) * c);
-        }
+        dma16(halo ? rsA : rsW, lds + __builtin_amdgcn_readfirstlane(stage * kStage + lo), vo, __builtin_amdgcn_readfirstlane(so));
     };
 
     f32x4 acc[16][NCO];
@@ -148,49 +161,66 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_wino_k(const WinoArgs wa) 
 #pragma unroll
         for (int j = 0; j < NCO; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // this lane's patch origin inside a stage: q plane h, rows 4*wave .. (hy = 2*wave + y, parity x & 1), column n + (x >> 1)
-    const int patch0 = h * kQS + (4 * wave) * kWinoHalf + n;
-    const int frag0 = kHalo + h * 16 + n;
+    // this lane's KS channels of a texel: plane (KS h) / 4, byte (KS h % 4) * 4 of the 16-byte slot; patch origin = rows
+    // 4*wave .. of the plane (hy = 2*wave + y, column parity x & 1), column n + (x >> 1)
+    const int patch0 = ((((KS * h) >> 2) * kQS + (4 * wave) * kWinoHalf + n) * 16 + ((KS * h) & 3) * 4);  // bytes
+    const int frag0 = kHalo * 16 + (h * 16 + n) * (4 * KS);                                                   // bytes
 
-    auto compute = [&](int stage) {
-        const f32x4 *sH = lds + stage * kStage + patch0;
-        const f32x4 *sW = lds + stage * kStage + frag0;
-        f32x4 v[4][4];
+    // One K step: 16 position groups of KS*NCO MFMAs, in the order xi = 1, 2, 0, 3 (rows 1 and 2 of the patch feed the
+    // first eight groups, row 0 / row 3 are read while those run).  Every LDS read is issued kAhead groups ahead of its
+    // first use and the DMA pieces of the NEXT step are spread over the first groups, so that neither the LDS latency nor
+    // the ~100-cycle issue cost of an LDS-DMA instruction opens a gap in the matrix pipe; sched_barrier keeps the compiler
+    // from sinking the reads back to their uses.
+    constexpr int kAhead = CH == 16 ? 2 : 3;
+    auto compute = [&](int stage, int cnext) {
+        const char *sH = reinterpret_cast<const char *>(lds + stage * kStage) + patch0;
+        const char *sW = reinterpret_cast<const char *>(lds + stage * kStage) + frag0;
+        vec d[4][4], A[kAhead + 1][NCO], r[4];
+        auto rd_frag = [&](int g) {
+            const int p = ((g >> 2) == 0 ? 4 : (g >> 2) == 1 ? 8 : (g >> 2) == 2 ? 0 : 12) + (g & 3);
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+            for (int j = 0; j < NCO; ++j) A[g % (kAhead + 1)][j] = *reinterpret_cast<const vec *>(sW + (j * 16 + p) * 64 * (4 * KS));
+        };
+        auto rd_row = [&](int y) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) v[y][x] = sH[(2 * y + (x & 1)) * kWinoHalf + (x >> 1)];
-        // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] (rows, then columns), in place
+            for (int x = 0; x < 4; ++x) d[y][x] = *reinterpret_cast<const vec *>(sH + ((2 * y + (x & 1)) * kWinoHalf + (x >> 1)) * 16);
+        };
+        rd_frag(0);
+        rd_row(1);
+        rd_row(2);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const f32x4 d0 = v[0][x], d1 = v[1][x], d2 = v[2][x], d3 = v[3][x];
-            v[0][x] = d0 - d2; v[1][x] = d1 + d2; v[2][x] = d2 - d1; v[3][x] = d1 - d3;
-        }
+        for (int g = 1; g < kAhead; ++g) rd_frag(g);
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const f32x4 d0 = v[y][0], d1 = v[y][1], d2 = v[y][2], d3 = v[y][3];
-            v[y][0] = d0 - d2; v[y][1] = d1 + d2; v[y][2] = d2 - d1; v[y][3] = d1 - d3;
-        }
+        for (int g = 0; g < 16; ++g) {
+            const int xi = (g >> 2) == 0 ? 1 : (g >> 2) == 1 ? 2 : (g >> 2) == 2 ? 0 : 3, nu = g & 3;
+            const int p = 4 * xi + nu;
+            if (g + kAhead < 16) rd_frag(g + kAhead);
+            if (g == 1) rd_row(0);
+            if (g == 5) rd_row(3);
+            if (g < kTPW && cnext >= 0) issue_one(g, cnext, cnext & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (nu == 0) {  // B^T d: rows combined for this xi
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            f32x4 A[NCO];
+                for (int x = 0; x < 4; ++x)
+                    r[x] = xi == 0 ? d[0][x] - d[2][x] : xi == 1 ? d[1][x] + d[2][x] : xi == 2 ? d[2][x] - d[1][x] : d[1][x] - d[3][x];
+            }
+            const vec v = nu == 0 ? r[0] - r[2] : nu == 1 ? r[1] + r[2] : nu == 2 ? r[2] - r[1] : r[1] - r[3];
 #pragma unroll
-            for (int j = 0; j < NCO; ++j) A[j] = sW[(j * 16 + p) * 64];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < KS; ++k)
 #pragma unroll
                 for (int j = 0; j < NCO; ++j)
-                    acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][k], v[p >> 2][p & 3][k], acc[p][j], 0, 0, 0);
+                    acc[p][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g % (kAhead + 1)][j][k], v[k], acc[p][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- K loop: chunk c+1 lands in the other stage while chunk c is computed on; one barrier per chunk --------------
-    issue(0, 0);
+    // ---- K loop: step c+1 lands in the other stage while step c is computed on; one barrier per step ----------------
+#pragma unroll
+    for (int k = 0; k < kTPW; ++k) issue_one(k, 0, 0);
     __syncthreads();  // (the compiler drains vmcnt before the barrier: the DMA of every wave has landed)
 #pragma unroll 1
-    for (int c = 0; c < nC; ++c) {
-        if (c + 1 < nC) issue(c + 1, (c + 1) & 1);
-        compute(c & 1);
+    for (int c = 0; c < nS; ++c) {
+        compute(c & 1, c + 1 < nS ? c + 1 : -1);
         __syncthreads();
     }
 
@@ -246,13 +276,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv3x3_wino_k(const WinoArgs wa) 
     }
 }
 
-template <int WAVES, int NCO>
+template <int WAVES, int NCO, int CH>
 int launch_wino(const ConvArgs &a, int N, hipStream_t st) {
     WinoArgs wa{a, (a.Wo + kWinoTileW - 1) / kWinoTileW, (a.Ho + 2 * WAVES - 1) / (2 * WAVES)};
     wa.c.NT = a.Cout / (16 * NCO);
     const long long blocks = (long long)N * wa.tiles_x * wa.tiles_y * wa.c.NT;
     if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3x3_wino_k<WAVES, NCO>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, wa);
+    hipLaunchKernelGGL((conv3x3_wino_k<WAVES, NCO, CH>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, wa);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }
@@ -270,8 +300,9 @@ bool wino_supported(const ConvArgs &a) {
 
 int launch_conv_wino(const ConvArgs &a, int N, int rows, hipStream_t st) {
     if (!wino_supported(a)) return IDH_EUNSUPPORTED;
-    if (rows == 8) return launch_wino<4, 2>(a, N, st);
-    return launch_wino<8, 2>(a, N, st);
+    if (rows == 108) return launch_wino<4, 2, 8>(a, N, st);   // 8-row tiles, 8-channel K steps: 56 KiB of LDS -> 2 workgroups / CU
+    if (rows == 8) return launch_wino<4, 2, 16>(a, N, st);
+    return launch_wino<8, 2, 16>(a, N, st);
 }
 
 }  // namespace idh_conv
@@ -281,13 +312,13 @@ extern "C" size_t idh_packed_wino_weight_floats(int Cout, int Cin) {
     return (size_t)((Cin + 15) & ~15) * ((Cout + 15) & ~15) * 16;
 }
 
-extern "C" int idh_pack_conv_weight_wino(const float *w, float *dst, int Cout, int Cin, void *stream) {
-    if (!w || !dst || Cout <= 0 || Cin <= 0) return IDH_EINVAL;
+extern "C" int idh_pack_conv_weight_wino(const float *w, float *dst, int Cout, int Cin, int ch, void *stream) {
+    if (!w || !dst || Cout <= 0 || Cin <= 0 || (ch != 16 && ch != 8)) return IDH_EINVAL;
     const int nC = (Cin + 15) / 16, nCB = (Cout + 15) / 16;
     const long long total = (long long)nC * nCB * 4096;
     int grid = idh_cdiv(total, 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(pack_wino_weight_k, dim3(grid), dim3(256), 0, idh_stream(stream), w, dst, Cout, Cin, nC, nCB);
+    hipLaunchKernelGGL(pack_wino_weight_k, dim3(grid), dim3(256), 0, idh_stream(stream), w, dst, Cout, Cin, nC * (16 / ch), nCB, ch / 4);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }

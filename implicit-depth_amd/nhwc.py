@@ -148,11 +148,14 @@ def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
     return dst
 
 
+WINO_CH = 16  # input channels per K step of the Winograd kernel (the packed layout depends on it)
+
+
 def packed_wino_weight(conv: nn.Conv2d) -> torch.Tensor:
     """Winograd-domain copy U = G g G^T of a 3x3 Conv2d weight in the MFMA A-fragment order of csrc/conv_wino.hip
     (idh_pack_conv_weight_wino); cached like ``packed_weight``."""
     w = conv.weight
-    key = (w.data_ptr(), _lib.param_version(w), str(w.device))
+    key = (w.data_ptr(), _lib.param_version(w), str(w.device), WINO_CH)
     cached = getattr(conv, "_idh_packed_wino", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -163,7 +166,7 @@ def packed_wino_weight(conv: nn.Conv2d) -> torch.Tensor:
         raise _lib.IdhError("the Winograd F(2x2,3x3) kernel covers 3x3 convolutions only")
     dst = torch.empty(L.idh_packed_wino_weight_floats(co, ci), device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    _lib.check(L.idh_pack_conv_weight_wino(wc.data_ptr(), dst.data_ptr(), co, ci, _lib.stream_ptr()), "idh_pack_conv_weight_wino")
+    _lib.check(L.idh_pack_conv_weight_wino(wc.data_ptr(), dst.data_ptr(), co, ci, WINO_CH, _lib.stream_ptr()), "idh_pack_conv_weight_wino")
     conv._idh_packed_wino = (key, dst)
     return dst
 

@@ -127,7 +127,7 @@ int idh_pack_conv_weight_split(const float *w_oihw, const float *w_1x1, void *ds
  * kernel by fp32 rounding only (~1e-6 of the output scale). */
 #define IDH_TILE_WINO 12
 size_t idh_packed_wino_weight_floats(int Cout, int Cin);
-int idh_pack_conv_weight_wino(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);
+int idh_pack_conv_weight_wino(const float *w_oihw, float *dst, int Cout, int Cin, int ch, void *stream);
 
 /* sizeof(idh_op) as compiled into the library (bindings assert their mirror matches). */
 size_t idh_sizeof_op(void);

@@ -19,7 +19,7 @@ LAYERS = [(64, 64, 192, 256, 0), (64, 64, 192, 256, 1), (192, 64, 192, 256, 0), 
 sel = os.environ.get("LAYERS")
 if sel:
     LAYERS = [LAYERS[int(i)] for i in sel.split(",")]
-VARIANTS = [("direct8", 8, 0), ("wino16", nhwc.TILE_WINO, 16), ("wino8", nhwc.TILE_WINO, 8)]
+VARIANTS = [("direct8", 8, 0), ("wino16", nhwc.TILE_WINO, 16), ("wino8h", nhwc.TILE_WINO, 108)]
 
 
 def build(conv, x, res, tm, tn):
@@ -27,12 +27,14 @@ def build(conv, x, res, tm, tn):
     Bn, H, W, cin = x.shape
     out = p.buffer(Bn, H, W, conv.out_channels)
     nhwc.WINOGRAD = tm == nhwc.TILE_WINO
+    nhwc.WINO_CH = 8 if tn == 108 else 16
     old = nhwc.WINO_MIN_BLOCKS
     nhwc.WINO_MIN_BLOCKS = 1
     try:
         p.conv(nhwc.View(x, 0, cin), conv, out, act=1, slope=0.2, res=None if res is None else nhwc.View(res, 0, conv.out_channels))
     finally:
         nhwc.WINOGRAD = False
+        nhwc.WINO_CH = 16
         nhwc.WINO_MIN_BLOCKS = old
     op = p.ops[0]
     if tm != nhwc.TILE_WINO:
