@@ -43,6 +43,21 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     return v;
 }
 
+// Epilogue activation with the (runtime, wave-uniform) selector tested ONCE: `body(fn)` is instantiated per activation
+// with a straight-line element function.  Calling act_apply per element instead leaves ~3 scalar branches around an inlined
+// expm1f for every output value — measured on the Winograd kernel: ~10k cycles of a 50k-cycle tile went to that.
+template <typename Body>
+__device__ __forceinline__ void act_dispatch(int act, float slope, Body &&body) {
+    if (act == IDH_ACT_LRELU) {
+        if (slope >= 0.f && slope <= 1.f) body([slope](float v) { return fmaxf(v, v * slope); });
+        else body([slope](float v) { return v < 0.f ? v * slope : v; });
+    } else if (act == IDH_ACT_ELU) {
+        body([](float v) { return v > 0.f ? v : expm1f(v); });
+    } else {
+        body([](float v) { return v; });
+    }
+}
+
 constexpr int kZeroFloats = 4096;
 
 // conv_split.hip

@@ -75,9 +75,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, f32x4 *dst, int
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)dst, 16, voff, soff, 0, 0);
 }
 
+// Developer build (-DIDH_ABL_WINO_TRACE, tools/trace_wino.sh): every wave logs s_memtime at its phase boundaries into
+// ConvArgs.ws (64 x 8 bytes per wave: [0] entry, [1] first DMA issued, [2] first barrier passed, [3+2c] K step c computed,
+// [4+2c] its barrier passed, [62] before the epilogue stores retire, [63] HW_ID).  Not part of the product library.
+#ifdef IDH_ABL_WINO_TRACE
+#define WINO_TRACE(idx) do { if (lane == 0) trace[(idx)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WINO_TRACE(idx) do { } while (0)
+#endif
+
 struct WinoArgs {
     ConvArgs c;
     int tiles_x, tiles_y;
+    int tiles;  // N * tiles_y * tiles_x * NT
 };
 
 template <int WAVES, int NCO, int CH>
@@ -99,7 +109,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     static_assert(kPanelPieces % WAVES == 0, "panel pieces must split evenly over the waves");
     constexpr int kPanel = kPanelPieces / WAVES;
     constexpr int kTPW = NP * kFull + kExtra + kPanel;  // DMA pieces per wave and K step
-    static_assert(kTPW <= 16, "one DMA piece per position group");
+    static_assert(CH == 8, "K steps of 8 channels: every tile has >= 2 steps (the first stores the previous tile's outputs, the last loads the residual)");
+    static_assert(kTPW <= 8 && 4 * NCO <= 8, "one DMA piece per even position group, one output store per odd group");
     constexpr int kHalo = NP * kQS;
     constexpr int kStage = kHalo + 64 * kPanelPieces;   // float4 slots per stage
     __shared__ f32x4 lds[2 * kStage];
@@ -109,21 +120,46 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, h = lane >> 4;
-
-    unsigned blk = idh_xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = blk % a.NT; blk /= a.NT;
-    const int tx = blk % wa.tiles_x; blk /= wa.tiles_x;
-    const int ty = blk % wa.tiles_y;
-    const int img = blk / wa.tiles_y;
-    const int y0 = ty * kRows, x0 = tx * kWinoTileW;
-    const int cb0 = nt * NCO;       // first 16-channel output block of this workgroup
-    const int n0 = 16 * cb0;
-    const int nS = s.cblocks * (16 / CH);  // K steps
+#ifdef IDH_ABL_WINO_TRACE
+    unsigned long long *trace = reinterpret_cast<unsigned long long *>(a.ws) + ((size_t)blockIdx.x * WAVES + wave) * 64;
+    int tr_i = 1;
+    WINO_TRACE(0);
+    if (lane == 0) trace[63] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+#endif
+    const int nS = s.cblocks * (16 / CH);  // K steps per tile
     const int nCB = a.Cout_pad / 16;
-
-    // ---- LDS-DMA descriptors: this wave's kTPW pieces of every K step ---------------------------------------------
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, s.cblocks * nCB * 16384, 0x00020000);
+
+    // ---- persistent workgroup: tiles t0, t0 + stride, ... < t_end.  The hardware places block b on XCD b % 8; every XCD
+    // gets one contiguous range of tiles and its resident workgroups walk it side by side, so the workgroups that
+    // share an input tile (the NT channel tiles, neighbouring halos) hit the same L2 at about the same time.
+    const int T = wa.tiles;
+    int t_cur, t_end, t_stride;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7;
+        t_stride = gridDim.x >> 3;
+        t_cur = (int)((long long)T * xcd / 8) + (int)(blockIdx.x >> 3);
+        t_end = (int)((long long)T * (xcd + 1) / 8);
+    } else {
+        t_cur = blockIdx.x; t_end = T; t_stride = gridDim.x;
+    }
+    if (t_cur >= t_end) return;
+
+    // tile -> (image, tile row, tile column, channel tile); channel tile fastest
+    int y0, x0, cb0, img;
+    auto decode = [&](int t) {
+        unsigned blk = (unsigned)t;
+        const int nt = blk % a.NT; blk /= a.NT;
+        const int tx = blk % wa.tiles_x; blk /= wa.tiles_x;
+        const int ty = blk % wa.tiles_y;
+        img = blk / wa.tiles_y;
+        y0 = ty * kRows; x0 = tx * kWinoTileW; cb0 = nt * NCO;
+    };
+    // ---- LDS-DMA descriptors of the tile whose K steps are being fetched --------------------------------------------
+    __amdgpu_buffer_rsrc_t rsA;
+    int voffF[kFull > 0 ? kFull : 1], voffX = 0, panel_so;
+    const int jx = kFull * WAVES + (wave * kExtra) / NP, qx = (wave * kExtra) % NP;  // this wave's share of the remaining j's
+    const int voffP = 16 * lane;
     auto halo_voff = [&](int j) {  // byte offset of this lane's texel in piece j of a plane: slot L of [row][17]
         const int L = 64 * j + lane;
         const int row = L / kWinoHalf, hxh = L - row * kWinoHalf;
@@ -131,13 +167,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         const bool ok = (L < kPlane) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
         return ok ? (iy * s.W + ix) * s.cs * 4 : kOob;  // out of the descriptor's range = zero padding
     };
-    int voffF[kFull > 0 ? kFull : 1];
+    auto set_fetch_tile = [&]() {  // from (y0, x0, cb0, img)
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
 #pragma unroll
-    for (int f = 0; f < kFull; ++f) voffF[f] = halo_voff(f * WAVES + wave);
-    const int jx = kFull * WAVES + (wave * kExtra) / NP, qx = (wave * kExtra) % NP;  // this wave's share of the remaining j's
-    const int voffX = kExtra ? halo_voff(jx) : 0;
-    const int voffP = 16 * lane;
-    // k-th DMA piece of this wave for K step c into `stage`; wave-uniform operands forced into SGPRs
+        for (int f = 0; f < kFull; ++f) voffF[f] = halo_voff(f * WAVES + wave);
+        if (kExtra) voffX = halo_voff(jx);
+        panel_so = (cb0 * (4 * KS) + wave * kPanel) * 1024;
+    };
+    // k-th DMA piece of this wave for K step c of the fetch tile into `stage`; wave-uniform operands forced into SGPRs
     auto issue_one = [&](int k, int c, int stage) {
         int so, lo, vo;
         bool halo = true;
@@ -148,18 +185,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
             const int q = qx + (k - NP * kFull);
             vo = voffX; so = 16 * q + 4 * CH * c; lo = q * kQS + 64 * jx;
         } else {
-            const int i = wave * kPanel + (k - NP * kFull - kExtra);
+            const int i = k - NP * kFull - kExtra;
             halo = false;
-            vo = voffP; so = ((c * nCB + cb0) * (4 * KS) + i) * 1024; lo = kHalo + 64 * i;
+            vo = voffP; so = panel_so + (c * nCB * (4 * KS) + i) * 1024; lo = kHalo + 64 * (wave * kPanel + i);
         }
+#ifdef IDH_ABL_WINO_NOHALO
+        if (halo && c + stage > 0) return;
+#endif
+#ifdef IDH_ABL_WINO_NOPANEL
+        if (!halo && c + stage > 0) return;
+#endif
         dma16(halo ? rsA : rsW, lds + __builtin_amdgcn_readfirstlane(stage * kStage + lo), vo, __builtin_amdgcn_readfirstlane(so));
     };
 
     f32x4 acc[16][NCO];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int j = 0; j < NCO; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // finished outputs of the previous tile, stored one 16-byte vector at a time under the next tile's first K step (a burst
+    // of 8 stores per wave at the end of a tile stalls the wave ~3k cycles on the store path)
+    f32x4 ost[2][2][NCO];  // ... and, under a tile's LAST K step, its residual tile (nS >= 2: never the step that stores)
+    int voffS[2][2];
+    __amdgpu_buffer_rsrc_t rsS;
+    bool pending = false;
 
     // this lane's KS channels of a texel: plane (KS h) / 4, byte (KS h % 4) * 4 of the 16-byte slot; patch origin = rows
     // 4*wave .. of the plane (hy = 2*wave + y, column parity x & 1), column n + (x >> 1)
@@ -172,18 +217,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     // the ~100-cycle issue cost of an LDS-DMA instruction opens a gap in the matrix pipe; sched_barrier keeps the compiler
     // from sinking the reads back to their uses.
     constexpr int kAhead = CH == 16 ? 2 : 3;
-    auto compute = [&](int stage, int cnext) {
-        const char *sH = reinterpret_cast<const char *>(lds + stage * kStage) + patch0;
-        const char *sW = reinterpret_cast<const char *>(lds + stage * kStage) + frag0;
+    auto compute = [&](int stage, int cnext, int snext, bool flush) {
+        // volatile LDS pointers: hipcc otherwise pairs the 8-byte reads into ds_read2_b64 (half rate, 2-way bank conflicts)
+        typedef const __attribute__((address_space(3))) volatile char lds_cchar;
+        typedef const __attribute__((address_space(3))) volatile vec lds_cvec;
+        lds_cchar *sH = (lds_cchar *)(lds + stage * kStage) + patch0;
+        lds_cchar *sW = (lds_cchar *)(lds + stage * kStage) + frag0;
         vec d[4][4], A[kAhead + 1][NCO], r[4];
         auto rd_frag = [&](int g) {
             const int p = ((g >> 2) == 0 ? 4 : (g >> 2) == 1 ? 8 : (g >> 2) == 2 ? 0 : 12) + (g & 3);
 #pragma unroll
-            for (int j = 0; j < NCO; ++j) A[g % (kAhead + 1)][j] = *reinterpret_cast<const vec *>(sW + (j * 16 + p) * 64 * (4 * KS));
+            for (int j = 0; j < NCO; ++j) A[g % (kAhead + 1)][j] = *(lds_cvec *)(sW + (j * 16 + p) * 64 * (4 * KS));
         };
         auto rd_row = [&](int y) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) d[y][x] = *reinterpret_cast<const vec *>(sH + ((2 * y + (x & 1)) * kWinoHalf + (x >> 1)) * 16);
+            for (int x = 0; x < 4; ++x) d[y][x] = *(lds_cvec *)(sH + ((2 * y + (x & 1)) * kWinoHalf + (x >> 1)) * 16);
         };
         rd_frag(0);
         rd_row(1);
@@ -197,14 +245,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
             if (g + kAhead < 16) rd_frag(g + kAhead);
             if (g == 1) rd_row(0);
             if (g == 5) rd_row(3);
-            if (g < kTPW && cnext >= 0) issue_one(g, cnext, cnext & 1);
+#ifndef IDH_ABL_WINO_NODMA
+            if ((g & 1) == 0 && (g >> 1) < kTPW && cnext >= 0) issue_one(g >> 1, cnext, snext);  // even groups: one DMA piece
+#endif
+#ifndef IDH_ABL_WINO_NOSTORE
+            if ((g & 1) == 1 && (g >> 1) < 4 * NCO && flush) {  // odd groups: one 16-byte store of the previous tile's outputs
+                const int k = g >> 1;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ost[k >> 1 & 1][k & 1][k >> 2]), rsS, voffS[k >> 1 & 1][k & 1] + 64 * (k >> 2), 0, 0);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#ifndef IDH_ABL_WINO_NOXFORM
             if (nu == 0) {  // B^T d: rows combined for this xi
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
                     r[x] = xi == 0 ? d[0][x] - d[2][x] : xi == 1 ? d[1][x] + d[2][x] : xi == 2 ? d[2][x] - d[1][x] : d[1][x] - d[3][x];
             }
+#endif
+#ifdef IDH_ABL_WINO_NOXFORM
+            const vec v = d[xi][nu];
+#else
             const vec v = nu == 0 ? r[0] - r[2] : nu == 1 ? r[1] + r[2] : nu == 2 ? r[2] - r[1] : r[1] - r[3];
+#endif
 #pragma unroll
             for (int k = 0; k < KS; ++k)
 #pragma unroll
@@ -214,75 +276,136 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         }
     };
 
-    // ---- K loop: step c+1 lands in the other stage while step c is computed on; one barrier per step ----------------
+    // ---- first tile: fetch K step 0 -----------------------------------------------------------------------------------
+    decode(t_cur);
+    set_fetch_tile();
 #pragma unroll
     for (int k = 0; k < kTPW; ++k) issue_one(k, 0, 0);
+    WINO_TRACE(tr_i++);
     __syncthreads();  // (the compiler drains vmcnt before the barrier: the DMA of every wave has landed)
-#pragma unroll 1
-    for (int c = 0; c < nS; ++c) {
-        compute(c & 1, c + 1 < nS ? c + 1 : -1);
-        __syncthreads();
-    }
+    WINO_TRACE(tr_i++);
 
-    // ---- epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; lane = 4 consecutive channels of the 2x2 pixels of tile n
-    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * a.Ho * a.Wo * a.out_cs, 0, a.Ho * a.Wo * a.out_cs * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)img * a.Ho * a.Wo * a.res_cs : a.out), 0,
-                                                                          a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
-    int voffO[2][2], voffR[2][2];
+    int it = 0;  // K steps done by this workgroup: step `it` is computed from stage it & 1
+#pragma unroll 1
+    for (;;) {
+        const int t_next = t_cur + t_stride;
+        const bool has_next = t_next < t_end;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int p = 0; p < 16; ++p)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int oy = y0 + 2 * wave + i, ox = x0 + 2 * n + j;
-            const bool ok = (oy < a.Ho) & (ox < a.Wo);
-            const int pixel = oy * a.Wo + ox;
-            voffO[i][j] = ok ? (pixel * a.out_cs + n0 + 4 * h) * 4 : kOob;
-            voffR[i][j] = ok ? (pixel * a.res_cs + n0 + 4 * h) * 4 : kOob;
+            for (int j = 0; j < NCO; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // epilogue operands of this tile, requested under its last K step: output / residual offsets (out-of-image pixels
+        // are out of the descriptors' range: loads read 0, stores are dropped), bias, residual tile
+        const int n0 = 16 * cb0;
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * a.Ho * a.Wo * a.out_cs, 0, a.Ho * a.Wo * a.out_cs * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)img * a.Ho * a.Wo * a.res_cs : a.out), 0,
+                                                                              a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+        int voffO[2][2];
+        f32x4 b4[NCO];
+
+#pragma unroll 1
+        for (int c = 0; c < nS; ++c) {
+            const bool last = c + 1 == nS;
+            if (last) {
+                int voffR[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int oy = y0 + 2 * wave + i, ox = x0 + 2 * n + j;
+                        const bool ok = (oy < a.Ho) & (ox < a.Wo);
+                        const int pixel = oy * a.Wo + ox;
+                        voffO[i][j] = ok ? (pixel * a.out_cs + n0 + 4 * h) * 4 : kOob;
+                        voffR[i][j] = ok ? (pixel * a.res_cs + n0 + 4 * h) * 4 : kOob;
+                    }
+#pragma unroll
+                for (int cb = 0; cb < NCO; ++cb) {
+                    b4[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 16 * cb + 4 * h) * 4, 0, 0));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) ost[i][j][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voffR[i][j] + 64 * cb, 0, 0));
+                }
+                if (has_next) {  // from here on the DMA descriptors belong to the next tile: its K step 0 lands under this step
+                    decode(t_next);
+                    set_fetch_tile();
+                }
+            }
+            compute(it & 1, last ? (has_next ? 0 : -1) : c + 1, (it + 1) & 1, pending);
+            pending = false;
+            ++it;
+            WINO_TRACE(tr_i < 61 ? tr_i++ : 61);
+            __syncthreads();
+            WINO_TRACE(tr_i < 61 ? tr_i++ : 61);
         }
-    f32x4 rv[2][2][NCO];
-    if (a.res) {
+
+        // ---- epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; lane = 4 consecutive channels of the 2x2 pixels of tile n
+        act_dispatch(a.act, a.slope, [&](auto fn) {
+#pragma unroll
+            for (int cb = 0; cb < NCO; ++cb) {
+                f32x4 t[2][4];
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) {
+                    t[0][nu] = acc[0 + nu][cb] + acc[4 + nu][cb] + acc[8 + nu][cb];
+                    t[1][nu] = acc[4 + nu][cb] - acc[8 + nu][cb] - acc[12 + nu][cb];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 y[2];
+                    y[0] = t[i][0] + t[i][1] + t[i][2];
+                    y[1] = t[i][1] - t[i][2] - t[i][3];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 o = y[j] + b4[cb] + ost[i][j][cb];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = fn(o[r]);
+#ifdef IDH_ABL_WINO_NOSTORE
+                        asm volatile("" ::"v"(o));
+#endif
+                        ost[i][j][cb] = o;
+                    }
+                }
+            }
+        });
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int cb = 0; cb < NCO; ++cb) rv[i][j][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voffR[i][j] + 64 * cb, 0, 0));
+            for (int j = 0; j < 2; ++j) voffS[i][j] = voffO[i][j];
+        rsS = rsO;
+        pending = true;
+        WINO_TRACE(tr_i < 61 ? tr_i++ : 61);
+        if (!has_next) break;
+        t_cur = t_next;
     }
+#ifndef IDH_ABL_WINO_NOSTORE
 #pragma unroll
-    for (int cb = 0; cb < NCO; ++cb) {
-        const f32x4 b4 = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + n0 + 16 * cb + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 t[2][4];
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            t[0][nu] = acc[0 + nu][cb] + acc[4 + nu][cb] + acc[8 + nu][cb];
-            t[1][nu] = acc[4 + nu][cb] - acc[8 + nu][cb] - acc[12 + nu][cb];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4 y[2];
-            y[0] = t[i][0] + t[i][1] + t[i][2];
-            y[1] = t[i][1] - t[i][2] - t[i][3];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x4 o = y[j] + b4;
-                if (a.res) o += rv[i][j][cb];
-                if (a.act != IDH_ACT_NONE) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], a.act, a.slope);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, voffO[i][j] + 64 * cb, 0, 0);
-            }
-        }
-    }
+    for (int k = 0; k < 4 * NCO; ++k)  // the last tile's outputs
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ost[k >> 1 & 1][k & 1][k >> 2]), rsS, voffS[k >> 1 & 1][k & 1] + 64 * (k >> 2), 0, 0);
+#endif
+    WINO_TRACE(62);
 }
 
 template <int WAVES, int NCO, int CH>
 int launch_wino(const ConvArgs &a, int N, hipStream_t st) {
-    WinoArgs wa{a, (a.Wo + kWinoTileW - 1) / kWinoTileW, (a.Ho + 2 * WAVES - 1) / (2 * WAVES)};
+    WinoArgs wa{a, (a.Wo + kWinoTileW - 1) / kWinoTileW, (a.Ho + 2 * WAVES - 1) / (2 * WAVES), 0};
     wa.c.NT = a.Cout / (16 * NCO);
-    const long long blocks = (long long)N * wa.tiles_x * wa.tiles_y * wa.c.NT;
-    if (blocks >= (1ll << 31)) return IDH_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3x3_wino_k<WAVES, NCO, CH>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, st, wa);
+    const long long tiles = (long long)N * wa.tiles_x * wa.tiles_y * wa.c.NT;
+    if (tiles >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    wa.tiles = (int)tiles;
+    // persistent grid: as many workgroups as the chip holds at once (LDS-limited), a multiple of the 8 XCDs
+    static int resident = 0;
+    if (resident == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident = cus > 0 ? cus : 256;
+    }
+    constexpr int kLdsBytes = 2 * (CH / 4 * wino_qs(WAVES) + 64 * NCO * CH) * 16;
+    const int per_cu = kLdsBytes * 2 <= 160 * 1024 ? 2 : 1;
+    long long grid = (long long)resident * per_cu;
+    if (grid > tiles) grid = tiles >= 8 ? tiles / 8 * 8 : tiles;
+    hipLaunchKernelGGL((conv3x3_wino_k<WAVES, NCO, CH>), dim3((unsigned)grid), dim3(64 * WAVES), 0, st, wa);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }
@@ -300,9 +423,8 @@ bool wino_supported(const ConvArgs &a) {
 
 int launch_conv_wino(const ConvArgs &a, int N, int rows, hipStream_t st) {
     if (!wino_supported(a)) return IDH_EUNSUPPORTED;
-    if (rows == 108) return launch_wino<4, 2, 8>(a, N, st);   // 8-row tiles, 8-channel K steps: 56 KiB of LDS -> 2 workgroups / CU
-    if (rows == 8) return launch_wino<4, 2, 16>(a, N, st);
-    return launch_wino<8, 2, 16>(a, N, st);
+    (void)rows;
+    return launch_wino<4, 2, 8>(a, N, st);   // 8-row tiles, 8-channel K steps: 56 KiB of LDS -> 2 workgroups / CU
 }
 
 }  // namespace idh_conv

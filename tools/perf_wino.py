@@ -19,7 +19,7 @@ LAYERS = [(64, 64, 192, 256, 0), (64, 64, 192, 256, 1), (192, 64, 192, 256, 0), 
 sel = os.environ.get("LAYERS")
 if sel:
     LAYERS = [LAYERS[int(i)] for i in sel.split(",")]
-VARIANTS = [("direct8", 8, 0), ("wino16", nhwc.TILE_WINO, 16), ("wino8h", nhwc.TILE_WINO, 108)]
+VARIANTS = [("direct8", 8, 0), ("wino", nhwc.TILE_WINO, 108)]
 
 
 def build(conv, x, res, tm, tn):
