@@ -1199,10 +1199,10 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
                           (long long)op.Ho * op.Wo * op.out_cs * 4 < (1ll << 31) && (!op.res || (long long)op.Ho * op.Wo * op.res_cs * 4 < (1ll << 31));
     if (op.tile_m == IDH_TILE_WINO) {
         // Winograd F(2x2,3x3) kernel (conv_wino.hip): src[0].w holds idh_pack_conv_weight_wino output
-        if (!wino_supported(a) || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16 && op.tile_n != 108)) return IDH_EUNSUPPORTED;
+        if (!wino_supported(a)) return IDH_EUNSUPPORTED;
         pc.lds_rows = 32;
         pc.tm = op.tile_m;
-        pc.tn = op.tile_n == 0 ? 16 : op.tile_n;  // tile rows (108: 8 rows, 8-channel K steps)
+        pc.tn = 0;
         pc.n_img = op.N;
         pc.blocks = 0;
     } else if (op.tile_m == IDH_SPLIT_F16X3) {

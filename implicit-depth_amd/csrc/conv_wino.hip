@@ -36,6 +36,7 @@ namespace {
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+constexpr int kWinoCH = 8;      // input channels per K step (the packed weight layout depends on it)
 constexpr int kWinoTileW = 32;   // output pixels per workgroup row = 16 Winograd tiles
 constexpr int kWinoHalf = 17;    // halo columns of one parity
 constexpr int kOob = 0x7fffffff;
@@ -424,7 +425,7 @@ bool wino_supported(const ConvArgs &a) {
 int launch_conv_wino(const ConvArgs &a, int N, int rows, hipStream_t st) {
     if (!wino_supported(a)) return IDH_EUNSUPPORTED;
     (void)rows;
-    return launch_wino<4, 2, 8>(a, N, st);   // 8-row tiles, 8-channel K steps: 56 KiB of LDS -> 2 workgroups / CU
+    return launch_wino<4, 2, kWinoCH>(a, N, st);   // 8-row tiles, 8-channel K steps: 56 KiB of LDS -> 2 workgroups / CU
 }
 
 }  // namespace idh_conv
@@ -434,8 +435,9 @@ extern "C" size_t idh_packed_wino_weight_floats(int Cout, int Cin) {
     return (size_t)((Cin + 15) & ~15) * ((Cout + 15) & ~15) * 16;
 }
 
-extern "C" int idh_pack_conv_weight_wino(const float *w, float *dst, int Cout, int Cin, int ch, void *stream) {
-    if (!w || !dst || Cout <= 0 || Cin <= 0 || (ch != 16 && ch != 8)) return IDH_EINVAL;
+extern "C" int idh_pack_conv_weight_wino(const float *w, float *dst, int Cout, int Cin, void *stream) {
+    constexpr int ch = kWinoCH;
+    if (!w || !dst || Cout <= 0 || Cin <= 0) return IDH_EINVAL;
     const int nC = (Cin + 15) / 16, nCB = (Cout + 15) / 16;
     const long long total = (long long)nC * nCB * 4096;
     int grid = idh_cdiv(total, 256);

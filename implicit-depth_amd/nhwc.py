@@ -148,14 +148,11 @@ def packed_weight(conv: nn.Conv2d) -> torch.Tensor:
     return dst
 
 
-WINO_CH = 16  # input channels per K step of the Winograd kernel (the packed layout depends on it)
-
-
 def packed_wino_weight(conv: nn.Conv2d) -> torch.Tensor:
     """Winograd-domain copy U = G g G^T of a 3x3 Conv2d weight in the MFMA A-fragment order of csrc/conv_wino.hip
     (idh_pack_conv_weight_wino); cached like ``packed_weight``."""
     w = conv.weight
-    key = (w.data_ptr(), _lib.param_version(w), str(w.device), WINO_CH)
+    key = (w.data_ptr(), _lib.param_version(w), str(w.device))
     cached = getattr(conv, "_idh_packed_wino", None)
     if cached is not None and cached[0] == key:
         return cached[1]
@@ -166,26 +163,29 @@ def packed_wino_weight(conv: nn.Conv2d) -> torch.Tensor:
         raise _lib.IdhError("the Winograd F(2x2,3x3) kernel covers 3x3 convolutions only")
     dst = torch.empty(L.idh_packed_wino_weight_floats(co, ci), device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    _lib.check(L.idh_pack_conv_weight_wino(wc.data_ptr(), dst.data_ptr(), co, ci, WINO_CH, _lib.stream_ptr()), "idh_pack_conv_weight_wino")
+    _lib.check(L.idh_pack_conv_weight_wino(wc.data_ptr(), dst.data_ptr(), co, ci, _lib.stream_ptr()), "idh_pack_conv_weight_wino")
     conv._idh_packed_wino = (key, dst)
     return dst
 
 
 TILE_WINO = 12  # IDH_TILE_WINO of include/idh_ops.h == the op's tile_m
 # Winograd F(2x2,3x3) for the eligible 3x3 stride-1 layers of fp32 plans (csrc/conv_wino.hip): fp32 operands and
-# accumulation, 2.25x fewer MFMAs.  WINO_MIN_BLOCKS: below this many (32 x 16 pixel x 32 channel) workgroups the direct
-# kernels' finer tiles fill the chip better.
-WINOGRAD = False
-WINO_MIN_BLOCKS = 512
+# accumulation, 2.25x fewer MFMAs; measured 1.67-1.84x over the direct LDS kernel at B=32 (tools/perf_wino.py).
+# Tiles are 32 x 8 pixels x 32 channels; WINO_MIN_TILES: below this many tiles the direct kernels' finer tiles fill the
+# chip better; WINO_MIN_FILL: smallest useful fraction of the tile grid that lies inside the map.
+WINOGRAD = True
+WINO_MIN_TILES = 512
+WINO_MIN_FILL = 0.74
 
 
 def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> bool:
     (v0, c0) = srcs[0]
     if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 32 or isinstance(v0, CatView) or len(srcs) > 1:
         return False
-    if Wo < 32 or Ho < 16:
+    ty, tx = -(-Ho // 8), -(-Wo // 32)
+    if Ho * Wo < WINO_MIN_FILL * (ty * 8) * (tx * 32):
         return False
-    return N * (-(-Ho // 16)) * (-(-Wo // 32)) * (cout // 32) >= WINO_MIN_BLOCKS
+    return N * ty * tx * (cout // 32) >= WINO_MIN_TILES
 
 
 SPLIT_CODE = {"f16x3": 11}  # IDH_SPLIT_F16X3 of include/idh_ops.h == the op's tile_m
@@ -422,7 +422,7 @@ class Plan:
         if use_split:
             tm, tn, split = SPLIT_CODE[self.math], choose_split_rows(out.N, out.H, out.W, conv.out_channels), 1
         elif use_wino:
-            tm, tn, split = TILE_WINO, 16, 1
+            tm, tn, split = TILE_WINO, 0, 1
         elif lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
             chunks = sum(ceil16(v.C) // 16 for v, _ in srcs)
             tm, split = choose_lds_tile(out.N, out.H, out.W, conv.out_channels, chunks)

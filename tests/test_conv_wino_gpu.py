@@ -1,0 +1,136 @@
+"""Winograd F(2x2,3x3) conv kernel (csrc/conv_wino.hip) vs an fp64 torch reference, vs the direct kernel, and through the
+network goldens with the kernel forced onto every eligible layer.  Replaces the same nn.Conv2d calls as the direct kernel
+(reference modules/layers.py:59-95); fp32 operands and accumulation, so the bar stays the 1e-4 scale-relative tolerance of
+BASELINE.json — observed ~4e-7."""
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+import implicit_depth_amd.synthetic as syn
+from conftest import TOL, load_golden, rel_err
+from oracle import networks as onet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def wino_everywhere():
+    """Force the Winograd kernel onto every eligible layer regardless of grid size / tile fill."""
+    from implicit_depth_amd import nhwc
+
+    old = (nhwc.WINOGRAD, nhwc.WINO_MIN_TILES, nhwc.WINO_MIN_FILL)
+    nhwc.WINOGRAD, nhwc.WINO_MIN_TILES, nhwc.WINO_MIN_FILL = True, 1, 0.0
+    yield nhwc
+    nhwc.WINOGRAD, nhwc.WINO_MIN_TILES, nhwc.WINO_MIN_FILL = old
+
+
+def _run(nhwc, conv, x_nhwc, res, act, slope, wino, out_view=None):
+    old = nhwc.WINOGRAD
+    nhwc.WINOGRAD = wino
+    try:
+        p = nhwc.Plan(x_nhwc.device)
+        B, H, W, cs = x_nhwc.shape
+        out = p.buffer(B, H, W, conv.out_channels) if out_view is None else out_view
+        p.conv(nhwc.View(x_nhwc, 0, conv.in_channels), conv, out, act=act, slope=slope, res=res)
+    finally:
+        nhwc.WINOGRAD = old
+    assert (p.ops[0].tile_m == nhwc.TILE_WINO) == wino
+    p.run()
+    torch.cuda.synchronize()
+    return out.dense().clone()
+
+
+# (B, cin, cout, H, W, residual, act): ragged maps (partial tiles in both directions, odd sizes), channel counts that need
+# zero-padded input buffers (24, 112), wide outputs (NT = 3, 8), every activation, one map narrower than a tile
+@pytest.mark.parametrize("shape", [(2, 64, 64, 40, 64, True, 1), (1, 24, 64, 37, 45, False, 1), (3, 112, 96, 9, 33, True, 2), (1, 192, 64, 64, 96, False, 0),
+                                   (2, 128, 256, 24, 32, True, 1), (1, 16, 32, 8, 32, False, 1), (1, 64, 32, 5, 17, True, 1), (5, 32, 64, 16, 70, False, 1)])
+def test_wino_conv_vs_fp64_and_direct(shape, wino_everywhere):
+    nhwc = wino_everywhere
+    B, cin, cout, H, W, use_res, act = shape
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
+    syn.fill_state_dict(conv, seed=cin + cout + H)
+    g = torch.Generator(device="cuda").manual_seed(H * W)
+    xb = torch.zeros(B, H, W, nhwc.ceil16(cin), device="cuda")
+    xb[..., :cin] = torch.randn(B, H, W, cin, device="cuda", generator=g)
+    rb = torch.randn(B, H, W, cout, device="cuda", generator=g) if use_res else None
+    res = nhwc.View(rb, 0, cout) if use_res else None
+    ref = F.conv2d(xb[..., :cin].permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1)
+    if use_res:
+        ref = ref + rb.permute(0, 3, 1, 2).double()
+    ref = (F.leaky_relu(ref, 0.2) if act == 1 else F.elu(ref) if act == 2 else ref).permute(0, 2, 3, 1)
+    yw = _run(nhwc, conv, xb, res, act, 0.2, True)
+    yd = _run(nhwc, conv, xb, res, act, 0.2, False)
+    assert rel_err(yw.cpu(), ref.cpu()) < 1e-5, "Winograd kernel vs fp64"
+    assert rel_err(yw.cpu(), yd.cpu()) < 1e-5, "Winograd kernel vs direct kernel"
+
+
+def test_wino_conv_channel_strided_views(wino_everywhere):
+    """input = channel slice of a wider concat buffer, output = slice of another, residual strided too (torch.cat elimination)"""
+    nhwc = wino_everywhere
+    B, H, W, cin, cout = 2, 24, 64, 64, 64
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
+    syn.fill_state_dict(conv, seed=5)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    big = torch.randn(B, H, W, 192, device="cuda", generator=g)
+    rbig = torch.randn(B, H, W, 128, device="cuda", generator=g)
+    obig = torch.full((B, H, W, 192), 7.0, device="cuda")
+    p = nhwc.Plan(big.device)
+    out = nhwc.View(obig, 64, cout)
+    p.conv(nhwc.View(big, 128, cin), conv, out, act=1, slope=0.2, res=nhwc.View(rbig, 64, cout))
+    assert p.ops[0].tile_m == nhwc.TILE_WINO
+    p.run()
+    ref = F.conv2d(big[..., 128:192].permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1) + rbig[..., 64:128].permute(0, 3, 1, 2).double()
+    ref = F.leaky_relu(ref, 0.2).permute(0, 2, 3, 1)
+    assert rel_err(obig[..., 64:128].cpu(), ref.cpu()) < 1e-5
+    assert torch.all(obig[..., :64] == 7.0) and torch.all(obig[..., 128:] == 7.0), "neighbouring channel slices must stay untouched"
+
+
+def test_wino_weight_update_invalidates_packed_cache(wino_everywhere):
+    nhwc = wino_everywhere
+    conv = nn.Conv2d(32, 32, 3, 1, 1).cuda()
+    syn.fill_state_dict(conv, seed=1)
+    x = torch.randn(1, 16, 32, 32, device="cuda")
+    y0 = _run(nhwc, conv, x, None, 0, 0.2, True)
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+    y1 = _run(nhwc, conv, x, None, 0, 0.2, True)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(y1.cpu(), ref.cpu()) < 1e-5 and not torch.equal(y0, y1)
+
+
+def test_networks_with_wino_forced_match_goldens(wino_everywhere):
+    """CVEncoder + BDDecoderPP goldens (reference outputs) with every eligible layer on the Winograd kernel"""
+    from implicit_depth_amd import networks as net
+
+    Hm, Wm, Dcv = 24, 32, 16
+    pyr = syn.encoder_pyramid(1, Hm * 4, Wm * 4, seed=11)
+    cvol = syn.randn((1, Dcv, Hm, Wm), 11, "cv_in")
+    cve = net.CVEncoder(num_ch_cv=Dcv, num_ch_enc=[48, 64, 160, 256], num_ch_outs=[64, 128, 256, 384])
+    syn.fill_state_dict(cve, seed=12)
+    g = load_golden("g3_cvencoder")
+    outs = cve.cuda()(cvol.cuda(), [p.cuda() for p in pyr[1:]])
+    plan = next(iter(cve.__dict__["_idh_plans"].values()))[0]
+    assert any(op.kind == 1 and op.tile_m == wino_everywhere.TILE_WINO for op in plan.ops), "no layer took the Winograd kernel"
+    for i, o in enumerate(outs):
+        assert rel_err(o.cpu(), g[f"o{i}"]) < TOL
+    dec = net.BDDecoderPP([24, 64, 128, 256, 384])
+    syn.fill_state_dict(dec, seed=13)
+    gd = load_golden("g3_bddecoder")
+    dec_in = [pyr[0]] + [torch.as_tensor(g[f"o{i}"]) for i in range(4)]
+    out = dec.cuda()([t.cuda() for t in dec_in])
+    for i in range(4):
+        assert rel_err(out[f"feature_s{i}_b1hw"].cpu(), gd[f"s{i}"]) < TOL
+
+
+def test_default_plan_uses_wino_at_bench_batch():
+    """the default heuristics put the big 3x3 stride-1 layers of a 32-frame batch on the Winograd kernel, and none at one
+    small frame (fewer tiles than resident workgroups)"""
+    from implicit_depth_amd import nhwc
+
+    conv = nn.Conv2d(64, 64, 3, 1, 1).cuda()
+    for B, H, W, want in ((8, 96, 128, True), (1, 24, 32, False)):
+        x = torch.randn(B, H, W, 64, device="cuda")
+        p = nhwc.Plan(x.device)
+        p.conv(nhwc.View(x, 0, 64), conv, p.buffer(B, H, W, 64))
+        assert (p.ops[0].tile_m == nhwc.TILE_WINO) == want

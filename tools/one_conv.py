@@ -12,8 +12,7 @@ conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda(); syn.fill_state_dict(conv, 1)
 x = torch.randn(B, H, W, cin, device="cuda")
 p = nhwc.Plan(x.device)
 out = p.buffer(B, H, W, cout)
-if tm == nhwc.TILE_WINO:  # Winograd kernel: the plan packs Winograd-domain weights
-    nhwc.WINOGRAD, nhwc.WINO_MIN_BLOCKS, nhwc.WINO_CH = True, 1, (8 if tn == 108 else 16)
+nhwc.WINOGRAD, nhwc.WINO_MIN_TILES = tm == nhwc.TILE_WINO, 1  # Winograd kernel: the plan packs Winograd-domain weights
 p.conv(nhwc.View(x, 0, cin), conv, out, act=1)
 op = p.ops[0]; op.tile_m, op.tile_n, op.split_k = tm, tn, split
 if split > 1:

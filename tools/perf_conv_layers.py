@@ -5,6 +5,7 @@ import torch
 from torch import nn
 import implicit_depth_amd.synthetic as syn
 from implicit_depth_amd import nhwc
+nhwc.WINOGRAD = False  # this tool forces the direct kernels' tile codes
 
 B = int(os.environ.get("B", 4))
 # (cin, cout, H, W, ks, stride)  representative layers of CVEncoder / BDDecoderPP @512x384

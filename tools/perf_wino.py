@@ -19,29 +19,26 @@ LAYERS = [(64, 64, 192, 256, 0), (64, 64, 192, 256, 1), (192, 64, 192, 256, 0), 
 sel = os.environ.get("LAYERS")
 if sel:
     LAYERS = [LAYERS[int(i)] for i in sel.split(",")]
-VARIANTS = [("direct8", 8, 0), ("wino", nhwc.TILE_WINO, 108)]
+VARIANTS = [("direct8", 8, 0), ("wino", nhwc.TILE_WINO, 0)]
 
 
 def build(conv, x, res, tm, tn):
     p = nhwc.Plan(x.device)
     Bn, H, W, cin = x.shape
     out = p.buffer(Bn, H, W, conv.out_channels)
-    nhwc.WINOGRAD = tm == nhwc.TILE_WINO
-    nhwc.WINO_CH = 8 if tn == 108 else 16
-    old = nhwc.WINO_MIN_BLOCKS
-    nhwc.WINO_MIN_BLOCKS = 1
+    old_w, nhwc.WINOGRAD = nhwc.WINOGRAD, tm == nhwc.TILE_WINO
+    old = nhwc.WINO_MIN_TILES
+    nhwc.WINO_MIN_TILES = 1
     try:
         p.conv(nhwc.View(x, 0, cin), conv, out, act=1, slope=0.2, res=None if res is None else nhwc.View(res, 0, conv.out_channels))
     finally:
-        nhwc.WINOGRAD = False
-        nhwc.WINO_CH = 16
-        nhwc.WINO_MIN_BLOCKS = old
+        nhwc.WINOGRAD = old_w
+        nhwc.WINO_MIN_TILES = old
     op = p.ops[0]
     if tm != nhwc.TILE_WINO:
         op.tile_m, op.tile_n = tm, tn
     else:
         assert op.tile_m == nhwc.TILE_WINO
-        op.tile_n = tn
     p._arr = None
     return p, out
 

@@ -5,6 +5,7 @@ import torch
 from torch import nn
 import implicit_depth_amd.synthetic as syn
 from implicit_depth_amd import nhwc
+nhwc.WINOGRAD = False  # this tool forces the direct kernels' tile codes
 cin, cout, H, W, tm, tn, split = [int(v) for v in sys.argv[1:8]]
 B = int(sys.argv[8]) if len(sys.argv) > 8 else 32
 use_res = len(sys.argv) > 9 and sys.argv[9] == "1"

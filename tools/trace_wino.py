@@ -10,17 +10,17 @@ from implicit_depth_amd import nhwc
 
 cin, cout, H, W, tn = [int(v) for v in sys.argv[1:6]]
 B = int(sys.argv[6]) if len(sys.argv) > 6 else 32
-waves = 8 if tn == 16 else 4
-nhwc.WINOGRAD, nhwc.WINO_MIN_BLOCKS, nhwc.WINO_CH = True, 1, (8 if tn == 108 else 16)
+waves = 4
+nhwc.WINOGRAD, nhwc.WINO_MIN_TILES = True, 1
 conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda(); syn.fill_state_dict(conv, 1)
 x = torch.randn(B, H, W, cin, device="cuda")
 p = nhwc.Plan(x.device)
 out = p.buffer(B, H, W, cout)
 p.conv(nhwc.View(x, 0, cin), conv, out, act=1)
-op = p.ops[0]; op.tile_n = tn
-rows = 16 if tn == 16 else 8
+op = p.ops[0]
+rows = 8
 tiles = B * (-(-H // rows)) * (-(-W // 32)) * (cout // 32)
-per_cu = 2 if tn == 108 else 1
+per_cu = 2
 blocks = min(tiles, 256 * per_cu)
 tr = torch.zeros(blocks * waves * 64, dtype=torch.int64, device="cuda")
 op.ws = tr.data_ptr()
@@ -28,7 +28,7 @@ p._arr = None
 for _ in range(3): p.run()
 torch.cuda.synchronize()
 t = tr.cpu().numpy().reshape(blocks, waves, 64).astype(np.int64)
-nS = (cin + 15) // 16 * (2 if tn == 108 else 1)
+nS = (cin + 15) // 16 * 2
 print(f"{cin}->{cout} @{H}x{W} B={B} tile_n={tn}: {tiles} tiles on {blocks} persistent workgroups x {waves} waves, {nS} K steps per tile")
 med = lambda a: float(np.median(a))
 print(f"  workgroup life (entry -> exit)  {med(t[:, :, 62] - t[:, :, 0]):9.0f} cycles = {tiles / blocks:.1f} tiles -> {med(t[:, :, 62] - t[:, :, 0]) / (tiles / blocks):.0f} per tile")
