@@ -192,19 +192,19 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &a, unsigned blk_i
         }
         float *o = a.out + m * a.out_cs;
         const float *rp = a.res ? a.res + m * a.res_cs : nullptr;
+        act_dispatch(a.act, a.slope, [&](auto fn) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n_base + 16 * j + 4 * h;
-            if (co >= a.Cout) continue;  // Cout % 4 == 0 (host-checked)
-            f32x4 v = acc[i][j];
-            if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
-            if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
-            if (a.act != IDH_ACT_NONE) {
+            for (int j = 0; j < TN; ++j) {
+                const int co = n_base + 16 * j + 4 * h;
+                if (co >= a.Cout) continue;  // Cout % 4 == 0 (host-checked)
+                f32x4 v = acc[i][j];
+                if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + co);
+                if (rp) v += *reinterpret_cast<const f32x4 *>(rp + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, a.slope);
+                for (int r = 0; r < 4; ++r) v[r] = fn(v[r]);
+                *reinterpret_cast<f32x4 *>(o + co) = v;
             }
-            *reinterpret_cast<f32x4 *>(o + co) = v;
-        }
+        });
     }
 }
 
@@ -681,17 +681,18 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] += rv[i][j];
     }
+    // activation selector tested once, straight-line element code (act_dispatch, conv_args.h)
+    act_dispatch(a.act, a.slope, [&](auto fn) {
 #pragma unroll
-    for (int i = 0; i < RW; ++i)
+        for (int i = 0; i < RW; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            f32x4 v = acc[i][j];  // bias already inside (bias_first)
-            if (a.act != IDH_ACT_NONE) {
+            for (int j = 0; j < NJ; ++j) {
+                f32x4 v = acc[i][j];  // bias already inside (bias_first)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.act, a.slope);
+                for (int r = 0; r < 4; ++r) v[r] = fn(v[r]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsO, voffO[i] + 64 * j, 0, 0);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsO, voffO[i] + 64 * j, 0, 0);
-        }
+    });
 }
 
 template <int RW, bool UP, int NJ = 4, bool NORM = false, bool S2 = false>

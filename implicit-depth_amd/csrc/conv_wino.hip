@@ -26,6 +26,8 @@
 //     panel  [co block][pos 16][h 4][m 16] float4 = A fragments in read order (packed in exactly this order).
 // * Epilogue: output transform (24 adds per tile and channel quad) in registers, + bias + residual, LeakyReLU, 16-byte
 //   NHWC stores (a lane holds 4 consecutive channels of the 2x2 pixels of its tile).
+#include <type_traits>
+
 #include "conv_args.h"
 #include "../../include/idh_ops.h"
 
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     // the ~100-cycle issue cost of an LDS-DMA instruction opens a gap in the matrix pipe; sched_barrier keeps the compiler
     // from sinking the reads back to their uses.
     constexpr int kAhead = CH == 16 ? 2 : 3;
-    auto compute = [&](int stage, int cnext, int snext, bool flush) {
+    auto compute = [&](int stage, int cnext, int snext, bool flush) {  // flush: the previous tile's outputs leave under this step
         // volatile LDS pointers: hipcc otherwise pairs the 8-byte reads into ds_read2_b64 (half rate, 2-way bank conflicts)
         typedef const __attribute__((address_space(3))) volatile char lds_cchar;
         typedef const __attribute__((address_space(3))) volatile vec lds_cvec;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
             if (g == 1) rd_row(0);
             if (g == 5) rd_row(3);
 #ifndef IDH_ABL_WINO_NODMA
-            if ((g & 1) == 0 && (g >> 1) < kTPW && cnext >= 0) issue_one(g >> 1, cnext, snext);  // even groups: one DMA piece
+            if ((g & 1) == 0 && (g >> 1) < kTPW) issue_one(g >> 1, cnext, snext);  // even groups: one DMA piece
 #endif
 #ifndef IDH_ABL_WINO_NOSTORE
             if ((g & 1) == 1 && (g >> 1) < 4 * NCO && flush) {  // odd groups: one 16-byte store of the previous tile's outputs
@@ -334,7 +336,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
                     set_fetch_tile();
                 }
             }
-            compute(it & 1, last ? (has_next ? 0 : -1) : c + 1, (it + 1) & 1, pending);
+            // (the DMA of the step after the workgroup's last one is issued too — it re-reads this tile's step 0 into the idle
+            // stage and is never used: no branch in the K loop)
+            compute(it & 1, last ? 0 : c + 1, (it + 1) & 1, pending);
             pending = false;
             ++it;
             WINO_TRACE(tr_i < 61 ? tr_i++ : 61);
