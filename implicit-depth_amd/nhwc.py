@@ -172,9 +172,10 @@ TILE_WINO = 12  # IDH_TILE_WINO of include/idh_ops.h == the op's tile_m
 # Winograd F(2x2,3x3) for the eligible 3x3 stride-1 layers of fp32 plans (csrc/conv_wino.hip): fp32 operands and
 # accumulation, 2.25x fewer MFMAs; measured 1.67-1.84x over the direct LDS kernel at B=32 (tools/perf_wino.py).
 # Tiles are 32 x 8 pixels x 32 channels; WINO_MIN_TILES: below this many tiles the direct kernels' finer tiles fill the
-# chip better; WINO_MIN_FILL: smallest useful fraction of the tile grid that lies inside the map.
+# chip better (conv stage of the hot path with thresholds off / 512 / 256 / 128 / 64, tools/perf_levels.py: B=1 2.67 / 2.66 /
+# 2.46 / 2.45 / 2.66 ms, B=2 4.43 / 3.90 / 3.91 / 3.80 / 3.89, B=4 7.75 / 6.64 / 6.36 / 6.26 / 6.47); WINO_MIN_FILL: smallest useful fraction of the tile grid that lies inside the map.
 WINOGRAD = True
-WINO_MIN_TILES = 512
+WINO_MIN_TILES = 128
 WINO_MIN_FILL = 0.74
 
 
