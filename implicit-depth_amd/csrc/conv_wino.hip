@@ -77,6 +77,14 @@ __global__ __launch_bounds__(256) void pack_wino_weight_k(const float *__restric
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, f32x4 *dst, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)dst, 16, voff, soff, 0, 0);
 }
+// (base, bytes) of a buffer kept as plain scalars: a source picked at run time is two s_cselects, not a branch
+struct BufRef {
+    const float *p;
+    int bytes;
+};
+__device__ __forceinline__ void dma16(BufRef b, f32x4 *dst, int voff, int soff) {
+    dma16(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b.p), 0, b.bytes, 0x00020000), dst, voff, soff);
+}
 
 // Developer build (-DIDH_ABL_WINO_TRACE, tools/trace_wino.sh): every wave logs s_memtime at its phase boundaries into
 // ConvArgs.ws (64 x 8 bytes per wave: [0] entry, [1] first DMA issued, [2] first barrier passed, [3+2c] K step c computed,
@@ -93,7 +101,11 @@ struct WinoArgs {
     int tiles;  // N * tiles_y * tiles_x * NT
 };
 
-template <int WAVES, int NCO, int CH>
+// SRC2: a second source, the 1x1 projection of another tensor (BasicBlock's conv2(h) + downsample(x), layers.py:86-92), is
+// accumulated in the OUTPUT domain: after the Winograd steps the tile runs "P steps" of 16 channels each — the same halo
+// region of x (4 planes, only the patch centres are read) and a 2 KiB panel of the ordinary packed 1x1 weights in the same
+// two LDS stages — whose MFMAs add W1 . x to the 2x2 output pixels directly (the registers that hold the residual tile).
+template <int WAVES, int NCO, int CH, bool SRC2>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs wa) {
     constexpr int KS = CH / 4;   // MFMA k-steps per K step = consecutive channels per lane
     constexpr int NP = CH / 4;   // 4-channel planes of the halo per K step
@@ -115,7 +127,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     static_assert(CH == 8, "K steps of 8 channels: every tile has >= 2 steps (the first stores the previous tile's outputs, the last loads the residual)");
     static_assert(kTPW <= 8 && 4 * NCO <= 8, "one DMA piece per even position group, one output store per odd group");
     constexpr int kHalo = NP * kQS;
-    constexpr int kStage = kHalo + 64 * kPanelPieces;   // float4 slots per stage
+    constexpr int kTight = 32 * kRows;                   // float4 slots of one 4-channel plane of the tile's own pixels (no halo)
+    constexpr int kStage3 = kHalo + 64 * kPanelPieces;   // float4 slots of a Winograd step's stage
+    constexpr int kStageP = 8 * kTight + 64 * 2 * NCO;   // ... of a P step's (SRC2): 32 channels of the tile + 2 x NCO panel pieces
+    constexpr int kStage = SRC2 && kStageP > kStage3 ? kStageP : kStage3;
     __shared__ f32x4 lds[2 * kStage];
 
     const ConvArgs &a = wa.c;
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
 #endif
     const int nS = s.cblocks * (16 / CH);  // K steps per tile
     const int nCB = a.Cout_pad / 16;
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, s.cblocks * nCB * 16384, 0x00020000);
+    const BufRef rsW{s.w, s.cblocks * nCB * 16384};
 
     // ---- persistent workgroup: tiles t0, t0 + stride, ... < t_end.  The hardware places block b on XCD b % 8; every XCD
     // gets one contiguous range of tiles and its resident workgroups walk it side by side, so the workgroups that
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         y0 = ty * kRows; x0 = tx * kWinoTileW; cb0 = nt * NCO;
     };
     // ---- LDS-DMA descriptors of the tile whose K steps are being fetched --------------------------------------------
-    __amdgpu_buffer_rsrc_t rsA;
+    BufRef rsA;
     int voffF[kFull > 0 ? kFull : 1], voffX = 0, panel_so;
     const int jx = kFull * WAVES + (wave * kExtra) / NP, qx = (wave * kExtra) % NP;  // this wave's share of the remaining j's
     const int voffP = 16 * lane;
@@ -171,24 +186,48 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         return ok ? (iy * s.W + ix) * s.cs * 4 : kOob;  // out of the descriptor's range = zero padding
     };
     auto set_fetch_tile = [&]() {  // from (y0, x0, cb0, img)
-        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
+        rsA = BufRef{s.in + (size_t)img * s.H * s.W * s.cs, s.H * s.W * s.cs * 4};
 #pragma unroll
         for (int f = 0; f < kFull; ++f) voffF[f] = halo_voff(f * WAVES + wave);
         if (kExtra) voffX = halo_voff(jx);
         panel_so = (cb0 * (4 * KS) + wave * kPanel) * 1024;
     };
-    // k-th DMA piece of this wave for K step c of the fetch tile into `stage`; wave-uniform operands forced into SGPRs
-    auto issue_one = [&](int k, int c, int stage) {
+    // ---- second source (P steps of 32 channels): 8 planes of the tile's own 32 x kRows pixels, [plane][row][column parity][16]
+    // float4 (kTight / 64 pieces each: wave w copies piece w of every plane -> one offset VGPR), and 2 x NCO panel pieces of the
+    // ordinary packed 1x1 weights (one per wave)
+    static_assert(!SRC2 || (kTight == 64 * WAVES && 2 * NCO == WAVES), "P-step pieces: one per plane and one of the panel per wave");
+    constexpr int kTPW2 = SRC2 ? 9 : 0;
+    const ConvSrc &s1 = a.s[1];
+    const int nS2 = SRC2 ? (s1.cblocks + 1) / 2 : 0;  // P steps per tile
+    BufRef rsA2 = rsW, rsW2 = rsW;
+    int voffT = 0, voffP2 = 0;
+    if constexpr (SRC2) {
+        rsW2 = BufRef{s1.w, s1.cblocks * 4 * a.Cout_pad * 16};
+        voffP2 = ((lane >> 4) * a.Cout_pad + (lane & 15)) * 16;  // idh_pack_conv_weight(ks = 1): [ci / 4][co][4]
+    }
+    auto set_fetch_tile2 = [&]() {  // from (y0, x0, img); same map size as source 0
+        if constexpr (SRC2) {
+            rsA2 = BufRef{s1.in + (size_t)img * s1.H * s1.W * s1.cs, s1.H * s1.W * s1.cs * 4};
+            const int L = 64 * wave + lane;  // slot of a plane: [row][parity][16]
+            const int iy = y0 + (L >> 5), ix = x0 + 2 * (L & 15) + ((L >> 4) & 1);
+            voffT = ((iy < s1.H) & (ix < s1.W)) ? (iy * s1.W + ix) * s1.cs * 4 : kOob;
+        }
+    };
+    // k-th DMA piece of this wave for the NEXT step into `stage`: Winograd step c of the fetch tile, or (p, SRC2 only) P step c
+    // of the tile in flight.  Branch-free: both candidates are formed and selected (a uniform branch per piece costs more
+    // in the K loop than the selects); wave-uniform operands forced into SGPRs
+    auto issue_next = [&](int k, bool p, int c, int stage, int cbf) {
         int so, lo, vo;
         bool halo = true;
-        if (k < NP * kFull) {
-            const int f = k / NP, q = k % NP;
+        const int k0 = k < kTPW ? k : kTPW - 1;  // (pieces kTPW.. exist for P steps only: the Winograd candidate repeats its last piece)
+        if (k0 < NP * kFull) {
+            const int f = k0 / NP, q = k0 % NP;
             vo = voffF[f]; so = 16 * q + 4 * CH * c; lo = q * kQS + 64 * (f * WAVES + wave);
-        } else if (k < NP * kFull + kExtra) {
-            const int q = qx + (k - NP * kFull);
+        } else if (k0 < NP * kFull + kExtra) {
+            const int q = qx + (k0 - NP * kFull);
             vo = voffX; so = 16 * q + 4 * CH * c; lo = q * kQS + 64 * jx;
         } else {
-            const int i = k - NP * kFull - kExtra;
+            const int i = k0 - NP * kFull - kExtra;
             halo = false;
             vo = voffP; so = panel_so + (c * nCB * (4 * KS) + i) * 1024; lo = kHalo + 64 * (wave * kPanel + i);
         }
@@ -198,7 +237,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
 #ifdef IDH_ABL_WINO_NOPANEL
         if (!halo && c + stage > 0) return;
 #endif
-        dma16(halo ? rsA : rsW, lds + __builtin_amdgcn_readfirstlane(stage * kStage + lo), vo, __builtin_amdgcn_readfirstlane(so));
+        BufRef rs = halo ? rsA : rsW;
+        if constexpr (SRC2) {
+            int so1, lo1, vo1;
+            bool halo1 = true;
+            if (k < 8) {  // plane k: channels 32 c + 4 k ..; the upper half of an odd last step lies past the packed weights: zeros
+                vo1 = (k >= 4 && 2 * c + 1 >= s1.cblocks) ? kOob : voffT;
+                so1 = 16 * k + 128 * c; lo1 = k * kTight + 64 * wave;
+            } else {      // panel piece (16-channel half wave / NCO, output block wave % NCO)
+                const int hh = wave / NCO, cbw = wave % NCO;
+                halo1 = false;
+                vo1 = voffP2; so1 = (4 * (2 * c + hh) * a.Cout_pad + 16 * (cbf + cbw)) * 16; lo1 = 8 * kTight + 64 * wave;
+            }
+            // bit blends, not ?: — hipcc turns selects of this much arithmetic back into a branch per piece
+            const int m = -(int)p;
+            const unsigned long long m64 = (unsigned long long)(long long)m;
+            vo ^= (vo ^ vo1) & m; so ^= (so ^ so1) & m; lo ^= (lo ^ lo1) & m;
+            const BufRef rs1 = halo1 ? rsA2 : rsW2;
+            const unsigned long long p0 = (unsigned long long)rs.p, p1 = (unsigned long long)rs1.p;
+            rs.p = reinterpret_cast<const float *>(p0 ^ ((p0 ^ p1) & m64));
+            rs.bytes ^= (rs.bytes ^ rs1.bytes) & m;
+        }
+        dma16(rs, lds + __builtin_amdgcn_readfirstlane(stage * kStage + lo), vo, __builtin_amdgcn_readfirstlane(so));
     };
 
     f32x4 acc[16][NCO];
@@ -220,7 +280,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     // the ~100-cycle issue cost of an LDS-DMA instruction opens a gap in the matrix pipe; sched_barrier keeps the compiler
     // from sinking the reads back to their uses.
     constexpr int kAhead = CH == 16 ? 2 : 3;
-    auto compute = [&](int stage, int cnext, int snext, bool flush) {  // flush: the previous tile's outputs leave under this step
+    auto compute = [&](int stage, bool pnext, int cnext, int snext, int cbf, bool flush) {  // flush: the previous tile's outputs leave under this step
         // volatile LDS pointers: hipcc otherwise pairs the 8-byte reads into ds_read2_b64 (half rate, 2-way bank conflicts)
         typedef const __attribute__((address_space(3))) volatile char lds_cchar;
         typedef const __attribute__((address_space(3))) volatile vec lds_cvec;
@@ -249,7 +309,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
             if (g == 1) rd_row(0);
             if (g == 5) rd_row(3);
 #ifndef IDH_ABL_WINO_NODMA
-            if ((g & 1) == 0 && (g >> 1) < kTPW) issue_one(g >> 1, cnext, snext);  // even groups: one DMA piece
+            if ((g & 1) == 0 && (g >> 1) < kTPW) issue_next(g >> 1, pnext, cnext, snext, cbf);  // even groups: one DMA piece
+            if (SRC2 && g >= 13 && (g & 1) && kTPW + (g - 13) / 2 < kTPW2) {  // a P step has more pieces than a Winograd step
+                if (pnext) issue_next(kTPW + (g - 13) / 2, true, cnext, snext, cbf);
+            }
 #endif
 #ifndef IDH_ABL_WINO_NOSTORE
             if ((g & 1) == 1 && (g >> 1) < 4 * NCO && flush) {  // odd groups: one 16-byte store of the previous tile's outputs
@@ -279,11 +342,47 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         }
     };
 
+    // One P step (SRC2): 32 channels of the 1x1 source.  Lane (n, h) reads channels 4h..4h+3 and 16+4h.. of the four pixels of
+    // its tile (ds_read_b128 from planes h and 4+h) and the W1 fragments of both halves and each output block; 8 MFMA k-steps
+    // per pixel and block go straight into the output-domain registers.
+    auto compute_p = [&](int stage, bool pnext, int cnext, int snext, int cbf) {
+        const f32x4 *sH = lds + stage * kStage + h * kTight + (4 * wave) * 16 + n;
+        const f32x4 *sW = lds + stage * kStage + 8 * kTight + lane;
+        f32x4 d2[2][2][2], A1[2][NCO];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int j = 0; j < NCO; ++j) A1[hh][j] = sW[64 * (hh * NCO + j)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) d2[i][j][hh] = sH[hh * 4 * kTight + (2 * i + j) * 16];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {  // (pixel g >> 1, channel half g & 1)
+            if (pnext) {
+                issue_next(g, true, cnext, snext, cbf);
+                if (g == 7) issue_next(8, true, cnext, snext, cbf);
+            } else if (g < kTPW) {
+                issue_next(g, false, cnext, snext, cbf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int px = g >> 1, hh = g & 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < NCO; ++j)
+                    ost[px >> 1][px & 1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[hh][j][k], d2[px >> 1][px & 1][hh][k], ost[px >> 1][px & 1][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // ---- first tile: fetch K step 0 -----------------------------------------------------------------------------------
     decode(t_cur);
     set_fetch_tile();
 #pragma unroll
-    for (int k = 0; k < kTPW; ++k) issue_one(k, 0, 0);
+    for (int k = 0; k < kTPW; ++k) issue_next(k, false, 0, 0, 0);
     WINO_TRACE(tr_i++);
     __syncthreads();  // (the compiler drains vmcnt before the barrier: the DMA of every wave has landed)
     WINO_TRACE(tr_i++);
@@ -308,38 +407,49 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         int voffO[2][2];
         f32x4 b4[NCO];
 
+        set_fetch_tile2();     // P-step descriptors of THIS tile (its Winograd descriptors were set one tile ago)
+        const int cb_cur = cb0;
+        const int nT = nS + nS2;
 #pragma unroll 1
-        for (int c = 0; c < nS; ++c) {
-            const bool last = c + 1 == nS;
-            if (last) {
-                int voffR[2][2];
+        for (int c = 0; c < nT; ++c) {
+            const bool last = c + 1 == nT;
+            if (c + 1 == nS) {  // last Winograd step: the residual tile lands in the output-domain registers
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int oy = y0 + 2 * wave + i, ox = x0 + 2 * n + j;
-                        const bool ok = (oy < a.Ho) & (ox < a.Wo);
-                        const int pixel = oy * a.Wo + ox;
-                        voffO[i][j] = ok ? (pixel * a.out_cs + n0 + 4 * h) * 4 : kOob;
-                        voffR[i][j] = ok ? (pixel * a.res_cs + n0 + 4 * h) * 4 : kOob;
+                        const int voffR = ((oy < a.Ho) & (ox < a.Wo)) ? ((oy * a.Wo + ox) * a.res_cs + n0 + 4 * h) * 4 : kOob;
+#pragma unroll
+                        for (int cb = 0; cb < NCO; ++cb) ost[i][j][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voffR + 64 * cb, 0, 0));
+                    }
+            }
+            if (last) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int oy = y0 + 2 * wave + i, ox = x0 + 2 * n + j;
+                        voffO[i][j] = ((oy < a.Ho) & (ox < a.Wo)) ? ((oy * a.Wo + ox) * a.out_cs + n0 + 4 * h) * 4 : kOob;
                     }
 #pragma unroll
-                for (int cb = 0; cb < NCO; ++cb) {
-                    b4[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 16 * cb + 4 * h) * 4, 0, 0));
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) ost[i][j][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voffR[i][j] + 64 * cb, 0, 0));
-                }
-                if (has_next) {  // from here on the DMA descriptors belong to the next tile: its K step 0 lands under this step
+                for (int cb = 0; cb < NCO; ++cb) b4[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 16 * cb + 4 * h) * 4, 0, 0));
+                if (has_next) {  // from here on the Winograd DMA descriptors belong to the next tile: its step 0 lands under this step
                     decode(t_next);
                     set_fetch_tile();
                 }
             }
-            // (the DMA of the step after the workgroup's last one is issued too — it re-reads this tile's step 0 into the idle
-            // stage and is never used: no branch in the K loop)
-            compute(it & 1, last ? 0 : c + 1, (it + 1) & 1, pending);
-            pending = false;
+            // next step: Winograd step c+1 of this tile, P step c+1-nS of this tile, or step 0 of the next tile (the DMA of the
+            // step after the workgroup's last one is issued too — it re-reads a step 0 into the idle stage and is never
+            // used: no branch in the K loop)
+            const bool pnext = SRC2 && !last && c + 1 >= nS;
+            const int cnext = last ? 0 : pnext ? c + 1 - nS : c + 1, sn = (it + 1) & 1;
+            if (!SRC2 || c < nS) {
+                compute(it & 1, pnext, cnext, sn, cb_cur, pending);
+                pending = false;
+            } else {
+                compute_p(it & 1, pnext, cnext, sn, cb_cur);
+            }
             ++it;
             WINO_TRACE(tr_i < 61 ? tr_i++ : 61);
             __syncthreads();
@@ -392,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     WINO_TRACE(62);
 }
 
-template <int WAVES, int NCO, int CH>
+template <int WAVES, int NCO, int CH, bool SRC2>
 int launch_wino(const ConvArgs &a, int N, hipStream_t st) {
     WinoArgs wa{a, (a.Wo + kWinoTileW - 1) / kWinoTileW, (a.Ho + 2 * WAVES - 1) / (2 * WAVES), 0};
     wa.c.NT = a.Cout / (16 * NCO);
@@ -406,11 +516,12 @@ int launch_wino(const ConvArgs &a, int N, hipStream_t st) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         resident = cus > 0 ? cus : 256;
     }
-    constexpr int kLdsBytes = 2 * (CH / 4 * wino_qs(WAVES) + 64 * NCO * CH) * 16;
+    constexpr int kLds3 = CH / 4 * wino_qs(WAVES) + 64 * NCO * CH, kLdsP = 8 * 32 * 2 * WAVES + 64 * 2 * NCO;
+    constexpr int kLdsBytes = 2 * (SRC2 && kLdsP > kLds3 ? kLdsP : kLds3) * 16;
     const int per_cu = kLdsBytes * 2 <= 160 * 1024 ? 2 : 1;
     long long grid = (long long)resident * per_cu;
     if (grid > tiles) grid = tiles >= 8 ? tiles / 8 * 8 : tiles;
-    hipLaunchKernelGGL((conv3x3_wino_k<WAVES, NCO, CH>), dim3((unsigned)grid), dim3(64 * WAVES), 0, st, wa);
+    hipLaunchKernelGGL((conv3x3_wino_k<WAVES, NCO, CH, SRC2>), dim3((unsigned)grid), dim3(64 * WAVES), 0, st, wa);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }
@@ -421,7 +532,10 @@ namespace idh_conv {
 
 bool wino_supported(const ConvArgs &a) {
     const ConvSrc &s = a.s[0];
-    return s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && !a.s[1].in && a.S == 1 && (a.Cout % 32) == 0 &&
+    const ConvSrc &s1 = a.s[1];
+    const bool src2_ok = !s1.in || (s1.ks == 1 && s1.stride == 1 && !s1.up_in[0] && !s1.norm && s1.H == s.H && s1.W == s.W &&
+                                    (long long)s1.H * s1.W * s1.cs * 4 < (1ll << 31) && (long long)s1.cblocks * a.Cout_pad * 64 < (1ll << 31));
+    return s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && src2_ok && a.S == 1 && (a.Cout % 32) == 0 &&
            (long long)s.H * s.W * s.cs * 4 < (1ll << 31) && (long long)a.Ho * a.Wo * a.out_cs * 4 < (1ll << 31) &&
            (!a.res || (long long)a.Ho * a.Wo * a.res_cs * 4 < (1ll << 31)) && (long long)s.cblocks * a.Cout_pad * 1024 < (1ll << 31);
 }
@@ -429,7 +543,8 @@ bool wino_supported(const ConvArgs &a) {
 int launch_conv_wino(const ConvArgs &a, int N, int rows, hipStream_t st) {
     if (!wino_supported(a)) return IDH_EUNSUPPORTED;
     (void)rows;
-    return launch_wino<4, 2, kWinoCH>(a, N, st);   // 8-row tiles, 8-channel K steps: 56 KiB of LDS -> 2 workgroups / CU
+    // 8-row tiles, 8-channel K steps: 56 KiB of LDS -> 2 workgroups / CU
+    return a.s[1].in ? launch_wino<4, 2, kWinoCH, true>(a, N, st) : launch_wino<4, 2, kWinoCH, false>(a, N, st);
 }
 
 }  // namespace idh_conv

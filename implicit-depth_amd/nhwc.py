@@ -181,8 +181,12 @@ WINO_MIN_FILL = 0.74
 
 def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> bool:
     (v0, c0) = srcs[0]
-    if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 32 or isinstance(v0, CatView) or len(srcs) > 1:
+    if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 32 or isinstance(v0, CatView):
         return False
+    if len(srcs) > 1:  # fused second source: BasicBlock's 1x1 stride-1 projection (accumulated in the output domain)
+        (v1, c1) = srcs[1]
+        if c1.kernel_size[0] != 1 or c1.stride[0] != 1 or isinstance(v1, CatView):
+            return False
     ty, tx = -(-Ho // 8), -(-Wo // 32)
     if Ho * Wo < WINO_MIN_FILL * (ty * 8) * (tx * 32):
         return False

@@ -122,8 +122,8 @@ int idh_pack_conv_weight_split(const float *w_oihw, const float *w_1x1, void *ds
  * stride-1 convs of BasicBlock, layers.py:59-95).  IDH_OP_CONV with tile_m = IDH_TILE_WINO; src[0].w = the output of
  * idh_pack_conv_weight_wino (U = G g G^T per (co, ci), in MFMA A-fragment order:
  * [Cin_pad/8][Cout_pad/16][position 16][ci pair 4][co 16][2]); tile_n is ignored (32 x 8 pixel x 32 channel tiles).
- * Shape family: 3x3, stride 1, zero padding, one source, Cout % 32 == 0, split_k == 1; anything else:
- * IDH_EUNSUPPORTED.  Results differ from the direct kernel by fp32 rounding only (~1e-6 of the output scale). */
+ * Shape family: 3x3, stride 1, zero padding, Cout % 32 == 0, split_k == 1; src[1] may be a 1x1 stride-1 projection of a
+ * tensor of the same size (weights packed by idh_pack_conv_weight as usual); anything else: IDH_EUNSUPPORTED.  Results differ from the direct kernel by fp32 rounding only (~1e-6 of the output scale). */
 #define IDH_TILE_WINO 12
 size_t idh_packed_wino_weight_floats(int Cout, int Cin);
 int idh_pack_conv_weight_wino(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);

@@ -174,6 +174,7 @@ def test_fused_upsample_concat_is_bit_identical_to_materialised():
     pyr = syn.encoder_pyramid(2, 256, 384, seed=5, channels=(24, 64, 128, 256, 384))
     feats = [t.cuda() for t in pyr]
     old = nhwc.FUSE_UPSAMPLE, nhwc.FUSED_UP_ROWS
+    old_wino, nhwc.WINOGRAD = nhwc.WINOGRAD, False  # bit-identity holds kernel by kernel: a materialised concat would take the Winograd kernel
     try:
         outs = {}
         for fuse, rows in ((False, 8), (True, 8), (True, 4)):
@@ -186,6 +187,7 @@ def test_fused_upsample_concat_is_bit_identical_to_materialised():
             assert (n_up == 0 and fused_srcs > 0) if fuse else (n_up > 0 and fused_srcs == 0)
     finally:
         nhwc.FUSE_UPSAMPLE, nhwc.FUSED_UP_ROWS = old
+        nhwc.WINOGRAD = old_wino
         dec.__dict__.pop("_idh_plans", None)
     for key in ((True, 8), (True, 4)):
         for k, v in outs[(False, 8)].items():

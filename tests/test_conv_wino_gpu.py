@@ -65,6 +65,43 @@ def test_wino_conv_vs_fp64_and_direct(shape, wino_everywhere):
     assert rel_err(yw.cpu(), yd.cpu()) < 1e-5, "Winograd kernel vs direct kernel"
 
 
+# (B, cin, cout, H, W, cin2, act): fused 1x1 projection of a second tensor (BasicBlock's conv2(h) + downsample(x)): channel
+# counts with an odd number of 16-channel chunks (24, 112, 208: the last 32-channel P step is half empty), wide ones, ragged maps
+@pytest.mark.parametrize("shape", [(2, 64, 64, 40, 64, 192, 1), (1, 64, 64, 37, 45, 24, 1), (3, 32, 96, 9, 33, 112, 2), (1, 128, 128, 16, 32, 384, 1),
+                                   (2, 64, 32, 8, 70, 208, 0), (1, 16, 64, 24, 32, 16, 1)])
+def test_wino_conv_with_fused_projection(shape, wino_everywhere):
+    nhwc = wino_everywhere
+    B, cin, cout, H, W, cin2, act = shape
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
+    proj = nn.Conv2d(cin2, cout, 1).cuda()
+    syn.fill_state_dict(conv, seed=cin + cout + H)
+    syn.fill_state_dict(proj, seed=cin2 + H)
+    g = torch.Generator(device="cuda").manual_seed(H * W + cin2)
+    xb = torch.randn(B, H, W, cin, device="cuda", generator=g)
+    x2 = torch.zeros(B, H, W, nhwc.ceil16(cin2), device="cuda")
+    x2[..., :cin2] = torch.randn(B, H, W, cin2, device="cuda", generator=g)
+    ref = (F.conv2d(xb.permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1) +
+           F.conv2d(x2[..., :cin2].permute(0, 3, 1, 2).double(), proj.weight.double(), proj.bias.double()))
+    ref = (F.leaky_relu(ref, 0.2) if act == 1 else F.elu(ref) if act == 2 else ref).permute(0, 2, 3, 1)
+    outs = []
+    for wino in (True, False):
+        old = nhwc.WINOGRAD
+        nhwc.WINOGRAD = wino
+        try:
+            p = nhwc.Plan(xb.device)
+            out = p.buffer(B, H, W, cout)
+            p.conv(nhwc.View(xb, 0, cin), conv, out, act=act, slope=0.2, x2=nhwc.View(x2, 0, cin2), conv2=proj)
+        finally:
+            nhwc.WINOGRAD = old
+        assert (p.ops[0].tile_m == nhwc.TILE_WINO) == wino
+        p.run()
+        p.run()  # persistent kernel state must not leak between launches
+        torch.cuda.synchronize()
+        outs.append(out.dense().clone())
+    assert rel_err(outs[0].cpu(), ref.cpu()) < 1e-5, "Winograd kernel + fused projection vs fp64"
+    assert rel_err(outs[0].cpu(), outs[1].cpu()) < 1e-5, "vs the direct kernel"
+
+
 def test_wino_conv_channel_strided_views(wino_everywhere):
     """input = channel slice of a wider concat buffer, output = slice of another, residual strided too (torch.cat elimination)"""
     nhwc = wino_everywhere

@@ -10,13 +10,18 @@ from implicit_depth_amd import nhwc
 
 cin, cout, H, W, tn = [int(v) for v in sys.argv[1:6]]
 B = int(sys.argv[6]) if len(sys.argv) > 6 else 32
+cin2 = int(sys.argv[7]) if len(sys.argv) > 7 else 0  # fused 1x1 projection of a cin2-channel tensor
 waves = 4
 nhwc.WINOGRAD, nhwc.WINO_MIN_TILES = True, 1
 conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda(); syn.fill_state_dict(conv, 1)
 x = torch.randn(B, H, W, cin, device="cuda")
 p = nhwc.Plan(x.device)
 out = p.buffer(B, H, W, cout)
-p.conv(nhwc.View(x, 0, cin), conv, out, act=1)
+proj = x2 = None
+if cin2:
+    proj = nn.Conv2d(cin2, cout, 1).cuda(); syn.fill_state_dict(proj, 2)
+    x2 = torch.randn(B, H, W, cin2, device="cuda")
+p.conv(nhwc.View(x, 0, cin), conv, out, act=1, x2=None if proj is None else nhwc.View(x2, 0, cin2), conv2=proj)
 op = p.ops[0]
 rows = 8
 tiles = B * (-(-H // rows)) * (-(-W // 32)) * (cout // 32)
@@ -28,7 +33,7 @@ p._arr = None
 for _ in range(3): p.run()
 torch.cuda.synchronize()
 t = tr.cpu().numpy().reshape(blocks, waves, 64).astype(np.int64)
-nS = (cin + 15) // 16 * 2
+nS = (cin + 15) // 16 * 2 + ((cin2 + 15) // 16 + 1) // 2
 print(f"{cin}->{cout} @{H}x{W} B={B} tile_n={tn}: {tiles} tiles on {blocks} persistent workgroups x {waves} waves, {nS} K steps per tile")
 med = lambda a: float(np.median(a))
 print(f"  workgroup life (entry -> exit)  {med(t[:, :, 62] - t[:, :, 0]):9.0f} cycles = {tiles / blocks:.1f} tiles -> {med(t[:, :, 62] - t[:, :, 0]) / (tiles / blocks):.0f} per tile")
