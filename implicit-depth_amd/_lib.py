@@ -130,14 +130,33 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
-def param_version(t) -> int:
-    """Version counter of a parameter (bumped by in-place updates: the packed-weight caches key on it).  Tensors
-    created under torch.inference_mode() do not track one — they cannot be modified in place outside inference mode
-    either, so a constant is a valid key for them."""
+_weights_epoch = 0
+
+
+def invalidate_weight_caches() -> None:
+    """Forget every packed-weight / plan cache entry keyed on parameters whose modifications torch does not count
+    (tensors created under ``torch.inference_mode()``).  Called automatically after ``load_state_dict`` on the drop-in
+    modules and ``HotPath``; call it by hand after any other in-place edit of inference-mode parameters
+    (``param.copy_()``, ``param.mul_()`` ... inside ``with torch.inference_mode():``)."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def watch_state_dict_loads(module) -> None:
+    """``module.load_state_dict()`` (on the module or any parent) invalidates the caches above."""
+    if not module.__dict__.get("_idh_sd_hook"):
+        module.register_load_state_dict_post_hook(lambda m, incompatible_keys: invalidate_weight_caches())
+        module.__dict__["_idh_sd_hook"] = True
+
+
+def param_version(t):
+    """Cache key component that changes when parameter ``t`` is modified in place: torch's version counter — or, for
+    tensors created under ``torch.inference_mode()`` (no counter, yet ``load_state_dict`` / ``copy_`` inside inference mode DO
+    modify them), the epoch bumped by ``invalidate_weight_caches()``."""
     try:
         return t._version
     except RuntimeError:
-        return -1
+        return ("inference", _weights_epoch)
 
 
 def require_cuda_f32(*tensors):

@@ -80,6 +80,7 @@ class CostVolumeManager(nn.Module):
 
     def __init__(self, matching_height, matching_width, num_depth_bins=64, matching_dim_size=None, num_source_views=None):
         super().__init__()
+        _lib.watch_state_dict_loads(self)  # load_state_dict invalidates packed-weight caches of inference-mode parameters
         self.num_depth_bins = num_depth_bins
         self.matching_height = matching_height
         self.matching_width = matching_width
@@ -284,7 +285,8 @@ class FeatureVolumeManager(CostVolumeManager):
         L = _lib.lib()
         D = self.num_depth_bins
         sc = scratch if scratch is not None else {}
-        key = ("fv", B, H, W, D, str(dev))
+        # per stream: two forwards of one HotPath on different HIP streams must not share the prologue's workspace
+        key = ("fv", B, H, W, D, str(dev), torch.cuda.current_stream().cuda_stream)
         if sc.get("fv_key") != key:
             wsb = L.idh_feature_volume_workspace_bytes(B)
             sc.update(fv_key=key, fv_wsb=wsb, fv_ws=torch.empty(max(wsb // 4, 1), device=dev), fv_planes=torch.empty(D, device=dev))

@@ -1024,11 +1024,16 @@ __global__ __launch_bounds__(256) void instnorm_stats_k(const float *__restrict_
     const int q = threadIdx.x % cq;
     const int prow = threadIdx.x / cq, pstep = 256 / cq;  // host guarantees cq divides 256
     const int p0 = chunk * kInChunk, p1 = min(HW, p0 + kInChunk);
+    // sums of (x - pivot) and (x - pivot)^2 with pivot = the image's first pixel: E[x^2] - mean^2 on the raw values cancels
+    // catastrophically for a channel whose |mean| is large against its spread (~(mean/std)^2 * 1e-7 relative; a biased 1x1 conv on
+    // ReLU features); shifted by any sample of the distribution the two terms are both of the order of the variance
+    const float4 pv = *reinterpret_cast<const float4 *>(in + (size_t)n * HW * cs + 4 * q);
     float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
     for (int p = p0 + prow; p < p1; p += pstep) {
         const float4 v = *reinterpret_cast<const float4 *>(in + ((size_t)n * HW + p) * cs + 4 * q);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        ss[0] = fmaf(v.x, v.x, ss[0]); ss[1] = fmaf(v.y, v.y, ss[1]); ss[2] = fmaf(v.z, v.z, ss[2]); ss[3] = fmaf(v.w, v.w, ss[3]);
+        const float d0 = v.x - pv.x, d1 = v.y - pv.y, d2 = v.z - pv.z, d3 = v.w - pv.w;
+        s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
+        ss[0] = fmaf(d0, d0, ss[0]); ss[1] = fmaf(d1, d1, ss[1]); ss[2] = fmaf(d2, d2, ss[2]); ss[3] = fmaf(d3, d3, ss[3]);
     }
     float *mine = red + threadIdx.x * 8;
     for (int e = 0; e < 4; ++e) { mine[e] = s[e]; mine[4 + e] = ss[e]; }
@@ -1042,10 +1047,10 @@ __global__ __launch_bounds__(256) void instnorm_stats_k(const float *__restrict_
     }
 }
 
-// mean / 1/sqrt(var + eps) per (image, channel) from the chunk partials, in fixed chunk order (deterministic);
-// stats[n][2][C] lives behind the partials in the same workspace
-__global__ __launch_bounds__(256) void instnorm_finalize_k(const float *__restrict__ part, int C, int HW, int nchunks,
-                                                           float *__restrict__ stats) {
+// mean / 1/sqrt(var + eps) per (image, channel) from the chunk partials (shifted by the image's first pixel, see above), in
+// fixed chunk order (deterministic); stats[n][2][C] lives behind the partials in the same workspace
+__global__ __launch_bounds__(256) void instnorm_finalize_k(const float *__restrict__ part, const float *__restrict__ in, int cs, int C, int HW,
+                                                           int nchunks, float *__restrict__ stats) {
     const int n = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f, ss = 0.f;
@@ -1054,9 +1059,9 @@ __global__ __launch_bounds__(256) void instnorm_finalize_k(const float *__restri
             s += o[0];
             ss += o[C];
         }
-        const float mean = s / (float)HW;
-        const float var = fmaxf(ss / (float)HW - mean * mean, 0.f);  // biased, as nn.InstanceNorm2d
-        stats[(size_t)n * 2 * C + c] = mean;
+        const float ms = s / (float)HW;                                    // mean - pivot
+        const float var = fmaxf(ss / (float)HW - ms * ms, 0.f);          // biased, as nn.InstanceNorm2d
+        stats[(size_t)n * 2 * C + c] = in[(size_t)n * HW * cs + c] + ms;
         stats[(size_t)n * 2 * C + C + c] = 1.0f / sqrtf(var + 1e-5f);
     }
 }
@@ -1532,7 +1537,7 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                                    nchunks, op.ws);
                 IDH_CHECK_LAUNCH();
                 float *stats = op.ws + (size_t)op.N * nchunks * 2 * C;
-                IDH_LAUNCH(instnorm_finalize_k, dim3(op.N), dim3(256), 0, st, op.ws, C, HW, nchunks, stats);
+                IDH_LAUNCH(instnorm_finalize_k, dim3(op.N), dim3(256), 0, st, op.ws, s.in, s.cs, C, HW, nchunks, stats);
                 IDH_CHECK_LAUNCH();
                 if (!op.out) break;  // statistics only: the consumer conv normalises on load (idh_conv_src.norm)
                 const long long total = (long long)op.N * HW * (C >> 2);

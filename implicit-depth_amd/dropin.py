@@ -124,7 +124,9 @@ def fused_forward(model: nn.Module, math: str = None):
     and the outputs runs as ONE fused pass of ``HotPath`` (matching-encoder head, volume, CVEncoder, decoder, occlusion
     MLP / depth heads) instead of module by module.  The third-party image encoder and ResNet18 stem still run as the
     model's own torch modules.  ``model.forward = fused_forward(model)`` installs it; the model's config / checkpoint
-    surface is untouched (the hot-path modules are converted in place and share their parameters with the pipeline)."""
+    surface is untouched (the hot-path modules are converted in place and share their parameters with the pipeline).
+    Side effects on the input dicts are the reference's: ``cur_data["prior_mask"]`` and, with ``bd_edge_regularision``,
+    ``cur_data["edge_mask"]`` (computed by the reference's own ``get_edge_mask``, which must then be importable)."""
     from . import _lib
 
     hot = hot_path_of(model, math=math)
@@ -166,6 +168,15 @@ def fused_forward(model: nn.Module, math: str = None):
             out = hot(mc, msrc, cur_feats, src_cam_T_cur_cam, cur_cam_T_src_cam, src_K, cur_invK, return_mask=return_mask, **kw)
         if "prior_mask" in out:
             cur_data["prior_mask"] = out.pop("prior_mask")  # run_mlp_val stores it on the inputs (bd_model.py:431)
+        if is_bd and getattr(opts, "bd_edge_regularision", False) and "depth_b1hw" in cur_data:
+            # run_mlp_val's other side effect (bd_model.py:444-447): the edge mask compute_binary_losses reads.  It is the
+            # reference's own loss-side helper (utils/generic_utils.py:286, needs kornia) — not part of this path
+            try:
+                from utils.generic_utils import get_edge_mask
+            except ImportError as e:
+                raise _lib.IdhError("run_opts.bd_edge_regularision needs the reference's utils.generic_utils.get_edge_mask (kornia) on the "
+                                    "import path to fill inputs['edge_mask']; unset the option for pure inference") from e
+            cur_data["edge_mask"] = get_edge_mask(cur_data["depth_b1hw"])
         return out
 
     return forward

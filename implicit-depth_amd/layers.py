@@ -7,12 +7,15 @@ from __future__ import annotations
 
 from torch import nn
 
+from . import _lib
+
 
 class BasicBlock(nn.Module):
     expansion = 1
 
     def __init__(self, inplanes: int, planes: int, stride: int = 1):
         super().__init__()
+        _lib.watch_state_dict_loads(self)  # load_state_dict invalidates packed-weight caches of inference-mode parameters
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=1, bias=True)
         if inplanes == planes and stride == 1:

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import _lib
 from .layers import BasicBlock
 
 
@@ -28,6 +29,7 @@ class CVEncoder(nn.Module):
 
     def __init__(self, num_ch_cv, num_ch_enc, num_ch_outs):
         super().__init__()
+        _lib.watch_state_dict_loads(self)  # load_state_dict invalidates packed-weight caches of inference-mode parameters
         self.convs = nn.ModuleDict()
         self.num_ch_enc = []
         self.num_blocks = len(num_ch_outs)
@@ -53,6 +55,7 @@ class _DecoderPP(nn.Module):
 
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
         super().__init__()
+        _lib.watch_state_dict_loads(self)  # load_state_dict invalidates packed-weight caches of inference-mode parameters
         self.num_output_channels = num_output_channels
         self.use_skips = use_skips
         self.upsample_mode = "nearest"
@@ -122,6 +125,7 @@ class BinaryMLPNetwork(nn.Module):
 
     def __init__(self, input_channels, mlp_size=128, use_prior=False):
         super().__init__()
+        _lib.watch_state_dict_loads(self)  # load_state_dict invalidates packed-weight caches of inference-mode parameters
         self.scales = list(range(4))
         self.use_prior = use_prior
         extra = 2 if use_prior else 1
@@ -150,6 +154,7 @@ class ResnetMatchingEncoder(nn.Module):
 
     def __init__(self, backbone_modules, num_ch_out: int = 16, backbone_channels: int = 64):
         super().__init__()
+        _lib.watch_state_dict_loads(self)  # load_state_dict invalidates packed-weight caches of inference-mode parameters
         backbone_modules = list(backbone_modules)
         if len(backbone_modules) != 5:
             raise ValueError("expected the 5 backbone modules conv1, bn1, relu, maxpool, layer1")
@@ -204,6 +209,7 @@ class SkipDecoder(nn.Module):
 
     def __init__(self, input_channels, use_bn=False):
         super().__init__()
+        _lib.watch_state_dict_loads(self)  # load_state_dict invalidates packed-weight caches of inference-mode parameters
         input_channels = list(input_channels)[::-1]
         self.input_channels = input_channels
         self.output_channels = [256, 128, 64, 64]

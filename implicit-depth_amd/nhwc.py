@@ -706,16 +706,61 @@ def math_of(module: nn.Module) -> str:
     return getattr(module, "conv_math", None) or DEFAULT_MATH
 
 
-def _plan_cache(module: nn.Module) -> Dict:
+PLAN_CACHE_ENTRIES = 4
+
+
+class PlanCache:
+    """Small LRU of execution plans (one entry = ops + all activation buffers of one input shape): an evaluation loop whose last
+    batch is ragged, or a caller alternating two layouts / batch sizes, replays instead of rebuilding; the oldest entry (and its
+    buffers) goes when a fifth shape arrives."""
+
+    def __init__(self, entries: int = PLAN_CACHE_ENTRIES):
+        import collections
+
+        self.entries = entries
+        self.d = collections.OrderedDict()
+
+    def get(self, key):
+        ent = self.d.get(key)
+        if ent is not None:
+            self.d.move_to_end(key)
+        return ent
+
+    def put(self, key, ent):
+        self.d[key] = ent
+        self.d.move_to_end(key)
+        while len(self.d) > self.entries:
+            self.d.popitem(last=False)
+        return ent
+
+    def values(self):
+        return self.d.values()
+
+    def __len__(self):
+        return len(self.d)
+
+    def clear(self):
+        self.d.clear()
+
+
+def build_flags() -> tuple:
+    """Module-level switches that shape a plan at build time (part of every plan-cache key: toggling one takes effect on the
+    next call instead of silently replaying a plan built under the old setting)."""
+    return (FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
+            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, DEFAULT_MATH)
+
+
+def _plan_cache(module: nn.Module) -> PlanCache:
     c = module.__dict__.get("_idh_plans")
     if c is None:
-        c = {}
+        c = PlanCache()
         module.__dict__["_idh_plans"] = c
+        _lib.watch_state_dict_loads(module)
     return c
 
 
 def _param_key(module: nn.Module):
-    return (math_of(module),) + tuple((p.data_ptr(), _lib.param_version(p)) for p in module.parameters())
+    return (math_of(module), build_flags()) + tuple((p.data_ptr(), _lib.param_version(p)) for p in module.parameters())
 
 
 def _check_in(*ts):
@@ -733,7 +778,6 @@ def block_forward_nchw(blk, x: torch.Tensor) -> torch.Tensor:
     cache = _plan_cache(blk)
     ent = cache.get(key)
     if ent is None:
-        cache.clear()
         p = Plan(x.device, math=math_of(blk))
         N, Cc, H, W = x.shape
         xin = p.buffer(N, H, W, Cc)
@@ -742,7 +786,7 @@ def block_forward_nchw(blk, x: torch.Tensor) -> torch.Tensor:
         i_out = p.export_nchw(y)
         p.schedule()
         ent = (p, i_in, i_out, y)
-        cache[key] = ent
+        cache.put(key, ent)
     p, i_in, i_out, y = ent
     out = torch.empty(y.N, y.C, y.H, y.W, device=x.device, dtype=torch.float32)
     p.set_in(i_in, x)
@@ -784,7 +828,6 @@ def cv_encoder_forward_nchw(enc, x: torch.Tensor, img_feats: List[torch.Tensor])
     cache = _plan_cache(enc)
     ent = cache.get(key)
     if ent is None:
-        cache.clear()
         p = Plan(x.device, math=math_of(enc))
         N, D, H, W = x.shape
         xin = p.buffer(N, H, W, D)
@@ -793,7 +836,7 @@ def cv_encoder_forward_nchw(enc, x: torch.Tensor, img_feats: List[torch.Tensor])
         i_out = [p.export_nchw(o) for o in outs]
         p.schedule()
         ent = (p, i_x, i_img, i_out, outs)
-        cache[key] = ent
+        cache.put(key, ent)
     p, i_x, i_img, i_out, outs = ent
     res = [torch.empty(o.N, o.C, o.H, o.W, device=x.device, dtype=torch.float32) for o in outs]
     p.set_in(i_x, x)
@@ -857,7 +900,6 @@ def decoder_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dict[str, t
     cache = _plan_cache(dec)
     ent = cache.get(key)
     if ent is None:
-        cache.clear()
         p = Plan(feats[0].device, math=math_of(dec))
         views, i_in = [], []
         for f in feats:
@@ -873,7 +915,7 @@ def decoder_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dict[str, t
                 i_out[i] = p.export_nchw(v)
         p.schedule()
         ent = (p, i_in, i_out, final)
-        cache[key] = ent
+        cache.put(key, ent)
     p, i_in, i_out, final = ent
     for i, f in zip(i_in, feats):
         p.set_in(i, f)
@@ -936,7 +978,6 @@ def matching_head_forward(enc, feat_nchw: torch.Tensor, channels_last: bool = Fa
     cache = _plan_cache(enc)
     ent = cache.get(key)
     if ent is None:
-        cache.clear()
         p = Plan(x.device, math=math_of(enc))
         N, Cc, H, W = x.shape
         if FUSE_HEAD_IMPORT and Plan.pointwise_nchw_eligible(enc.net[5]):
@@ -948,7 +989,7 @@ def matching_head_forward(enc, feat_nchw: torch.Tensor, channels_last: bool = Fa
         i_out = None if channels_last else p.export_nchw(y)
         p.schedule()
         ent = (p, i_in, i_out, y)
-        cache[key] = ent
+        cache.put(key, ent)
     p, i_in, i_out, y = ent
     p.set_in(i_in, x)
     if channels_last:
@@ -1018,7 +1059,6 @@ def skip_regression_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dic
     cache = _plan_cache(dec)
     ent = cache.get(key)
     if ent is None:
-        cache.clear()
         p = Plan(feats[0].device, math=math_of(dec))
         views, i_in = [], []
         for f in feats:
@@ -1031,7 +1071,7 @@ def skip_regression_forward_nchw(dec, input_features: List[torch.Tensor]) -> Dic
         i_head = {i: p.head(hv, last, torch.empty(1, device=feats[0].device)) for i, (hv, last) in heads.items()}
         p.schedule()
         ent = (p, i_in, i_feat, i_head, final)
-        cache[key] = ent
+        cache.put(key, ent)
     p, i_in, i_feat, i_head, final = ent
     for i, f in zip(i_in, feats):
         p.set_in(i, f)

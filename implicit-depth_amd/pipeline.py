@@ -46,7 +46,8 @@ class HotPath(nn.Module):
         self.matching_model = matching_model  # ResnetMatchingEncoder (drop-in or reference): its net[5:] head runs here
         self.min_depth, self.max_depth = float(min_depth), float(max_depth)
         self.thresholder = None  # like BDModel.thresholder (bd_model.py:141): per-depth thresholds of the infer_depth search
-        self._plans: Dict = {}
+        self._plans = nhwc.PlanCache()  # LRU: a ragged last batch / alternating shapes replay instead of rebuilding
+        _lib.watch_state_dict_loads(self)
 
     # ------------------------------------------------------------------------------------
     def _plan(self, B, K, C, H, W, enc_shapes: Sequence[Sequence[int]], device, head: Optional[str] = None, head_ch: int = 0):
@@ -58,7 +59,6 @@ class HotPath(nn.Module):
         ent = self._plans.get(key)
         if ent is not None:
             return ent
-        self._plans.clear()
         D = self.cost_volume.num_depth_bins
         p = nhwc.Plan(device, math=self.conv_math)
         st = {"lowest": None, "planes": torch.empty(D, device=device)}
@@ -106,8 +106,7 @@ class HotPath(nn.Module):
                 ent["heads"][i] = p.head(hv, last, torch.empty(1, device=device))
         # the volume kernel runs between the matching head and the CVEncoder: two replay segments of one plan
         ent["n_head_ops"] = p.schedule_segments(n_pre)
-        self._plans[key] = ent
-        return ent
+        return self._plans.put(key, ent)
 
     # ------------------------------------------------------------------------------------
     def forward(self, matching_cur_feats: Optional[torch.Tensor], matching_src_feats: Optional[torch.Tensor], cur_feats: List[torch.Tensor],

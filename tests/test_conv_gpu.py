@@ -145,6 +145,24 @@ def test_matching_head_golden_and_layouts():
     assert rel_err(enc(img).cpu(), ref) < TOL
 
 
+def test_instance_norm_of_a_channel_with_a_large_mean():
+    """nn.InstanceNorm2d on a channel whose |mean| is ~1e3 x its spread (a biased 1x1 conv on ReLU features): E[x^2] - mean^2 on
+    the raw fp32 values loses ~(mean/std)^2 * 1e-7 = 10 % of the variance; the kernels accumulate around a pivot instead."""
+    from implicit_depth_amd import nhwc
+
+    N, H, W, C = 2, 40, 48, 32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g)
+    x[..., : C // 2] += 1000.0  # mean / std = 1e3
+    x[..., C // 2 :] *= 50.0
+    p = nhwc.Plan(x.device)
+    out = p.buffer(N, H, W, C)
+    p.instance_norm(nhwc.View(x, 0, C), out)
+    p.run()
+    ref = torch.nn.functional.instance_norm(x.permute(0, 3, 1, 2).double()).permute(0, 2, 3, 1)
+    assert rel_err(out.dense().cpu(), ref.cpu()) < 1e-4
+
+
 @pytest.mark.parametrize("reg", [False, True])
 def test_skip_decoder_golden(reg):
     """SkipDecoder / SkipDecoderRegression (networks_fast.py): ELU convs, nearest x2, concat, 1x1 heads."""

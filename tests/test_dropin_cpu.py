@@ -1,5 +1,6 @@
 """Structure-driven conversion (implicit_depth_amd.dropin): channel configs are inferred from
 the module being replaced and the state_dict transfers 1:1.  CPU only (no kernels run)."""
+import pytest
 import torch
 
 import implicit_depth_amd.synthetic as syn
@@ -52,3 +53,49 @@ def test_feature_mlp_column_maps_are_a_permutation_of_the_reference_layout():
         n_in = 16 * (K + 1) + 10 * K + 4
         assert sorted(used) == list(range(n_in)), "every reference MLP input column appears exactly once"
         assert len(vox) == 16 * (K + 4) and len(pix) == 32 and len(pose) == 3 * K
+
+
+def test_inference_mode_parameters_invalidate_weight_caches_on_load_state_dict():
+    """Parameters created under torch.inference_mode() have no version counter, yet load_state_dict() / copy_() inside
+    inference mode do modify them (test_bd.py builds and loads the model that way): the cache key component must change
+    when a drop-in module's state dict is (re)loaded, and on explicit invalidation."""
+    import torch
+
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd.layers import BasicBlock
+
+    with torch.inference_mode():
+        bb = BasicBlock(16, 16)
+        w = bb.conv1.weight
+        with pytest.raises(RuntimeError):
+            w._version
+        k0 = _lib.param_version(w)
+        assert k0 == _lib.param_version(w)
+        bb.load_state_dict({k: v * 2 for k, v in bb.state_dict().items()})
+        k1 = _lib.param_version(w)
+        assert k1 != k0, "load_state_dict on the module must change the key"
+        parent = torch.nn.Sequential(bb)
+        parent.load_state_dict(parent.state_dict())
+        assert _lib.param_version(w) != k1, "load_state_dict on a parent module must change it too"
+        k2 = _lib.param_version(w)
+        w.mul_(0.5)  # not observable: documented to need the explicit call
+        _lib.invalidate_weight_caches()
+        assert _lib.param_version(w) != k2
+    # ordinary parameters keep using torch's counter
+    bb2 = BasicBlock(16, 16)
+    v0 = _lib.param_version(bb2.conv1.weight)
+    with torch.no_grad():
+        bb2.conv1.weight.mul_(0.5)
+    assert _lib.param_version(bb2.conv1.weight) == v0 + 1
+
+
+def test_plan_cache_is_a_small_lru():
+    from implicit_depth_amd import nhwc
+
+    c = nhwc.PlanCache(entries=3)
+    for k in "abc":
+        c.put(k, k.upper())
+    assert c.get("a") == "A"          # refreshes "a"
+    c.put("d", "D")                    # evicts the least recently used: "b"
+    assert c.get("b") is None and c.get("a") == "A" and c.get("c") == "C" and c.get("d") == "D" and len(c) == 3
+    assert isinstance(nhwc.build_flags(), tuple) and nhwc.WINOGRAD in nhwc.build_flags()

@@ -152,3 +152,34 @@ def test_model_built_under_inference_mode():
         out2 = model(d["cur_feats"], d["src_feats"], [t.cuda() for t in pyr], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
                      rendered_depth=rd.cuda())
     assert torch.equal(out["pred_0"], out2["pred_0"]) and bool(torch.isfinite(out["pred_0"]).all())
+
+
+def test_plan_cache_replays_alternating_batch_sizes():
+    """An eval loop whose last batch is ragged (every scan of test_bd.py:146-152), or a caller alternating two batch sizes,
+    must replay cached plans: the plan objects and their buffers stay the same, and the results do not change."""
+    (B1, B2), K, H, W, D, P = (3, 2), 2, 16, 32, 16, 2
+    model, inp, pyr, rd = _build(B1, K, H, W, D, P)
+    model.cuda()
+
+    def run(nb):
+        d = {k: v[:nb].cuda() for k, v in inp.items()}
+        return model(d["cur_feats"], d["src_feats"], [t[:nb].cuda() for t in pyr], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
+                     rendered_depth=rd[:nb].cuda())["pred_0"].clone()
+
+    y1 = run(B1)
+    ents = [id(e["plan"]) for e in model._plans.values()]
+    y2 = run(B2)
+    assert len(model._plans) == 2
+    for _ in range(2):
+        assert torch.equal(run(B1), y1) and torch.equal(run(B2), y2)
+    assert len(model._plans) == 2 and ents[0] in [id(e["plan"]) for e in model._plans.values()], "the first plan was rebuilt"
+    # a build-time switch is part of the key: toggling it builds a new plan instead of replaying the stale one
+    from implicit_depth_amd import nhwc
+
+    old = nhwc.MERGE_LEVELS
+    nhwc.MERGE_LEVELS = not old
+    try:
+        y1b = run(B1)
+        assert len(model._plans) == 3 and rel_err(y1b.cpu(), y1.cpu()) < 1e-6
+    finally:
+        nhwc.MERGE_LEVELS = old
