@@ -59,6 +59,7 @@ def parse(argv=None):
     ap.add_argument("--planes", type=int, default=0, help="depth planes D; 0 = 64 (96 for --workload temporal)")
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--sequences", type=int, default=1, help="--workload temporal: independent sequences per GPU in one batch, each carrying its own prior")
     ap.add_argument("--no-head", action="store_true", help="start at finished matching features (round-1 workload) instead of the layer1 map")
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "f16x3"],
                     help="arithmetic of the 3x3 stride-1 convs: fp32 MFMA (default) or the fp32-equivalent split-precision kernels")
@@ -415,10 +416,12 @@ class HotPathWorkload:
 
 
 class TemporalWorkload(HotPathWorkload):
-    """BASELINE.json configs[4] as the reference runs it (inference/inference.py:139-157): B=1, 8-frame tuple, D=96
-    planes, prior-enabled occlusion MLP, ONE query plane at 2 m (the `plane_2.0` asset), the previous frame's
-    sigmoid(pred_0) + cam_T_world carried as the prior.  Frames of a sequence are serially dependent, so a step = one
-    frame and GPUs run independent sequences (weak scaling)."""
+    """BASELINE.json configs[4] as the reference runs it (inference/inference.py:139-157): 8-frame tuple, D=96 planes,
+    prior-enabled occlusion MLP, ONE query plane at 2 m (the `plane_2.0` asset), the previous frame's sigmoid(pred_0) +
+    cam_T_world carried as the prior.  Frames of a sequence are serially dependent, so a step = one frame of each of the
+    S independent sequences a GPU runs side by side in one batch (``--sequences``, default 1 = the reference's loop; every
+    sequence has its own camera track and its own carried prior), and GPUs run disjoint sets of sequences (weak scaling;
+    SURVEY.md §8e)."""
 
     name = "temporal"
     scaling = "weak"
@@ -427,26 +430,31 @@ class TemporalWorkload(HotPathWorkload):
 
     def __init__(self, args, device, rank):
         a = copy.copy(args)
-        a.batch = 1  # one sequence per GPU
+        self.S = max(1, int(getattr(args, "sequences", 1)))
+        a.batch = self.S  # S sequences per GPU, one frame of each per step
         super().__init__(a, device, rank)
         import implicit_depth_amd.synthetic as syn
 
-        self.rd = torch.full((1, 1, self.Hi // 2, self.Wi // 2), 2.0, device=device)
+        S = self.S
+        self.rd = torch.full((S, 1, self.Hi // 2, self.Wi // 2), 2.0, device=device)
         self.host_rd = self.rd.cpu()
         K0 = syn.intrinsics(self.Wi // 2, self.Hi // 2).float()
-        self.K0, self.invK0 = K0[None].to(device), torch.linalg.inv(K0)[None].to(device)
-        # camera drifts 5 cm / frame along x: the prior is re-projected with a real motion every frame
+        self.K0, self.invK0 = K0[None].expand(S, 4, 4).contiguous().to(device), torch.linalg.inv(K0)[None].expand(S, 4, 4).contiguous().to(device)
+        # sequence s drifts (5 + s/2) cm / frame along x and s mm / frame along y: the prior is re-projected with a real,
+        # sequence-specific motion every frame
         self.poses = []
         for t in range(64):
-            T = torch.eye(4)
-            T[0, 3] = 0.05 * t
-            self.poses.append((T[None].to(device), torch.linalg.inv(T)[None].to(device)))  # world_T_cam, cam_T_world
+            T = torch.eye(4).repeat(S, 1, 1)
+            for q in range(S):
+                T[q, 0, 3] = (0.05 + 0.005 * q) * t
+                T[q, 1, 3] = 0.001 * q * t
+            self.poses.append((T.to(device), torch.linalg.inv(T).to(device)))  # world_T_cam, cam_T_world
         self.t = 0
         self.prev = None
 
     def metric(self):
         return (f"frames/sec (temporal BDModel.forward hot path, {self.Wi}x{self.Hi}, {self.D} planes, {self.K + 1}-frame tuple, "
-                "prior carried frame to frame, B=1 per GPU)")
+                f"prior carried frame to frame, {self.S} sequence(s) per GPU)")
 
     def step(self, ev=None):
         if ev is not None:
@@ -631,24 +639,52 @@ def main():
             with torch.inference_mode():
                 out["warp_match"] = WarpMatchDot(a3, device, rank).kernel_roofline()
             torch.cuda.empty_cache()
-            if world == 1:  # BASELINE.json configs[4]: the temporal loop, B=1, D=96, prior carried over 48 frames
-                a4 = copy.copy(args)
-                a4.planes, a4.views, a4.volume = 96, 7, "mlp"
-                tw = TemporalWorkload(a4, device, rank)
+            if world == 1:  # BASELINE.json configs[4]: the temporal loop, D=96, prior carried over 48 frames
+                def temporal_run(S):
+                    a4 = copy.copy(args)
+                    a4.planes, a4.views, a4.volume, a4.sequences = 96, 7, "mlp", S
+                    tw = TemporalWorkload(a4, device, rank)
+                    with torch.inference_mode():
+                        for _ in range(8):
+                            tw.step()
+                        torch.cuda.synchronize()
+                        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(48)]
+                        t0 = time.perf_counter()
+                        for e in evs:
+                            tw.step(e)
+                        torch.cuda.synchronize()
+                        el = time.perf_counter() - t0
+                    ts = [a.elapsed_time(b) for a, b in evs]
+                    cfg = tw.config()["workload"]
+                    del tw
+                    torch.cuda.empty_cache()
+                    return {"value": S * len(evs) / el, "unit": "frames/s", "sequences": S, "frames": S * len(evs), "ms_per_step_median_hip_events": _median(ts)}, cfg
+
+                one, cfg = temporal_run(1)  # the reference's loop: one sequence, one frame at a time
+                out["temporal"] = {"value": one["value"], "unit": "frames/s", "frames": one["frames"],
+                                   "ms_per_frame_median_hip_events": one["ms_per_step_median_hip_events"], "config": cfg,
+                                   # S independent sequences per GPU in one batch, each carrying its own prior (how the path shards
+                                   # "by sequence"): frames/s of all S sequences together
+                                   "sequences_per_gpu": {"1": one, "4": temporal_run(4)[0], "8": temporal_run(8)[0]}}
+            if args.volume == "mlp" and args.views != 8:
+                # BASELINE.json's literal "8 source views" through the whole path (the headline is the reference-native 8-frame
+                # tuple = 7 source views): same batch, D, head and query planes, K = 8
+                a5 = copy.copy(args)
+                a5.views = 8
+                w8 = HotPathWorkload(a5, device, rank)
                 with torch.inference_mode():
-                    for _ in range(8):
-                        tw.step()
+                    for _ in range(3):
+                        w8.step()
                     torch.cuda.synchronize()
-                    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(48)]
                     t0 = time.perf_counter()
-                    for e in evs:
-                        tw.step(e)
+                    for _ in range(10):
+                        w8.step()
                     torch.cuda.synchronize()
-                    el = time.perf_counter() - t0
-                ts = [a.elapsed_time(b) for a, b in evs]
-                out["temporal"] = {"value": len(evs) / el, "unit": "frames/s", "frames": len(evs), "ms_per_frame_median_hip_events": _median(ts),
-                                   "config": tw.config()["workload"]}
-                del tw
+                    el8 = (time.perf_counter() - t0) / 10
+                out["k8"] = {"value": frames_per_step_total / el8, "unit": "frames/s", "ms_per_step": el8 * 1e3, "source_views": 8,
+                             "depth_planes": a5.planes, "per_gpu_batch": w8.B, "volume": "mlp", "steps": 10,
+                             "note": "whole hot path with K = 8 source views (BASELINE.json's literal configuration); rank-0 rate x ranks"}
+                del w8
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
