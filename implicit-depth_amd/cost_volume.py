@@ -184,17 +184,20 @@ def feature_mlp_column_maps(K: int, C: int = 16):
     base_r = base + 4 * K + 1
     col_ray = lambda k, e: base_r + 3 + 3 * k + e
     base_p = base_r + 3 * (K + 1)
-    voxel = list(range(C * K))  # blocks 0..K-1: warped features, identity order
-    for cblk in range(4):
+    voxel = list(range(C * K))  # K * C/16 blocks: warped features, identity order
+    # metadata blocks: lane quarter q carries, for each of its J views v = q + 4j, [mask, z, dot, ray angle, ray xyz] at
+    # 7j..7j+6, and (quarter 0) the plane depth at 7J.  J = 2 for K <= 8 (fv_mlp_k's fixed layout), else ceil(K/4)
+    # (fv_mlp_gen_k); ceil((7J+1)/4) blocks of 16 columns
+    J = 2 if K <= 8 else -(-K // 4)
+    for cblk in range(-(-(7 * J + 1) // 4)):
         for q in range(4):
             for kk in range(4):
-                j = 4 * cblk + kk
-                v = q if j < 7 else q + 4
-                jj = j % 7 if j < 14 else j
+                idx = 4 * cblk + kk
+                v = q + 4 * (idx // 7)
                 col = -1
-                if j < 14 and v < K:
-                    col = [col_mask(v), col_z(v), col_dot(v), col_ang(v), col_ray(v, 0), col_ray(v, 1), col_ray(v, 2)][jj]
-                elif j == 14 and q == 0:
+                if idx < 7 * J and v < K:
+                    col = [col_mask(v), col_z(v), col_dot(v), col_ang(v), col_ray(v, 0), col_ray(v, 1), col_ray(v, 2)][idx % 7]
+                elif idx == 7 * J and q == 0:
                     col = col_plane
                 voxel.append(col)
     pixel = [C * K + i for i in range(C)]  # block 0: current-view features
@@ -243,8 +246,10 @@ class FeatureVolumeManager(CostVolumeManager):
         K, C = self.num_source_views, self.matching_dim_size
         w1, w2, w3 = (l.weight.detach() for l in lins)
         _lib.require_cuda_f32(w1, w2, w3)
-        if w1.shape[0] != 128 or tuple(w2.shape) != (128, 128) or tuple(w3.shape) != (1, 128) or C != 16:
-            raise _lib.IdhError("feature-volume kernel is specialised for C=16, MLP widths [*,128,128,1]")
+        if w1.shape[0] != 128 or tuple(w2.shape) != (128, 128) or tuple(w3.shape) != (1, 128) or C not in (16, 32) or K > 16:
+            raise _lib.IdhError("feature-volume kernels cover matching_dim_size 16 / 32, up to 16 source views and MLP widths [*,128,128,1]")
+        if math == "f16x3" and (C != 16 or K > 8):
+            raise _lib.IdhError("the split-precision feature volume covers matching_dim_size 16 and up to 8 source views")
         vox, pix, pose = feature_mlp_column_maps(K, C)
         dev = w1.device
         w1e = torch.cat([w1, torch.zeros(128, 1, device=dev)], 1)

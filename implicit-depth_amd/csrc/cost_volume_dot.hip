@@ -84,8 +84,11 @@ __device__ __forceinline__ float dot16(const float4 &a0, const float4 &a1, const
     return s;
 }
 
-__global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,   // B,N,16
-                                                const float *__restrict__ src,   // B,K,N,16
+// CQ = matching feature channels / 16: 1 for every shipped configuration (options.py:138 matching_feature_dims = 16); 2 / 4 cover
+// matching_feature_dims = 32 / 64 on this kernel only (the quad / window kernels are specialised for 64-byte texels)
+template <int CQ>
+__global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,   // B,N,16 CQ
+                                                const float *__restrict__ src,   // B,K,N,16 CQ
                                                 const float *__restrict__ src_K, // B,K,4,4
                                                 const float *__restrict__ src_E, // B,K,4,4
                                                 const float *__restrict__ cur_invK,  // B,4,4
@@ -124,9 +127,26 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
     const int y = p / W, x = p - y * W;
     const float pxf = (float)x + 0.5f, pyf = (float)y + 0.5f;
 
-    const float4 *cp = reinterpret_cast<const float4 *>(cur + (size_t)b * ext.cur_bs + (size_t)p * kC);
+    constexpr int kCc = kC * CQ;  // channels of this instantiation
+    const float4 *cp = reinterpret_cast<const float4 *>(cur + (size_t)b * ext.cur_bs + (size_t)p * kCc);
     const float *pl = ext.planes ? ext.planes + (size_t)b * ext.planes_sb + (size_t)p * ext.planes_sp : nullptr;
-    const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+    float4 cc[4 * CQ];
+#pragma unroll
+    for (int i = 0; i < 4 * CQ; ++i) cc[i] = cp[i];
+    auto tapdot = [&](const float *t) {  // <cur, texel> in channel order, one fmaf chain (as dot16)
+        const float4 *tp = reinterpret_cast<const float4 *>(t);
+        float sacc = dot16(cc[0], cc[1], cc[2], cc[3], tp);
+#pragma unroll
+        for (int i = 1; i < CQ; ++i) {
+            const float4 b0 = tp[4 * i], b1 = tp[4 * i + 1], b2 = tp[4 * i + 2], b3 = tp[4 * i + 3];
+            const float4 a0 = cc[4 * i], a1 = cc[4 * i + 1], a2 = cc[4 * i + 2], a3 = cc[4 * i + 3];
+            sacc = fmaf(a0.x, b0.x, sacc); sacc = fmaf(a0.y, b0.y, sacc); sacc = fmaf(a0.z, b0.z, sacc); sacc = fmaf(a0.w, b0.w, sacc);
+            sacc = fmaf(a1.x, b1.x, sacc); sacc = fmaf(a1.y, b1.y, sacc); sacc = fmaf(a1.z, b1.z, sacc); sacc = fmaf(a1.w, b1.w, sacc);
+            sacc = fmaf(a2.x, b2.x, sacc); sacc = fmaf(a2.y, b2.y, sacc); sacc = fmaf(a2.z, b2.z, sacc); sacc = fmaf(a2.w, b2.w, sacc);
+            sacc = fmaf(a3.x, b3.x, sacc); sacc = fmaf(a3.y, b3.y, sacc); sacc = fmaf(a3.z, b3.z, sacc); sacc = fmaf(a3.w, b3.w, sacc);
+        }
+        return sacc;
+    };
 
     const int DP = (D + kGroups - 1) / kGroups;
     const int d0 = g * DP;
@@ -165,11 +185,11 @@ __global__ __launch_bounds__(256) void cv_dot_k(const float *__restrict__ cur,  
             const float wy1 = (y0 + 1 < H) ? fy : 0.f;
             const int xa0 = min(max(x0, 0), W - 1), xa1 = min(x0 + 1, W - 1);
             const int ya0 = min(max(y0, 0), H - 1), ya1 = min(y0 + 1, H - 1);
-            const float *sb = src + (size_t)b * ext.src_bs + (size_t)k * N * kC;
-            const float t00 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya0 * W + xa0) * kC));
-            const float t01 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya0 * W + xa1) * kC));
-            const float t10 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya1 * W + xa0) * kC));
-            const float t11 = dot16(c0, c1, c2, c3, reinterpret_cast<const float4 *>(sb + (size_t)(ya1 * W + xa1) * kC));
+            const float *sb = src + (size_t)b * ext.src_bs + (size_t)k * N * kCc;
+            const float t00 = tapdot(sb + (size_t)(ya0 * W + xa0) * kCc);
+            const float t01 = tapdot(sb + (size_t)(ya0 * W + xa1) * kCc);
+            const float t10 = tapdot(sb + (size_t)(ya1 * W + xa0) * kCc);
+            const float t11 = tapdot(sb + (size_t)(ya1 * W + xa1) * kCc);
             const float top = fmaf(wx1, t01, wx0 * t00);
             const float bot = fmaf(wx1, t11, wx0 * t10);
             acc += fmaf(wy1, bot, wy0 * top);
@@ -808,7 +828,8 @@ static void cv_win_split(int B, int K, int H, int W, int D, int *psplit, int *un
 }
 
 // 0 = automatic; otherwise the caller's choice when that kernel covers the shape (else -1)
-static int cv_pick_kernel(int forced, int B, int K, int H, int W, int D) {
+static int cv_pick_kernel(int forced, int B, int K, int H, int W, int D, int C = kC) {
+    if (C != kC) return (forced == 0 || forced == IDH_CV_KERNEL_LANE) ? IDH_CV_KERNEL_LANE : -1;  // wider texels: the lane kernel only
     const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;  // 32-bit tap offsets within one (b,k) image
     const bool win_ok = quad_ok && W >= kWW && H >= kWH && W < 32768 && H < 32768 && K <= kMaxPairs;  // PlaneBox / WinEntry pack coordinates in 15 / 16 bits
     (void)D;
@@ -824,14 +845,14 @@ static int cv_pick_kernel(int forced, int B, int K, int H, int W, int D) {
     }
 }
 
-static int cv_resolve_ext(const idh_volume_opts *o, int K, int H, int W, CvExt *e) {
+static int cv_resolve_ext(const idh_volume_opts *o, int K, int H, int W, CvExt *e, int C = kC) {
     const long long N = (long long)H * W;
     e->planes = nullptr; e->planes_sb = e->planes_sd = 0; e->planes_sp = 0;
-    e->cur_bs = N * kC; e->src_bs = (long long)K * N * kC;
+    e->cur_bs = N * C; e->src_bs = (long long)K * N * C;
     if (!o) return IDH_OK;
     if (o->cur_batch_stride) e->cur_bs = o->cur_batch_stride;
     if (o->src_batch_stride) e->src_bs = o->src_batch_stride;
-    if (e->cur_bs < N * kC || e->src_bs < (long long)K * N * kC || (e->cur_bs & 3) || (e->src_bs & 3)) return IDH_EINVAL;
+    if (e->cur_bs < N * C || e->src_bs < (long long)K * N * C || (e->cur_bs & 3) || (e->src_bs & 3)) return IDH_EINVAL;
     if (o->planes) {
         if (o->planes_pixel_stride != 0 && o->planes_pixel_stride != 1) return IDH_EINVAL;
         e->planes = o->planes; e->planes_sb = o->planes_batch_stride; e->planes_sd = o->planes_plane_stride;
@@ -848,15 +869,15 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
     const bool own_planes = opts && opts->planes;
     if (B < 0 || K < 0 || H <= 0 || W <= 0 || D <= 0) return IDH_EINVAL;
     if (!own_planes && (!(dmin > 0.f) || !(dmax > 0.f))) return IDH_EINVAL;
-    if (C != kC || D > kMaxPlanes || K > IDH_MAX_SOURCE_VIEWS) return IDH_EUNSUPPORTED;
+    if ((C != kC && C != 2 * kC && C != 4 * kC) || D > kMaxPlanes || K > IDH_MAX_SOURCE_VIEWS) return IDH_EUNSUPPORTED;
     if (B == 0) return IDH_OK;
     if (cost_nhwc_cs != 0 && cost_nhwc_cs < D) return IDH_EINVAL;
     if (!cur_nhwc || !cost || !cur_invK_44 || (K > 0 && (!src_nhwc || !src_K_44 || !src_E_44)))
         return IDH_EINVAL;
     CvExt ext;
-    if (int rc = cv_resolve_ext(opts, K, H, W, &ext)) return rc;
+    if (int rc = cv_resolve_ext(opts, K, H, W, &ext, C)) return rc;
     if (own_planes) { planes_d = nullptr; dmin = dmax = 1.f; }
-    const int which = cv_pick_kernel(opts ? opts->kernel : 0, B, K, H, W, D);
+    const int which = cv_pick_kernel(opts ? opts->kernel : 0, B, K, H, W, D, C);
     if (which < 0) return IDH_EINVAL;
     if (which == IDH_CV_KERNEL_WINDOW) {
         WinArgs a{};
@@ -886,9 +907,13 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
         return IDH_OK;
     }
     const int tiles = idh_cdiv((long long)H * W, kTilePx);
-    hipLaunchKernelGGL(cv_dot_k, dim3((unsigned)(B * tiles)), dim3(256), 0, idh_stream(stream), cur_nhwc,
-                       src_nhwc, src_K_44, src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles, cost_nhwc_cs,
-                       cost, lowest_bhw, planes_d, ext);
+#define IDH_LANE(CQ_)                                                                                                         \
+    hipLaunchKernelGGL(cv_dot_k<CQ_>, dim3((unsigned)(B * tiles)), dim3(256), 0, idh_stream(stream), cur_nhwc, src_nhwc, src_K_44, \
+                       src_E_44, cur_invK_44, dmin, dmax, B, K, H, W, D, tiles, cost_nhwc_cs, cost, lowest_bhw, planes_d, ext)
+    if (C == kC) IDH_LANE(1);
+    else if (C == 2 * kC) IDH_LANE(2);
+    else IDH_LANE(4);
+#undef IDH_LANE
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }

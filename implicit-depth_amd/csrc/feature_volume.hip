@@ -36,11 +36,11 @@ constexpr int kHid = 128;
 constexpr int kNS = 8;            // 128 / 16
 constexpr int kMaxK = 8;          // LDS budget: (K+4)*8 KiB + 64 KiB = 160 KiB exactly at K = 8 (b2 / w3 stay in L1)
 
-// per-b workspace layout (floats): [0,96) hom[k][12]   [96,128) tsrc[k][4]   [128,137) invK 3x3
-//                                  [144, 144+128) bias1_b
-constexpr int kWsHom = 0, kWsT = 96, kWsInvK = 128, kWsBias = 144;
-static_assert(kWsBias + kHid <= 272, "workspace layout");
-constexpr int kWsStrideReal = 272;
+// per-b workspace layout (floats), sized for IDH_MAX_SOURCE_VIEWS = 16 views: [0,192) hom[k][12]   [192,256) tsrc[k][4]
+//                                  [256,265) invK 3x3   [272, 272+128) bias1_b
+constexpr int kWsHom = 0, kWsT = 192, kWsInvK = 256, kWsBias = 272;
+static_assert(kWsT == 12 * IDH_MAX_SOURCE_VIEWS && kWsInvK == kWsT + 4 * IDH_MAX_SOURCE_VIEWS && kWsBias + kHid <= 400, "workspace layout");
+constexpr int kWsStrideReal = 400;
 
 __device__ __forceinline__ float lrelu01(float x) { return x >= 0.f ? x : x * 0.01f; }
 
@@ -61,7 +61,7 @@ __global__ void fv_setup_k(const float *__restrict__ src_K, const float *__restr
                            float *__restrict__ ws) {
     const int b = blockIdx.x, t = threadIdx.x;
     float *o = ws + (size_t)b * kWsStrideReal;
-    __shared__ float s_pd[3 * kMaxK];  // kMaxK = 8
+    __shared__ float s_pd[3 * IDH_MAX_SOURCE_VIEWS];
     if (t < K) {
         const float *Km = src_K + (size_t)(b * K + t) * 16, *Em = src_E + (size_t)(b * K + t) * 16;
         const float *iK = cur_invK + (size_t)b * 16, *Pm = src_poses + (size_t)(b * K + t) * 16;
@@ -114,6 +114,7 @@ struct FvArgs {
     int B, K, H, W, D;
     int tiles_per_img;     // ceil(N/16)
     int DP, G;             // planes per task, plane groups
+    int J, MB;             // generic kernel: source views per lane quarter (view q + 4j), metadata blocks = ceil((7J + 1) / 4)
     float dmin, dmax;
     // idh_volume_opts, resolved: batch strides (floats) and caller-supplied planes (null = log-spaced)
     long long cur_bs, src_bs;
@@ -385,6 +386,229 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 }
                 if (q == 0 && live) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic variant: any source-view count up to IDH_MAX_SOURCE_VIEWS (FeatureVolumeManager takes num_source_views from
+// model_num_views - 1, reference cost_volume.py:382-435 / depth_model.py:206-212) and matching_feature_dims = 16 * CB
+// (options.py:138).  Same arithmetic and operand order as fv_mlp_k; what changes is where things live:
+//   * W1's per-voxel blocks — K*CB feature blocks + MB metadata blocks, up to 40 x 8 KiB — no longer fit next to W2 in
+//     LDS and are read through L1 / L2 as MFMA fragments (every wave of the chip reads the same 8 KiB per block);
+//   * lane quarter q carries the metadata of views q, q+4, .. q+4(J-1) (J = ceil(K/4), or 2 for K <= 8 as in fv_mlp_k):
+//     7J values + the plane depth = MB = ceil((7J+1)/4) metadata blocks; the view loop is unrolled over (j, r) so that
+//     every metadata register index is a compile-time constant;
+//   * no software pipelining of the taps: this is the coverage path, fv_mlp_k<7> stays the measured one.
+template <int CB>
+__global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4 *sW2 = reinterpret_cast<f32x4 *>(smem_raw);  // 8*8*64
+    {
+        const f32x4 *g2 = reinterpret_cast<const f32x4 *>(a.w2);
+        for (int i = threadIdx.x; i < kNS * kNS * 64; i += 512) sW2[i] = g2[i];
+    }
+    __syncthreads();
+    const f32x4 *gW1 = reinterpret_cast<const f32x4 *>(a.w1v);
+    const float *s_b2 = a.vecs, *s_w3 = a.vecs + kHid;
+    const float b3 = a.vecs[2 * kHid];
+    constexpr int kCc = kC * CB;
+    constexpr int kJmax = IDH_MAX_SOURCE_VIEWS / 4;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ln = lane & 15, q = lane >> 4;
+    const int N = a.H * a.W;
+    const int K = a.K, J = a.J, MB = a.MB;
+    const float Wf = (float)a.W, Hf = (float)a.H;
+    const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
+
+    for (long long task = (long long)idh_xcd_remap(blockIdx.x, gridDim.x) * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
+        const int g = __builtin_amdgcn_readfirstlane((int)(task % a.G));
+        const int tile = __builtin_amdgcn_readfirstlane((int)((task / a.G) % a.tiles_per_img));
+        const int b = __builtin_amdgcn_readfirstlane((int)(task / ((long long)a.G * a.tiles_per_img)));
+        const int p_raw = tile * 16 + ln;
+        const bool live = p_raw < N;
+        const int p = live ? p_raw : N - 1;
+        const int py = p / a.W, px = p - py * a.W;
+        const float pxf = (float)px + 0.5f, pyf = (float)py + 0.5f;
+        const float *pb = a.ws + (size_t)b * kWsStrideReal;
+
+        f32x4 cur4[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) cur4[cb] = *reinterpret_cast<const f32x4 *>(a.cur + (size_t)b * a.cur_bs + (size_t)p * kCc + 16 * cb + 4 * q);
+        const float *iK = pb + kWsInvK;
+        const float rx = fmaf(iK[0], pxf, fmaf(iK[1], pyf, iK[2]));
+        const float ry = fmaf(iK[3], pxf, fmaf(iK[4], pyf, iK[5]));
+        const float rz = fmaf(iK[6], pxf, fmaf(iK[7], pyf, iK[8]));
+
+        f32x4 pre[kNS];
+#pragma unroll
+        for (int i = 0; i < kNS; ++i) pre[i] = *reinterpret_cast<const f32x4 *>(pb + kWsBias + 16 * i + 4 * q);
+        const int d0 = g * a.DP, d1 = min(a.D, d0 + a.DP);
+        if (d0 >= d1) continue;
+        const float rn = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+        const float crx = rx / rn, cry = ry / rn, crz = rz / rn;
+        {
+            const f32x4 rayB = (q == 0) ? (f32x4){crx, cry, crz, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 *w1p = reinterpret_cast<const f32x4 *>(a.w1p);
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const f32x4 A0 = w1p[(cb * kNS + i) * 64 + lane];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) pre[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[kk], cur4[cb][kk], pre[i], 0, 0, 0);
+                }
+                const f32x4 A1 = w1p[(CB * kNS + i) * 64 + lane];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) pre[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[kk], rayB[kk], pre[i], 0, 0, 0);
+            }
+        }
+
+        f32x4 ob = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool vec_ok = ((d0 & 3) == 0) && ((a.vol_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.vol) & 15) == 0);
+#pragma unroll 1
+        for (int d = d0; d < d1; ++d) {
+            const float depth = fv_plane(a, b, p, d);
+            const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
+            f32x4 acc1[kNS];
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
+            float m[8 * kJmax];  // this quarter's metadata: [7j .. 7j+6] = mask, z, dot, ray angle, ray xyz of view q + 4j; [7J] = plane depth
+#pragma unroll
+            for (int i = 0; i < 8 * kJmax; ++i) m[i] = 0.f;
+            bool any_inb = false, any_front = false;
+#pragma unroll
+            for (int j = 0; j < kJmax; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * j + r;
+                    if (k < K) {
+                        const float *hm = pb + kWsHom + 12 * k;
+                        const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+                        const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+                        const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+                        const float cx = fmaf(depth, qx, hm[9]);
+                        const float cy = fmaf(depth, qy, hm[10]);
+                        const float cz = fmaf(depth, qz, hm[11]);
+                        const float z = fmaxf(cz, 1e-5f);
+                        float rc = __builtin_amdgcn_rcpf(z);
+                        rc = rc * fmaf(-z, rc, 2.0f);
+                        const float su = cx * rc, sv = cy * rc;
+                        any_inb |= (su > 2.f) & (su < Wf - 2.f) & (sv > 2.f) & (sv < Hf - 2.f);
+                        any_front |= z > 0.f;
+                        const float sx = fminf(fmaxf(su - 0.5f, -1.0f), Wf);
+                        const float sy = fminf(fmaxf(sv - 0.5f, -1.0f), Hf);
+                        const float x0f = floorf(sx), y0f = floorf(sy);
+                        const float fx = sx - x0f, fy = sy - y0f;
+                        const int x0 = (int)x0f, y0 = (int)y0f;
+                        const float wx0 = (x0 >= 0 && x0 < a.W) ? 1.0f - fx : 0.f;
+                        const float wx1 = (x0 + 1 < a.W) ? fx : 0.f;
+                        const float wy0 = (y0 >= 0 && y0 < a.H) ? 1.0f - fy : 0.f;
+                        const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
+                        const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
+                        const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
+                        const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+                        const float *sb = a.src + (size_t)b * a.src_bs + (size_t)k * N * kCc + 4 * q;
+                        const float maskv = z > 0.f ? 1.f : 0.f;
+                        float part = 0.f;
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) {
+                            const f32x4 t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kCc + 16 * cb);
+                            const f32x4 t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kCc + 16 * cb);
+                            const f32x4 t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kCc + 16 * cb);
+                            const f32x4 t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kCc + 16 * cb);
+                            f32x4 wv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) wv[e] = fmaf(w11, t11[e], fmaf(w10, t10[e], fmaf(w01, t01[e], w00 * t00[e])));
+                            // per-quarter partial of <warped, cur> in channel order: block cb's 4 channels of this quarter
+                            float pc = wv[0] * cur4[cb][0];
+                            pc = fmaf(wv[1], cur4[cb][1], pc); pc = fmaf(wv[2], cur4[cb][2], pc); pc = fmaf(wv[3], cur4[cb][3], pc);
+                            part += pc;
+#pragma unroll
+                            for (int i = 0; i < kNS; ++i) {
+                                const f32x4 A = gW1[((size_t)(k * CB + cb) * kNS + i) * 64 + lane];
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
+                            }
+                        }
+                        part += __shfl_xor(part, 16, 64);
+                        part += __shfl_xor(part, 32, 64);
+                        const float dotv = part * maskv;
+                        const bool mine = r == q;
+                        m[7 * j + 0] = mine ? maskv : m[7 * j + 0];
+                        m[7 * j + 1] = mine ? z : m[7 * j + 1];
+                        m[7 * j + 2] = mine ? dotv : m[7 * j + 2];
+                    }
+                }
+                // ray / ray angle of this quarter's j-th view (cost_volume.py:630-659)
+                const int v = q + 4 * j;
+                if (j < J && v < K) {
+                    const float *t = pb + kWsT + 4 * v;
+                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
+                    const float in = 1.0f / fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
+                    const float e0 = ax * in, e1 = ay * in, e2 = az * in;
+                    const float n1 = fmaxf(sqrtf(crx * crx + cry * cry + crz * crz), 1e-5f);
+                    const float n2 = fmaxf(sqrtf(e0 * e0 + e1 * e1 + e2 * e2), 1e-5f);
+                    m[7 * j + 3] = (crx * e0 + cry * e1 + crz * e2) / (n1 * n2);
+                    m[7 * j + 4] = e0; m[7 * j + 5] = e1; m[7 * j + 6] = e2;
+                }
+            }
+#pragma unroll
+            for (int jj = 1; jj <= kJmax; ++jj)
+                if (J == jj) m[7 * jj] = depth;
+#pragma unroll
+            for (int c = 0; c < 2 * kJmax; ++c) {
+                if (c < MB) {
+#pragma unroll
+                    for (int i = 0; i < kNS; ++i) {
+                        const f32x4 A = gW1[((size_t)(K * CB + c) * kNS + i) * 64 + lane];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], m[4 * c + kk], acc1[i], 0, 0, 0);
+                    }
+                }
+            }
+            f32x4 acc2[kNS];
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc1[i][r] = lrelu01(acc1[i][r]);
+                acc2[i] = *reinterpret_cast<const f32x4 *>(s_b2 + 16 * i + 4 * q);
+            }
+#pragma unroll
+            for (int c = 0; c < kNS; ++c) {
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const f32x4 A = sW2[(c * kNS + i) * 64 + lane];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], acc1[c][kk], acc2[i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) {
+                const f32x4 w3 = *reinterpret_cast<const f32x4 *>(s_w3 + 16 * i + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc = fmaf(w3[r], lrelu01(acc2[i][r]), sacc);
+            }
+            sacc += __shfl_xor(sacc, 16, 64);
+            sacc += __shfl_xor(sacc, 32, 64);
+            const float val = sacc + b3;
+            if (a.vol_cs > 0) {
+                const int e = (d - d0) & 3;
+                ob[0] = e == 0 ? val : ob[0]; ob[1] = e == 1 ? val : ob[1]; ob[2] = e == 2 ? val : ob[2]; ob[3] = e == 3 ? val : ob[3];
+                if (q == 0 && live && (e == 3 || d == d1 - 1)) {
+                    float *o = a.vol + ((size_t)b * N + p) * a.vol_cs + (d - e);
+                    if (e == 3 && vec_ok) *reinterpret_cast<f32x4 *>(o) = ob;
+                    else { o[0] = ob[0]; if (e >= 1) o[1] = ob[1]; if (e >= 2) o[2] = ob[2]; if (e >= 3) o[3] = ob[3]; }
+                }
+            } else if (q == 0 && live) {
+                a.vol[((size_t)b * a.D + d) * N + p] = val;
+            }
+            // overall mask: the reference overwrites it every plane, the LAST plane survives
+            if (q == 0 && live && a.mask != nullptr && d == a.D - 1) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
         }
     }
 }
@@ -783,7 +1007,8 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     const bool own_planes = opts && opts->planes;
     if (own_planes) { dmin = dmax = 1.f; planes_d = nullptr; }
     if (B < 0 || K <= 0 || H <= 0 || W <= 0 || D <= 0 || !(dmin > 0.f) || !(dmax > 0.f)) return IDH_EINVAL;
-    if (C != kC || K > kMaxK || D > 4096) return IDH_EUNSUPPORTED;
+    const bool generic = C != kC || K > kMaxK;  // fv_mlp_gen_k: matching_feature_dims 32, up to IDH_MAX_SOURCE_VIEWS views
+    if ((C != kC && C != 2 * kC) || K > IDH_MAX_SOURCE_VIEWS || D > 4096 || (generic && f16x3)) return IDH_EUNSUPPORTED;
     if (B == 0) return IDH_OK;
     if (!cur_nhwc || !src_nhwc || !src_K_44 || !src_E_44 || !src_poses_44 || !cur_invK_44 || !w1_voxel_packed ||
         !w1_pixel_packed || !w1_pose_rowmajor || !b1 || !w2_packed || !vecs_b2_w3_b3 || !vol)
@@ -802,11 +1027,13 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     a.vecs = vecs_b2_w3_b3; a.vol = vol; a.mask = mask_bhw; a.vol_cs = vol_nhwc_cs;
     a.B = B; a.K = K; a.H = H; a.W = W; a.D = D; a.dmin = dmin; a.dmax = dmax;
     const int N = H * W;
-    a.cur_bs = (long long)N * kC; a.src_bs = (long long)K * N * kC;
+    a.cur_bs = (long long)N * C; a.src_bs = (long long)K * N * C;
+    a.J = K <= kMaxK ? 2 : (K + 3) / 4;  // views per lane quarter (the packed W1 columns follow the same rule: feature_mlp_column_maps)
+    a.MB = (7 * a.J + 1 + 3) / 4;
     if (opts) {
         if (opts->cur_batch_stride) a.cur_bs = opts->cur_batch_stride;
         if (opts->src_batch_stride) a.src_bs = opts->src_batch_stride;
-        if (a.cur_bs < (long long)N * kC || a.src_bs < (long long)K * N * kC || (a.cur_bs & 3) || (a.src_bs & 3)) return IDH_EINVAL;
+        if (a.cur_bs < (long long)N * C || a.src_bs < (long long)K * N * C || (a.cur_bs & 3) || (a.src_bs & 3)) return IDH_EINVAL;
         if (opts->planes) {
             if (opts->planes_pixel_stride != 0 && opts->planes_pixel_stride != 1) return IDH_EINVAL;
             a.planes = opts->planes; a.planes_sb = opts->planes_batch_stride; a.planes_sd = opts->planes_plane_stride;
@@ -840,6 +1067,8 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     if (attr_set.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_gen_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_gen_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k<7>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -851,7 +1080,11 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
             return IDH_ELAUNCH;
         attr_set.mark();
     }
-    if (f16x3) {
+    if (generic) {
+        const size_t lds = (size_t)kNS * kNS * 64 * sizeof(f32x4);
+        if (C == kC) hipLaunchKernelGGL(fv_mlp_gen_k<1>, dim3(grid), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL(fv_mlp_gen_k<2>, dim3(grid), dim3(512), lds, st, a);
+    } else if (f16x3) {
         const int nb32 = (K + 5) / 2;
         const size_t lds = ((size_t)nb32 * kNS * 2 * 64 + 4 * kNS * 2 * 64) * 16;
         const float *sw1 = reinterpret_cast<const float *>(static_cast<const char *>(w1_voxel_packed) + (size_t)nb32 * kNS * 2 * 64 * 16);

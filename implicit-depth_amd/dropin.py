@@ -22,6 +22,17 @@ def _device(m: nn.Module):
     return None
 
 
+def infer_volume_dims(n_in: int):
+    """(num_source_views, matching_dim_size) from the input width of the feature-volume MLP, C (K+1) + 10 K + 4
+    (reference cost_volume.py:405-423): the reference keeps neither number on the module.  Unique for C in {16, 32} and
+    K <= 16 (the first coincidence, 540 = 16*21 + 204 = 32*13 + 124, needs 20 views)."""
+    for C in (16, 32):
+        K, r = divmod(n_in - C - 4, C + 10)
+        if r == 0 and 1 <= K <= 16:
+            return K, C
+    raise ValueError(f"cannot infer the number of source views / matching channels from an MLP input width of {n_in}")
+
+
 def convert_cost_volume(ref: nn.Module) -> nn.Module:
     name = type(ref).__name__
     H, W, D = ref.matching_height, ref.matching_width, ref.num_depth_bins
@@ -30,10 +41,8 @@ def convert_cost_volume(ref: nn.Module) -> nn.Module:
     elif name == "ZeroCostVolumeManager":
         new = cv.ZeroCostVolumeManager(H, W, D)
     elif name in ("FeatureVolumeManager", "FastFeatureVolumeManager"):
-        n_in = ref.mlp.net[0].in_features  # 16(K+1) + 10K + 4 (reference cost_volume.py:405-423)
-        if (n_in - 20) % 26:
-            raise ValueError(f"cannot infer the number of source views from an MLP input width of {n_in}")
-        new = cv.FeatureVolumeManager(H, W, D, num_source_views=(n_in - 20) // 26)
+        K, C = infer_volume_dims(ref.mlp.net[0].in_features)
+        new = cv.FeatureVolumeManager(H, W, D, num_source_views=K, matching_dim_size=C)
     else:
         raise ValueError(f"unrecognised cost volume class {name}")
     new.load_state_dict(ref.state_dict())

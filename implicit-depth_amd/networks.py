@@ -181,15 +181,14 @@ class ResnetMatchingEncoder(nn.Module):
 
 # --- skip decoder family (reference modules/networks_fast.py) ---------------------------------
 class ConvBlock(nn.Module):
-    """conv3x3 -> ELU -> conv3x3 -> ELU (networks_fast.py:10-28)."""
+    """conv3x3 -> ELU -> conv3x3 -> ELU (networks_fast.py:10-28); ``use_elu=False``: ReLU.  ``use_bn`` is accepted and — exactly
+    as in the reference, whose ConvBlock never creates a normalisation layer (networks_fast.py:11-19) — has no effect."""
 
     def __init__(self, in_ch, out_ch, use_elu=True, use_bn=False):
         super().__init__()
-        if not use_elu or use_bn:
-            raise ValueError("the gfx950 drop-in covers the shipped ELU / no-BN configuration")
         self.conv1 = nn.Conv2d(in_ch, out_ch, 3, padding=1)
         self.conv2 = nn.Conv2d(out_ch, out_ch, 3, padding=1)
-        self.non_lin = nn.ELU(inplace=True)
+        self.non_lin = nn.ELU(inplace=True) if use_elu else nn.ReLU(inplace=True)
 
 
 class ConvUpsampleAndConcatBlock(nn.Module):

@@ -1003,12 +1003,13 @@ def matching_head_forward(enc, feat_nchw: torch.Tensor, channels_last: bool = Fa
 
 # --- SkipDecoder / SkipDecoderRegression (reference modules/networks_fast.py:10-145) ------------
 def _conv_block(p: Plan, x: View, blk, out: Optional[View] = None) -> View:
-    """ConvBlock: conv3x3 -> ELU -> conv3x3 -> ELU (networks_fast.py:10-28)."""
+    """ConvBlock: conv3x3 -> ELU -> conv3x3 -> ELU (networks_fast.py:10-28); ReLU (= LeakyReLU with slope 0) with use_elu=False."""
+    act, slope = (ACT_LRELU, 0.0) if isinstance(blk.non_lin, nn.ReLU) else (ACT_ELU, 0.2)
     h = p.buffer(x.N, x.H, x.W, blk.conv1.out_channels)
-    p.conv(x, blk.conv1, h, act=ACT_ELU)
+    p.conv(x, blk.conv1, h, act=act, slope=slope)
     if out is None:
         out = p.buffer(x.N, x.H, x.W, blk.conv2.out_channels)
-    p.conv(h, blk.conv2, out, act=ACT_ELU)
+    p.conv(h, blk.conv2, out, act=act, slope=slope)
     return out
 
 

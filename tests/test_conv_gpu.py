@@ -179,6 +179,33 @@ def test_skip_decoder_golden(reg):
         assert rel_err(out[k].cpu(), g[k]) < TOL, k
 
 
+def test_conv_block_relu_and_use_bn_flag():
+    """ConvBlock(use_elu=False) -> ReLU; use_bn=True is accepted and, as in the reference (networks_fast.py:10-28 never builds a
+    normalisation layer), changes nothing."""
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd import nhwc
+
+    x = syn.randn((2, 24, 20, 36), 3, "cb_x")
+    for use_elu, use_bn in ((False, False), (True, True)):
+        blk = net.ConvBlock(24, 32, use_elu=use_elu, use_bn=use_bn)
+        assert sorted(blk.state_dict()) == ["conv1.bias", "conv1.weight", "conv2.bias", "conv2.weight"]
+        syn.fill_state_dict(blk, seed=9)
+        f = torch.nn.functional
+        act = f.elu if use_elu else f.relu
+        ref = act(f.conv2d(act(f.conv2d(x.double(), blk.conv1.weight.double(), blk.conv1.bias.double(), padding=1)), blk.conv2.weight.double(),
+                           blk.conv2.bias.double(), padding=1))
+        blk.cuda()
+        p = nhwc.Plan(torch.device("cuda:0"))
+        xin = p.buffer(2, 20, 36, 24)
+        i_in = p.import_nchw(x.shape, xin)
+        y = nhwc._conv_block(p, xin, blk)
+        out = torch.empty(2, 32, 20, 36, device="cuda")
+        p.export_nchw(y, out)
+        p.set_in(i_in, x.cuda())
+        p.run()
+        assert rel_err(out.cpu(), ref) < TOL
+
+
 def test_fused_upsample_concat_is_bit_identical_to_materialised():
     """nhwc.FUSE_UPSAMPLE: the decoder's x2 bilinear upsampling + concat interpolated inside the consumer conv's halo
     loader (idh_conv_src.up_*) instead of upsample2_k writing a concat buffer — same blend expression, so the outputs

@@ -39,7 +39,9 @@ def test_matches_reference_golden(name):
     assert _lowest_mismatch(low, g["lowest_cost"]) < 5e-3
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 16, 8, 8, 1), (2, 3, 16, 17, 23, 7), (1, 8, 16, 33, 31, 9), (3, 7, 16, 24, 32, 64), (1, 16, 16, 12, 20, 5)])
+# C = 32 / 64: matching_feature_dims beyond the shipped 16 (options.py:138) run on the one-lane-per-sample kernel
+@pytest.mark.parametrize("shape", [(1, 1, 16, 8, 8, 1), (2, 3, 16, 17, 23, 7), (1, 8, 16, 33, 31, 9), (3, 7, 16, 24, 32, 64), (1, 16, 16, 12, 20, 5),
+                                   (2, 3, 32, 17, 23, 7), (1, 8, 32, 48, 64, 16), (1, 2, 64, 9, 11, 3)])
 def test_matches_oracle_fp64(shape):
     B, K, C, H, W, D = shape
     inp = syn.cost_volume_inputs(B, K, C, H, W, seed=B + K, behind_view=K - 1 if K > 2 else -1, big_rotation_view=0 if K > 3 else -1)
@@ -144,11 +146,15 @@ def test_empty_batch_and_limits():
     assert rel_err(cv.cpu(), ref) < TOL
     with pytest.raises(_lib.IdhError):
         CostVolumeManager(8, 8, 513).cuda()(**big)
-    # the MLP feature volume keeps W1/W2 LDS-resident: K <= 8 (160 KiB)
-    k9 = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 9, 16, 8, 8, 2).items()}
-    m = FeatureVolumeManager(8, 8, 4, num_source_views=9).cuda()
+    # the MLP feature volume: up to IDH_MAX_SOURCE_VIEWS = 16 views (K > 8 on the generic kernel), 17 fail loudly
+    k17 = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 17, 16, 8, 8, 2).items()}
+    m = FeatureVolumeManager(8, 8, 4, num_source_views=17).cuda()
     with pytest.raises(_lib.IdhError):
-        m(**k9)
+        m(**k17)
+    # matching features of 48 channels: neither volume kernel family covers them
+    c48 = {k: v.cuda() for k, v in syn.cost_volume_inputs(1, 2, 48, 8, 8, 3).items()}
+    with pytest.raises(_lib.IdhError):
+        CostVolumeManager(8, 8, 4).cuda()(**c48)
 
 
 def test_depth_range_as_numbers_device_tensors_and_per_sample_tensors():

@@ -24,6 +24,11 @@ def test_convert_reference_models_keeps_state_dicts():
     r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("converted ok") == len(CONFIGS), r.stdout
+    # the reference's own constructors reject matching_scale != 1 (IndexError in the encoder / decoder channel lists,
+    # bd_model.py:75-83) and 9 / 12 source views or 32 matching channels construct and convert: the config surface the drop-ins
+    # must (and need not) cover
+    assert r.stdout.count("reference rejects matching_scale") == 2, r.stdout
+    assert r.stdout.count("wide config ok") == 3, r.stdout
 
 
 def _child():
@@ -91,6 +96,28 @@ def _child():
         assert hot.matching_model is m.matching_model  # the reference encoder: its net[5] / net[8] are what the head plan reads
         assert (hot.min_depth, hot.max_depth) == (m.run_opts.min_matching_depth, m.run_opts.max_matching_depth)
         print("converted ok", cls, fvt, K, decoder, prior, len(before), "tensors")
+
+    for ms in (0, 2):
+        o = Options()
+        o.image_width, o.image_height, o.matching_num_depth_bins, o.binary_loss_positive_weight, o.matching_scale = 128, 96, 16, 1.0, ms
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                BDModel(o)
+        except IndexError as e:
+            print("reference rejects matching_scale", ms, "->", repr(e))
+    for K, C in ((9, 16), (12, 16), (7, 32)):
+        o = Options()
+        o.image_width, o.image_height, o.matching_num_depth_bins, o.binary_loss_positive_weight = 128, 96, 16, 1.0
+        o.feature_volume_type, o.model_num_views, o.matching_feature_dims, o.bd_edge_regularision = "mlp_feature_volume", K + 1, C, False
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = DepthModel(o)  # the model that wires num_source_views / matching_dim_size through (depth_model.py:206-212)
+        syn.fill_state_dict(m, seed=6)
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        dropin.convert(m)
+        assert isinstance(m.cost_volume, cv.FeatureVolumeManager)
+        assert (m.cost_volume.num_source_views, m.cost_volume.matching_dim_size) == (K, C), (m.cost_volume.num_source_views, m.cost_volume.matching_dim_size)
+        assert list(m.state_dict()) == list(before) and all(torch.equal(m.state_dict()[k], before[k]) for k in before)
+        print("wide config ok", K, C)
 
 
 if __name__ == "__main__":

@@ -10,10 +10,10 @@ from oracle import cost_volume as ocv
 pytestmark = pytest.mark.gpu
 
 
-def _manager(K, H, W, D, seed):
+def _manager(K, H, W, D, seed, C=16):
     from implicit_depth_amd.cost_volume import FeatureVolumeManager
 
-    m = FeatureVolumeManager(H, W, D, mlp_channels=[202, 128, 128, 1], num_source_views=K)
+    m = FeatureVolumeManager(H, W, D, mlp_channels=[202, 128, 128, 1], num_source_views=K, matching_dim_size=C)
     syn.fill_state_dict(m.mlp, seed=seed, gain=1.4)
     return m
 
@@ -41,6 +41,26 @@ def test_matches_oracle_fp64(shape):
     B, K, H, W, D = shape
     inp = syn.cost_volume_inputs(B, K, 16, H, W, seed=K, behind_view=K - 1 if K > 2 else -1, big_rotation_view=0 if K > 3 else -1)
     m = _manager(K, H, W, D, 77 + K)
+    w = {k: v.double() for k, v in m.mlp.state_dict().items()}
+    d = {k: v.double() for k, v in inp.items()}
+    ref, rlow, _, rmask = ocv.feature_volume(d["cur_feats"], d["src_feats"], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
+                                             0.25, 5.0, D, w, return_mask=True)
+    m.cuda()
+    fv, low, planes, mask = m(**{k: v.cuda() for k, v in inp.items()}, return_mask=True)
+    assert rel_err(fv.cpu(), ref) < TOL
+    assert (mask.cpu() != rmask).float().mean().item() < 2e-3
+    assert ((low.cpu().double() - rlow).abs() > 1e-5).float().mean().item() < 5e-3
+
+
+# (B, K, C, H, W, D): the reference's config surface beyond the shipped yaml — FeatureVolumeManager takes any num_source_views
+# (cost_volume.py:382-435; DepthModel passes model_num_views - 1, depth_model.py:206-212) and matching_feature_dims is an
+# option (options.py:138).  K > 8 or C = 32 run on fv_mlp_gen_k (W1 blocks streamed through L2, metadata of view q + 4j)
+@pytest.mark.parametrize("shape", [(1, 9, 16, 12, 20, 5), (2, 12, 16, 17, 23, 6), (1, 16, 16, 9, 13, 3), (1, 7, 32, 24, 32, 8), (2, 3, 32, 10, 14, 4), (1, 10, 32, 8, 12, 3)])
+def test_generic_kernel_more_views_and_wider_features_vs_oracle_fp64(shape):
+    B, K, C, H, W, D = shape
+    inp = syn.cost_volume_inputs(B, K, C, H, W, seed=K + C, behind_view=K - 1, big_rotation_view=0)
+    m = _manager(K, H, W, D, 91 + K, C=C)
+    assert m.mlp.net[0].in_features == C * (K + 1) + 10 * K + 4
     w = {k: v.double() for k, v in m.mlp.state_dict().items()}
     d = {k: v.double() for k, v in inp.items()}
     ref, rlow, _, rmask = ocv.feature_volume(d["cur_feats"], d["src_feats"], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
