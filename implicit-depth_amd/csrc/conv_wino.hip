@@ -192,10 +192,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         if (kExtra) voffX = halo_voff(jx);
         panel_so = (cb0 * (4 * KS) + wave * kPanel) * 1024;
     };
-    // ---- second source (P steps of 32 channels): 8 planes of the tile's own 32 x kRows pixels, [plane][row][column parity][16]
-    // float4 (kTight / 64 pieces each: wave w copies piece w of every plane -> one offset VGPR), and 2 x NCO panel pieces of the
-    // ordinary packed 1x1 weights (one per wave)
-    static_assert(!SRC2 || (kTight == 64 * WAVES && 2 * NCO == WAVES), "P-step pieces: one per plane and one of the panel per wave");
+    // ---- second source (P steps of 32 channels): the tile's own 32 x kRows pixels, pixel-major — slot 8 P + (plane ^ swz(P)),
+    // P = (2 row + column parity) * 16 + column / 2, swz(P) = (P >> 1) & 7 — so that one LDS-DMA piece (64 slots) is the
+    // 128 contiguous bytes of 8 pixels (8 cache lines per piece: plane-major pieces of 64 scattered 16-byte granules kept
+    // the texture addresser busier than the matrix pipe) while the 16 lanes of a ds_read_b128 group still hit 16 different
+    // bank groups (the XOR spreads a plane over the 8 slots of consecutive pixel pairs).  32 pixel pieces (8 per wave; the
+    // piece only moves the scalar offset) and 2 x NCO panel pieces of the ordinary packed 1x1 weights (one per wave).
+    static_assert(!SRC2 || (kTight == 64 * WAVES && 2 * NCO == WAVES), "P-step pieces: eight of the pixels and one of the panel per wave");
     constexpr int kTPW2 = SRC2 ? 9 : 0;
     const ConvSrc &s1 = a.s[1];
     const int nS2 = SRC2 ? (s1.cblocks + 1) / 2 : 0;  // P steps per tile
@@ -205,14 +208,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         rsW2 = BufRef{s1.w, s1.cblocks * 4 * a.Cout_pad * 16};
         voffP2 = ((lane >> 4) * a.Cout_pad + (lane & 15)) * 16;  // idh_pack_conv_weight(ks = 1): [ci / 4][co][4]
     }
+    int tile2_so = 0;  // byte offset of the tile's first pixel in its image (wave-uniform)
     auto set_fetch_tile2 = [&]() {  // from (y0, x0, img); same map size as source 0
         if constexpr (SRC2) {
             rsA2 = BufRef{s1.in + (size_t)img * s1.H * s1.W * s1.cs, s1.H * s1.W * s1.cs * 4};
-            const int L = 64 * wave + lane;  // slot of a plane: [row][parity][16]
-            const int iy = y0 + (L >> 5), ix = x0 + 2 * (L & 15) + ((L >> 4) & 1);
-            voffT = ((iy < s1.H) & (ix < s1.W)) ? (iy * s1.W + ix) * s1.cs * 4 : kOob;
+            // lane L of a piece: pixel column 2 (L >> 3) (+ the piece's parity / half / row, in the scalar offset), plane (L & 7) ^ swz.
+            // Rows below the image are past the descriptor's range (zeros); columns right of it alias the next row's pixels and
+            // feed only tiles whose outputs are never stored (a 1x1 source mixes no pixels)
+            tile2_so = (y0 * s1.W + x0) * s1.cs * 4;
         }
     };
+    if constexpr (SRC2) voffT = 2 * (lane >> 3) * s1.cs * 4;
     // k-th DMA piece of this wave for the NEXT step into `stage`: Winograd step c of the fetch tile, or (p, SRC2 only) P step c
     // of the tile in flight.  Branch-free: both candidates are formed and selected (a uniform branch per piece costs more
     // in the K loop than the selects); wave-uniform operands forced into SGPRs
@@ -241,9 +247,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         if constexpr (SRC2) {
             int so1, lo1, vo1;
             bool halo1 = true;
-            if (k < 8) {  // plane k: channels 32 c + 4 k ..; the upper half of an odd last step lies past the packed weights: zeros
-                vo1 = (k >= 4 && 2 * c + 1 >= s1.cblocks) ? kOob : voffT;
-                so1 = 16 * k + 128 * c; lo1 = k * kTight + 64 * wave;
+            if (k < 8) {  // pixel piece t = 8 wave + k: row t >> 2, column parity (t >> 1) & 1, columns 16 (t & 1) ..; plane (lane & 7) ^ swz
+                const int t = 8 * wave + k;
+                const int plane = (lane & 7) ^ ((4 * (t & 1) + (lane >> 4)) & 7);  // swz(P) = (P >> 1) & 7, P & 15 = 8 (t & 1) + (lane >> 3)
+                // the upper half of an odd last step lies past the packed weights: zeros
+                vo1 = (plane >= 4 && 2 * c + 1 >= s1.cblocks) ? kOob : voffT + 16 * plane;
+                so1 = tile2_so + (((t >> 2) * s1.W + 16 * (t & 1) + ((t >> 1) & 1)) * s1.cs + 32 * c) * 4;
+                lo1 = 64 * t;
             } else {      // panel piece (16-channel half wave / NCO, output block wave % NCO)
                 const int hh = wave / NCO, cbw = wave % NCO;
                 halo1 = false;
@@ -310,8 +320,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
             if (g == 5) rd_row(3);
 #ifndef IDH_ABL_WINO_NODMA
             if ((g & 1) == 0 && (g >> 1) < kTPW) issue_next(g >> 1, pnext, cnext, snext, cbf);  // even groups: one DMA piece
-            if (SRC2 && g >= 13 && (g & 1) && kTPW + (g - 13) / 2 < kTPW2) {  // a P step has more pieces than a Winograd step
-                if (pnext) issue_next(kTPW + (g - 13) / 2, true, cnext, snext, cbf);
+            if (SRC2 && (g == 1 || g == 3) && kTPW + (g >> 1) < kTPW2) {  // a P step has more pieces than a Winograd step (odd groups
+                if (pnext) issue_next(kTPW + (g >> 1), true, cnext, snext, cbf);  // carry output stores only in a tile's FIRST step)
             }
 #endif
 #ifndef IDH_ABL_WINO_NOSTORE
@@ -346,7 +356,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     // its tile (ds_read_b128 from planes h and 4+h) and the W1 fragments of both halves and each output block; 8 MFMA k-steps
     // per pixel and block go straight into the output-domain registers.
     auto compute_p = [&](int stage, bool pnext, int cnext, int snext, int cbf) {
-        const f32x4 *sH = lds + stage * kStage + h * kTight + (4 * wave) * 16 + n;
+        // pixel P = ((2 wave + i) * 2 + j) * 16 + n -> slot 8 P + (plane ^ swz), swz = (n >> 1) & 7; plane h (channels 4h..) / 4 + h
+        const f32x4 *sH = lds + stage * kStage + 8 * ((4 * wave) * 16 + n);
+        const int x0s = h ^ ((n >> 1) & 7);
         const f32x4 *sW = lds + stage * kStage + 8 * kTight + lane;
         f32x4 d2[2][2][2], A1[2][NCO];
 #pragma unroll
@@ -358,14 +370,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) d2[i][j][hh] = sH[hh * 4 * kTight + (2 * i + j) * 16];
+                for (int hh = 0; hh < 2; ++hh) d2[i][j][hh] = sH[8 * 16 * (2 * i + j) + (x0s ^ (4 * hh))];
 #pragma unroll
         for (int g = 0; g < 8; ++g) {  // (pixel g >> 1, channel half g & 1)
+            // the next step's pieces go out in the first five of the eight groups: the last ones need ~1.5k cycles to land
             if (pnext) {
-                issue_next(g, true, cnext, snext, cbf);
-                if (g == 7) issue_next(8, true, cnext, snext, cbf);
-            } else if (g < kTPW) {
-                issue_next(g, false, cnext, snext, cbf);
+                if (g < 4) { issue_next(2 * g, true, cnext, snext, cbf); issue_next(2 * g + 1, true, cnext, snext, cbf); }
+                if (g == 4) issue_next(8, true, cnext, snext, cbf);
+            } else {
+                if (g < 3) { issue_next(2 * g, false, cnext, snext, cbf); issue_next(2 * g + 1, false, cnext, snext, cbf); }
+                if (g == 3 && kTPW > 6) issue_next(6, false, cnext, snext, cbf);
             }
             __builtin_amdgcn_sched_barrier(0);
             const int px = g >> 1, hh = g & 1;

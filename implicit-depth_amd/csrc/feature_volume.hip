@@ -209,7 +209,8 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 #pragma unroll
             for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
             // metadata registers of this lane: [0..6] view q, [7..13] view q+4, [14] plane depth
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m7 = 0.f, m8 = 0.f, m9 = 0.f;
+            const float m0 = q < K ? 1.f : 0.f, m7 = q + 4 < K ? 1.f : 0.f;  // "valid" masks: see maskv below
+            float m1 = 0.f, m2 = 0.f, m8 = 0.f, m9 = 0.f;
             // Software-pipelined view loop: the projection + 4 tap loads of view k+1 are issued
             // before the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work.
             struct Tap {
@@ -253,7 +254,9 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             for (int k = 0; k < K; ++k) {
                 const Tap nxt = issue(min(k + 1, K - 1));  // unconditional: counted vmcnt waits
                 const float z = cur.z;
-                const float maskv = z > 0.f ? 1.f : 0.f;
+                // the per-view "valid" input: (z > 0) AFTER z was clamped to 1e-5 (geometry_utils.py:86, cost_volume.py:216) — identically
+                // 1, NaN depths included (fmaxf(NaN, 1e-5) = 1e-5): a constant of the lane's two views, not per-view work
+                constexpr float maskv = 1.f;
                 f32x4 wv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -262,10 +265,10 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 part = fmaf(wv[1], cur4[1], part); part = fmaf(wv[2], cur4[2], part); part = fmaf(wv[3], cur4[3], part);
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
-                const float dotv = part * maskv;
+                const float dotv = part;  // * mask (== 1)
                 const bool s0 = (k == q), s1 = (k == q + 4);
-                m0 = s0 ? maskv : m0; m1 = s0 ? z : m1; m2 = s0 ? dotv : m2;
-                m7 = s1 ? maskv : m7; m8 = s1 ? z : m8; m9 = s1 ? dotv : m9;
+                m1 = s0 ? z : m1; m2 = s0 ? dotv : m2;
+                m8 = s1 ? z : m8; m9 = s1 ? dotv : m9;
                 // layer-1 block k: warped features of view k
 #pragma unroll
                 for (int i = 0; i < kNS; ++i) {
@@ -284,7 +287,10 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+#ifndef IDH_ABL_FV_VALU_PER_GROUP
+#define IDH_ABL_FV_VALU_PER_GROUP 3
+#endif
+                        __builtin_amdgcn_sched_group_barrier(0x002, IDH_ABL_FV_VALU_PER_GROUP, 0);
                     }
                 }
                 cur = nxt;
@@ -293,6 +299,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             float m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m10 = 0.f, m11 = 0.f, m12 = 0.f, m13 = 0.f;
             {
                 const int v0 = q, v1 = q + 4;
+#ifdef IDH_ABL_FV_OLDRAY
                 if (v0 < K) {
                     const float *t = pb + kWsT + 4 * v0;
                     const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
@@ -311,6 +318,23 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                     const float n2 = fmaxf(sqrtf(m11 * m11 + m12 * m12 + m13 * m13), 1e-5f);
                     m10 = (crx * m11 + cry * m12 + crz * m13) / (n1 * n2);
                 }
+#else
+                // unit ray e = (X - c) / |X - c| through v_rsq_f32 + one Newton step (<= 1 ulp), and the ray angle as the plain dot
+                // product cr . e: the reference divides it by max(|cr|, 1e-5) max(|e|, 1e-5) (cosine_similarity), both 1 up to
+                // rounding for unit vectors — a 1e-7 relative difference, three orders below the 1e-4 bar, for ~25 fewer vector
+                // instructions per view pair and plane (fp32 MFMA and VALU share the SIMD: every one is paid in matrix time)
+                auto ray = [&](int v, float &ang, float &e0, float &e1, float &e2) {
+                    const float *t = pb + kWsT + 4 * v;
+                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
+                    const float n2 = fmaf(az, az, fmaf(ay, ay, ax * ax));
+                    float in = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));
+                    in = in * fmaf(-0.5f * n2 * in, in, 1.5f);
+                    e0 = ax * in; e1 = ay * in; e2 = az * in;
+                    ang = fmaf(crz, e2, fmaf(cry, e1, crx * e0));
+                };
+                if (v0 < K) ray(v0, m3, m4, m5, m6);
+                if (v1 < K) ray(v1, m10, m11, m12, m13);
+#endif
             }
             const f32x4 mb[4] = {(f32x4){m0, m1, m2, m3}, (f32x4){m4, m5, m6, m7}, (f32x4){m8, m9, m10, m11},
                                  (f32x4){m12, m13, depth, 0.f}};
@@ -319,8 +343,9 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 #pragma unroll
                 for (int i = 0; i < kNS; ++i) {
                     const f32x4 A = sW1[((K + c) * kNS + i) * 64 + lane];
+                    // the last metadata slot of every quarter (block 3, k-step 3) is structurally zero in operand and weights
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], mb[c][kk], acc1[i], 0, 0, 0);
+                    for (int kk = 0; kk < (c == 3 ? 3 : 4); ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], mb[c][kk], acc1[i], 0, 0, 0);
                 }
             }
             // ---- LeakyReLU(0.01) -> layer 2 (weights from LDS) -> LeakyReLU -> layer 3 ----------
