@@ -111,22 +111,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     constexpr int NP = CH / 4;   // 4-channel planes of the halo per K step
     typedef float vec __attribute__((ext_vector_type(KS)));
     constexpr int kRows = 2 * WAVES;
-    constexpr int kPlane = wino_plane(WAVES);
-    constexpr int kQS = wino_qs(WAVES);
-    // LDS-DMA pieces (1 KiB each) of one K step, per wave: a plane of the halo is kJ pieces long; wave w copies piece
-    // j = f*WAVES + w of all NP planes (kFull rounds), its share of the kRem remaining j's (kExtra pieces of one j) and
-    // kPanel pieces of the weight panel -> one offset VGPR per distinct j plus one for the panel
-    constexpr int kJ = kQS / 64;
-    constexpr int kFull = kJ / WAVES, kRem = kJ % WAVES;
-    constexpr int kExtra = NP * kRem / WAVES;
-    static_assert(NP * kRem % WAVES == 0 && (kExtra == 0 || NP % kExtra == 0), "halo pieces must split evenly over the waves");
+    constexpr int kPlane = wino_plane(WAVES);  // halo texels: (kRows + 2) rows x 2 column parities x 17
+    // Halo in LDS, pixel-major: texel p = (2 hy + column parity) * 17 + column / 2 owns the NP consecutive 16-byte slots
+    // NP p .. (its CH channels), plane q in slot NP p + (q ^ swz), swz = (column / 2 >> 3) & 1 — so that an LDS-DMA piece is the
+    // contiguous 32 bytes of 32 texels (32 cache lines per piece instead of 64 scattered 16-byte granules) while the 32 lanes
+    // of a ds_read_b64 group (texel columns n .. n+15 of one row) still cover all 64 banks.
+    // Pieces (1 KiB each) of one K step: kHaloPieces of the halo — wave w copies pieces w, w + WAVES, .. (a wave with one fewer
+    // repeats its first: same bytes, same place) — and kPanel per wave of the weight panel: one offset VGPR per halo piece of
+    // the wave plus one for the panel
+    static_assert(NP == 2, "halo swizzle written for 8-channel K steps");
+    constexpr int kHaloPieces = (NP * kPlane + 63) / 64;
+    constexpr int kHP = (kHaloPieces + WAVES - 1) / WAVES;  // halo pieces per wave
     constexpr int kPanelPieces = NCO * 4 * KS;
     static_assert(kPanelPieces % WAVES == 0, "panel pieces must split evenly over the waves");
     constexpr int kPanel = kPanelPieces / WAVES;
-    constexpr int kTPW = NP * kFull + kExtra + kPanel;  // DMA pieces per wave and K step
+    constexpr int kTPW = kHP + kPanel;  // DMA pieces per wave and K step
     static_assert(CH == 8, "K steps of 8 channels: every tile has >= 2 steps (the first stores the previous tile's outputs, the last loads the residual)");
     static_assert(kTPW <= 8 && 4 * NCO <= 8, "one DMA piece per even position group, one output store per odd group");
-    constexpr int kHalo = NP * kQS;
+    constexpr int kHalo = 64 * kHaloPieces;
     constexpr int kTight = 32 * kRows;                   // float4 slots of one 4-channel plane of the tile's own pixels (no halo)
     constexpr int kStage3 = kHalo + 64 * kPanelPieces;   // float4 slots of a Winograd step's stage
     constexpr int kStageP = 8 * kTight + 64 * 2 * NCO;   // ... of a P step's (SRC2): 32 channels of the tile + 2 x NCO panel pieces
@@ -175,21 +177,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     };
     // ---- LDS-DMA descriptors of the tile whose K steps are being fetched --------------------------------------------
     BufRef rsA;
-    int voffF[kFull > 0 ? kFull : 1], voffX = 0, panel_so;
-    const int jx = kFull * WAVES + (wave * kExtra) / NP, qx = (wave * kExtra) % NP;  // this wave's share of the remaining j's
+    int voffH[kHP], panel_so;
     const int voffP = 16 * lane;
-    auto halo_voff = [&](int j) {  // byte offset of this lane's texel in piece j of a plane: slot L of [row][17]
-        const int L = 64 * j + lane;
-        const int row = L / kWinoHalf, hxh = L - row * kWinoHalf;
+    auto halo_piece = [&](int k) { return wave + WAVES * k < kHaloPieces ? wave + WAVES * k : wave; };  // k-th halo piece of this wave
+    auto halo_voff = [&](int j) {  // byte offset of this lane's 16 bytes of piece j: texel p = 32 j + lane / 2, plane (lane & 1) ^ swz
+        const int pt = 32 * j + (lane >> 1);
+        const int row = pt / kWinoHalf, hxh = pt - row * kWinoHalf;
+        const int q = (lane & 1) ^ ((hxh >> 3) & 1);
         const int iy = y0 - 1 + (row >> 1), ix = x0 - 1 + 2 * hxh + (row & 1);
-        const bool ok = (L < kPlane) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
-        return ok ? (iy * s.W + ix) * s.cs * 4 : kOob;  // out of the descriptor's range = zero padding
+        const bool ok = (pt < kPlane) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+        return ok ? (iy * s.W + ix) * s.cs * 4 + 16 * q : kOob;  // out of the descriptor's range = zero padding
     };
     auto set_fetch_tile = [&]() {  // from (y0, x0, cb0, img)
         rsA = BufRef{s.in + (size_t)img * s.H * s.W * s.cs, s.H * s.W * s.cs * 4};
 #pragma unroll
-        for (int f = 0; f < kFull; ++f) voffF[f] = halo_voff(f * WAVES + wave);
-        if (kExtra) voffX = halo_voff(jx);
+        for (int k = 0; k < kHP; ++k) voffH[k] = halo_voff(halo_piece(k));
         panel_so = (cb0 * (4 * KS) + wave * kPanel) * 1024;
     };
     // ---- second source (P steps of 32 channels): the tile's own 32 x kRows pixels, pixel-major — slot 8 P + (plane ^ swz(P)),
@@ -226,14 +228,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         int so, lo, vo;
         bool halo = true;
         const int k0 = k < kTPW ? k : kTPW - 1;  // (pieces kTPW.. exist for P steps only: the Winograd candidate repeats its last piece)
-        if (k0 < NP * kFull) {
-            const int f = k0 / NP, q = k0 % NP;
-            vo = voffF[f]; so = 16 * q + 4 * CH * c; lo = q * kQS + 64 * (f * WAVES + wave);
-        } else if (k0 < NP * kFull + kExtra) {
-            const int q = qx + (k0 - NP * kFull);
-            vo = voffX; so = 16 * q + 4 * CH * c; lo = q * kQS + 64 * jx;
+        if (k0 < kHP) {
+            vo = voffH[k0]; so = 4 * CH * c; lo = 64 * halo_piece(k0);
         } else {
-            const int i = k0 - NP * kFull - kExtra;
+            const int i = k0 - kHP;
             halo = false;
             vo = voffP; so = panel_so + (c * nCB * (4 * KS) + i) * 1024; lo = kHalo + 64 * (wave * kPanel + i);
         }
@@ -279,9 +277,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     __amdgpu_buffer_rsrc_t rsS;
     bool pending = false;
 
-    // this lane's KS channels of a texel: plane (KS h) / 4, byte (KS h % 4) * 4 of the 16-byte slot; patch origin = rows
-    // 4*wave .. of the plane (hy = 2*wave + y, column parity x & 1), column n + (x >> 1)
-    const int patch0 = ((((KS * h) >> 2) * kQS + (4 * wave) * kWinoHalf + n) * 16 + ((KS * h) & 3) * 4);  // bytes
+    // this lane's KS channels of a texel: plane q = (KS h) / 4, byte (KS h % 4) * 4 of the 16-byte slot NP p + (q ^ swz(column / 2)).
+    // Patch origin = texel (row 4 wave, column n); patch column x sits at column n + (x >> 1) of parity x & 1: two lane bases
+    const int pq = (KS * h) >> 2, pb8 = ((KS * h) & 3) * 4;
+    const int patch0 = (NP * ((4 * wave) * kWinoHalf + n) + (pq ^ ((n >> 3) & 1))) * 16 + pb8;              // bytes, x >> 1 == 0
     const int frag0 = kHalo * 16 + (h * 16 + n) * (4 * KS);                                                   // bytes
 
     // One K step: 16 position groups of KS*NCO MFMAs, in the order xi = 1, 2, 0, 3 (rows 1 and 2 of the patch feed the
@@ -294,7 +293,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         // volatile LDS pointers: hipcc otherwise pairs the 8-byte reads into ds_read2_b64 (half rate, 2-way bank conflicts)
         typedef const __attribute__((address_space(3))) volatile char lds_cchar;
         typedef const __attribute__((address_space(3))) volatile vec lds_cvec;
-        lds_cchar *sH = (lds_cchar *)(lds + stage * kStage) + patch0;
+        // (patch1 re-derived per step from an opaque copy of patch0's inputs: one address register fewer across the tile loop — a
+        // scratch reload inside the step would wait for every LDS-DMA piece in flight)
+        int n_o = n;
+        asm volatile("" : "+v"(n_o));
+        const int patch1 = patch0 + (NP + ((pq ^ (((n_o + 1) >> 3) & 1)) - (pq ^ ((n_o >> 3) & 1)))) * 16;
+        lds_cchar *sH0 = (lds_cchar *)(lds + stage * kStage) + patch0, *sH1 = (lds_cchar *)(lds + stage * kStage) + patch1;
         lds_cchar *sW = (lds_cchar *)(lds + stage * kStage) + frag0;
         vec d[4][4], A[kAhead + 1][NCO], r[4];
         auto rd_frag = [&](int g) {
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         };
         auto rd_row = [&](int y) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) d[y][x] = *(lds_cvec *)(sH + ((2 * y + (x & 1)) * kWinoHalf + (x >> 1)) * 16);
+            for (int x = 0; x < 4; ++x) d[y][x] = *(lds_cvec *)(((x >> 1) ? sH1 : sH0) + NP * (2 * y + (x & 1)) * kWinoHalf * 16);
         };
         rd_frag(0);
         rd_row(1);
@@ -316,8 +320,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
             const int xi = (g >> 2) == 0 ? 1 : (g >> 2) == 1 ? 2 : (g >> 2) == 2 ? 0 : 3, nu = g & 3;
             const int p = 4 * xi + nu;
             if (g + kAhead < 16) rd_frag(g + kAhead);
-            if (g == 1) rd_row(0);
-            if (g == 5) rd_row(3);
+            if (g == 5) rd_row(0);   // needed at g = 8; dead after it ...
+            if (g == 9) rd_row(3);   // ... so that row 3 (needed at g = 12) can take its registers
 #ifndef IDH_ABL_WINO_NODMA
             if ((g & 1) == 0 && (g >> 1) < kTPW) issue_next(g >> 1, pnext, cnext, snext, cbf);  // even groups: one DMA piece
             if (SRC2 && (g == 1 || g == 3) && kTPW + (g >> 1) < kTPW2) {  // a P step has more pieces than a Winograd step (odd groups
@@ -354,12 +358,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
 
     // One P step (SRC2): 32 channels of the 1x1 source.  Lane (n, h) reads channels 4h..4h+3 and 16+4h.. of the four pixels of
     // its tile (ds_read_b128 from planes h and 4+h) and the W1 fragments of both halves and each output block; 8 MFMA k-steps
-    // per pixel and block go straight into the output-domain registers.
+    // per pixel and block.
     auto compute_p = [&](int stage, bool pnext, int cnext, int snext, int cbf) {
         // pixel P = ((2 wave + i) * 2 + j) * 16 + n -> slot 8 P + (plane ^ swz), swz = (n >> 1) & 7; plane h (channels 4h..) / 4 + h
-        const f32x4 *sH = lds + stage * kStage + 8 * ((4 * wave) * 16 + n);
-        const int x0s = h ^ ((n >> 1) & 7);
-        const f32x4 *sW = lds + stage * kStage + 8 * kTight + lane;
+        // (recomputed per step from an opaque copy of the lane id: hoisted out of the tile loop these addresses only add to the
+        // register pressure of the Winograd steps and come back as scratch loads)
+        int ln_o = lane;
+        asm volatile("" : "+v"(ln_o));
+        const int n_o = ln_o & 15, h_o = ln_o >> 4;
+        const f32x4 *sH = lds + stage * kStage + 8 * ((4 * wave) * 16 + n_o);
+        const int x0s = h_o ^ ((n_o >> 1) & 7);
+        const f32x4 *sW = lds + stage * kStage + 8 * kTight + ln_o;
         f32x4 d2[2][2][2], A1[2][NCO];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
@@ -382,12 +391,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
                 if (g == 3 && kTPW > 6) issue_next(6, false, cnext, snext, cbf);
             }
             __builtin_amdgcn_sched_barrier(0);
+            // Output pixel (i, j) of a tile is, in the Winograd domain, position (3i, 3j) with sign (-1)^(i+j): A^T P = I for
+            // P = [1 0; 0 0; 0 0; 0 -1], so adding s W1.x to M[3i][3j] adds W1.x to Y[i][j] and nothing to the other three outputs.
+            // The P steps therefore accumulate straight into four of the Winograd accumulators (negated operand for the two
+            // mixed corners) and need no registers of their own.
             const int px = g >> 1, hh = g & 1;
+            const int pos = 12 * (px >> 1) + 3 * (px & 1);
+            f32x4 bop = d2[px >> 1][px & 1][hh];
+            if ((px >> 1) != (px & 1)) bop = -bop;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < NCO; ++j)
-                    ost[px >> 1][px & 1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[hh][j][k], d2[px >> 1][px & 1][hh][k], ost[px >> 1][px & 1][j], 0, 0, 0);
+                    acc[pos][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[hh][j][k], bop[k], acc[pos][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -418,8 +434,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
         const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)img * a.Ho * a.Wo * a.res_cs : a.out), 0,
                                                                               a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
-        int voffO[2][2];
         f32x4 b4[NCO];
+        const int ey0 = y0, ex0 = x0;  // (the DMA descriptors move on to the next tile under the last step)
 
         set_fetch_tile2();     // P-step descriptors of THIS tile (its Winograd descriptors were set one tile ago)
         const int cb_cur = cb0;
@@ -427,24 +443,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
 #pragma unroll 1
         for (int c = 0; c < nT; ++c) {
             const bool last = c + 1 == nT;
-            if (c + 1 == nS) {  // last Winograd step: the residual tile lands in the output-domain registers
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int oy = y0 + 2 * wave + i, ox = x0 + 2 * n + j;
-                        const int voffR = ((oy < a.Ho) & (ox < a.Wo)) ? ((oy * a.Wo + ox) * a.res_cs + n0 + 4 * h) * 4 : kOob;
-#pragma unroll
-                        for (int cb = 0; cb < NCO; ++cb) ost[i][j][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voffR + 64 * cb, 0, 0));
-                    }
-            }
             if (last) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int oy = y0 + 2 * wave + i, ox = x0 + 2 * n + j;
-                        voffO[i][j] = ((oy < a.Ho) & (ox < a.Wo)) ? ((oy * a.Wo + ox) * a.out_cs + n0 + 4 * h) * 4 : kOob;
+                        const bool ok = (oy < a.Ho) & (ox < a.Wo);
+                        const int voffR = ok ? ((oy * a.Wo + ox) * a.res_cs + n0 + 4 * h) * 4 : kOob;
+#pragma unroll
+                        for (int cb = 0; cb < NCO; ++cb) ost[i][j][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, voffR + 64 * cb, 0, 0));
                     }
 #pragma unroll
                 for (int cb = 0; cb < NCO; ++cb) b4[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 16 * cb + 4 * h) * 4, 0, 0));
@@ -501,7 +509,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) voffS[i][j] = voffO[i][j];
+            for (int j = 0; j < 2; ++j) {
+                const int oy = ey0 + 2 * wave + i, ox = ex0 + 2 * n + j;
+                voffS[i][j] = ((oy < a.Ho) & (ox < a.Wo)) ? ((oy * a.Wo + ox) * a.out_cs + n0 + 4 * h) * 4 : kOob;
+            }
         rsS = rsO;
         pending = true;
         WINO_TRACE(tr_i < 61 ? tr_i++ : 61);
@@ -530,7 +541,7 @@ int launch_wino(const ConvArgs &a, int N, hipStream_t st) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         resident = cus > 0 ? cus : 256;
     }
-    constexpr int kLds3 = CH / 4 * wino_qs(WAVES) + 64 * NCO * CH, kLdsP = 8 * 32 * 2 * WAVES + 64 * 2 * NCO;
+    constexpr int kLds3 = (CH / 4 * wino_plane(WAVES) + 63) / 64 * 64 + 64 * NCO * CH, kLdsP = 8 * 32 * 2 * WAVES + 64 * 2 * NCO;
     constexpr int kLdsBytes = 2 * (SRC2 && kLdsP > kLds3 ? kLdsP : kLds3) * 16;
     const int per_cu = kLdsBytes * 2 <= 160 * 1024 ? 2 : 1;
     long long grid = (long long)resident * per_cu;
