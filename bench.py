@@ -165,7 +165,7 @@ class WarpMatchDot:
                "kernel_ms": ms, "algorithmic_bytes_per_launch": alg, "frames_per_launch": self.B, "source_views": self.K, "depth_planes": self.D,
                "frames_per_s": self.B / (ms * 1e-3), "traffic": None,
                "note": "achieved = compulsory bytes (every input read once, every output written once) / kernel time; the kernel is bound by "
-                       "the on-chip gather + VALU work of D*K*N*4 bilinear taps, not by HBM (DESIGN.md 4.1)"}
+                       "the on-chip gather + VALU work of D*K*N*4 bilinear taps, not by HBM; BASELINE.json's >= 0.5 of the HBM peak is unattainable under this accounting: the packed-fp32 VALU floor of the sampling arithmetic alone is ~11 us/frame = 0.12 (DESIGN.md 4.1)"}
         pmc = _pmc_traffic(f"warp_match_dot/b{self.B}") if (self.K, self.D) == (8, 64) else None
         if pmc is not None and pmc.get("kernel") == self.dominant_kernel:
             out["traffic"], out["traffic_source"] = pmc["traffic_bytes_per_launch"], "profiles/pmc_traffic.json"
@@ -365,6 +365,49 @@ class HotPathWorkload:
         dom_res = (timed[self.dominant_kernel], len(dom), sum(self._conv_flops(o) for o in dom), sum(self._conv_executed_flops(o) for o in dom))
         all_res = (self._replay_ms(convs, iters), len(convs), sum(self._conv_flops(o) for o in convs), sum(self._conv_executed_flops(o) for o in convs))
         return dom_res, all_res
+
+    def fv_mlp_roofline(self, iters=10):
+        """The feature-volume kernel (`fv_mlp_k<K>`, second largest of the step) replayed alone between HIP events on the launch
+        stream, priced on the flops its MFMAs EXECUTE: per 16-voxel tile and plane 32 K (warped features) + 8 * 15 (metadata: 4
+        four-slot blocks minus the structurally-zero last slot) + 256 (layer 2) v_mfma_f32_16x16x4 of 2048 flops, + 64 per pixel
+        tile for the plane-independent pre-activation (csrc/feature_volume.hip; = SQ_INSTS_MFMA of the launch,
+        profiles/r03/pmc_mfma_util_hot_path_mlp_b32.json).  The algorithmic count of the reference's MLP (2 * MAC of
+        Linear(C (K+1) + 10 K + 4, 128), Linear(128, 128), Linear(128, 1), cost_volume.py:405-423) is reported beside it: the kernel
+        folds the current-view terms into a per-pixel pre-activation and the pose terms into a per-frame bias."""
+        if self.volume != "mlp" or self.K > 8 or self.C != 16:
+            return None
+        m = self.model
+        ent = next(iter(m._plans.values()))
+        d = self.d
+        call = lambda: m.cost_volume.fused_into(ent["cv_in"], ent["state"], ent["feats"], d["src_extrinsics"], d["src_poses"], d["src_Ks"],
+                                                d["cur_invK"], m.min_depth, m.max_depth, False)
+        for _ in range(2):
+            call()
+        times = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / iters)
+        ms = sorted(times)[1]
+        vox = self.B * self.H * self.W * self.D
+        executed = (vox // 16) * (32 * self.K + 120 + 256 + 64 / self.D) * 2048
+        n_in = self.C * (self.K + 1) + 10 * self.K + 4
+        algorithmic = 2 * vox * (n_in * 128 + 128 * 128 + 128)
+        busy = None
+        try:
+            rows = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_mfma_util_hot_path_mlp_b32.json")))
+            busy = next(r["mfma_util"] for r in rows if r["kernel"] == f"fv_mlp_k<{self.K}>") if (self.B, self.K, self.D) == (32, 7, 64) else None
+        except Exception:
+            pass
+        return {"kernel": f"fv_mlp_k<{self.K}>", "ms": ms, "bound": "mfma", "achieved": executed / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": executed / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "executed_flops_per_launch": executed,
+                "algorithmic_flops_per_launch": algorithmic, "achieved_algorithmic": algorithmic / (ms * 1e-3) / 1e12,
+                "mfma_busy": busy, "mfma_busy_source": "profiles/r03/pmc_mfma_util_hot_path_mlp_b32.json (SQ_VALU_MFMA_BUSY_CYCLES pass)" if busy else None,
+                "frames_per_launch": self.B}
 
     def metrics(self):
         """Per-frame metric rows (B, 120): PlaneEvaluator IoU / IoU+ / IoU- for 5 thresholds x 8 query
@@ -632,6 +675,11 @@ def main():
         }
         if split is not None:
             out["split_precision"] = split
+        if wl.name == "hot_path" and getattr(wl, "mlp_math", "fp32") == "fp32":
+            with torch.inference_mode():
+                fv = wl.fv_mlp_roofline()
+            if fv is not None:
+                out["fv_mlp"] = fv
         if wl.name == "hot_path" and not args.no_extras:
             # the north-star kernel on its own, same per-GPU batch (BASELINE.json configs[1]: K=8, D=64)
             a3 = copy.copy(args)

@@ -142,7 +142,8 @@ def fused_forward(model: nn.Module, math: str = None):
     is_bd = hasattr(model, "binary_mlp")
     opts = model.run_opts
     if getattr(opts, "matching_scale", 1) != 1:
-        raise _lib.IdhError("the fused forward covers matching_scale = 1 (every shipped configuration)")
+        raise _lib.IdhError("the fused forward covers matching_scale = 1: the only value the reference's BDModel / DepthModel constructors accept "
+                            "(0 and 2 raise IndexError in their channel lists, bd_model.py:75-83) and the one every shipped configuration uses")
 
     def forward(phase, cur_data, src_data, unbatched_matching_encoder_forward=False, return_mask=False, infer_depth=False, infer_res=None):
         if phase == "train":
