@@ -164,7 +164,7 @@ class WarpMatchDot:
         out = {"kernel": self.dominant_kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                "kernel_ms": ms, "algorithmic_bytes_per_launch": alg, "frames_per_launch": self.B, "source_views": self.K, "depth_planes": self.D,
                "frames_per_s": self.B / (ms * 1e-3), "traffic": None,
-               "note": "achieved = compulsory bytes (every input read once, every output written once) / kernel time; the kernel is bound by "
+               "note": "achieved = compulsory bytes (every input read once, every output written once) / time of the launch (cv_dot_win_k + its arg-max pass cv_argmax_k); bound by "
                        "the on-chip gather + VALU work of D*K*N*4 bilinear taps, not by HBM; BASELINE.json's >= 0.5 of the HBM peak is unattainable under this accounting: the packed-fp32 VALU floor of the sampling arithmetic alone is ~11 us/frame = 0.12 (DESIGN.md 4.1)"}
         pmc = _pmc_traffic(f"warp_match_dot/b{self.B}") if (self.K, self.D) == (8, 64) else None
         if pmc is not None and pmc.get("kernel") == self.dominant_kernel:
