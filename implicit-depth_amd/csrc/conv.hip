@@ -1442,8 +1442,26 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 }
                 int mix = 0;  // mixed prefix of small members
                 while (mix < run && kinds[mix] >= 0 && pcs[mix].blocks <= kLevelMaxBlocks) ++mix;
+                int wg = 0;  // prefix of Winograd convs with the same kind of second source: one persistent grid
+                if (op.kind == IDH_OP_CONV && pcs[0].lds_rows == 32) {
+                    wg = 1;
+                    while (wg < run && wg < wino_max_group() && ops[i + wg].kind == IDH_OP_CONV && pcs[wg].lds_rows == 32 &&
+                           (pcs[wg].a.s[1].in != nullptr) == (pcs[0].a.s[1].in != nullptr))
+                        ++wg;
+                }
                 int rc, used;
-                if (mix > cnt && mix > 1) {
+                if (wg > 1) {
+                    if (t_dry_run) {
+                        ++t_launches;
+                        rc = IDH_OK;
+                    } else {
+                        const ConvArgs *as[kMaxGroup];
+                        int ns[kMaxGroup];
+                        for (int j = 0; j < wg; ++j) { as[j] = &pcs[j].a; ns[j] = pcs[j].n_img; }
+                        rc = launch_conv_wino_group(as, ns, wg, st);
+                    }
+                    used = wg;
+                } else if (mix > cnt && mix > 1) {
                     rc = launch_level(pcs, kinds, mix, st);
                     used = mix;
                 } else if (cnt > 1) {

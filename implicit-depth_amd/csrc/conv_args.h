@@ -67,5 +67,7 @@ int launch_conv_split(const ConvArgs &a, int N, int mode, int rows, hipStream_t 
 // conv_wino.hip: Winograd F(2x2,3x3) on the fp32 matrix cores (3x3 stride 1, zero padding, one source, Cout % 32 == 0)
 bool wino_supported(const ConvArgs &a);
 int launch_conv_wino(const ConvArgs &a, int N, int rows, hipStream_t st);  // rows = 16 | 8 (tile rows per workgroup)
+int wino_max_group();
+int launch_conv_wino_group(const ConvArgs *const *as, const int *Ns, int n, hipStream_t st);  // independent convs, one persistent grid
 
 }  // namespace idh_conv

@@ -105,8 +105,18 @@ struct WinoArgs {
 // accumulated in the OUTPUT domain: after the Winograd steps the tile runs "P steps" of 16 channels each — the same halo
 // region of x (4 planes, only the patch centres are read) and a 2 KiB panel of the ordinary packed 1x1 weights in the same
 // two LDS stages — whose MFMAs add W1 . x to the 2x2 output pixels directly (the registers that hold the residual tile).
+// float4 slots of one of the two LDS stages
 template <int WAVES, int NCO, int CH, bool SRC2>
-__global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs wa) {
+constexpr int wino_stage_slots() {
+    constexpr int halo = ((CH / 4) * wino_plane(WAVES) + 63) / 64 * 64;
+    constexpr int s3 = halo + 64 * NCO * 4 * (CH / 4), sp = 8 * 32 * 2 * WAVES + 64 * 2 * NCO;
+    return SRC2 && sp > s3 ? sp : s3;
+}
+
+// The persistent tile loop of ONE convolution as seen by workgroup `vblock` of `vgrid` (the launch's own block index for a
+// single op; rotated per op in a grouped launch so that small ops land on different workgroups).
+template <int WAVES, int NCO, int CH, bool SRC2>
+__device__ __forceinline__ void wino_tiles(const WinoArgs &wa, f32x4 *lds, const unsigned vblock, const unsigned vgrid) {
     constexpr int KS = CH / 4;   // MFMA k-steps per K step = consecutive channels per lane
     constexpr int NP = CH / 4;   // 4-channel planes of the halo per K step
     typedef float vec __attribute__((ext_vector_type(KS)));
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     constexpr int kStage3 = kHalo + 64 * kPanelPieces;   // float4 slots of a Winograd step's stage
     constexpr int kStageP = 8 * kTight + 64 * 2 * NCO;   // ... of a P step's (SRC2): 32 channels of the tile + 2 x NCO panel pieces
     constexpr int kStage = SRC2 && kStageP > kStage3 ? kStageP : kStage3;
-    __shared__ f32x4 lds[2 * kStage];
+    static_assert(kStage == wino_stage_slots<WAVES, NCO, CH, SRC2>(), "stage size used by the kernels' LDS declaration");
 
     const ConvArgs &a = wa.c;
     const ConvSrc &s = a.s[0];
@@ -155,13 +165,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
     // share an input tile (the NT channel tiles, neighbouring halos) hit the same L2 at about the same time.
     const int T = wa.tiles;
     int t_cur, t_end, t_stride;
-    if ((gridDim.x & 7) == 0) {
-        const int xcd = blockIdx.x & 7;
-        t_stride = gridDim.x >> 3;
-        t_cur = (int)((long long)T * xcd / 8) + (int)(blockIdx.x >> 3);
+    if ((vgrid & 7) == 0) {
+        const int xcd = vblock & 7;
+        t_stride = vgrid >> 3;
+        t_cur = (int)((long long)T * xcd / 8) + (int)(vblock >> 3);
         t_end = (int)((long long)T * (xcd + 1) / 8);
     } else {
-        t_cur = blockIdx.x; t_end = T; t_stride = gridDim.x;
+        t_cur = vblock; t_end = T; t_stride = vgrid;
     }
     if (t_cur >= t_end) return;
 
@@ -528,25 +538,82 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs w
 }
 
 template <int WAVES, int NCO, int CH, bool SRC2>
-int launch_wino(const ConvArgs &a, int N, hipStream_t st) {
-    WinoArgs wa{a, (a.Wo + kWinoTileW - 1) / kWinoTileW, (a.Ho + 2 * WAVES - 1) / (2 * WAVES), 0};
+__global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_k(const WinoArgs wa) {
+    __shared__ f32x4 lds[2 * wino_stage_slots<WAVES, NCO, CH, SRC2>()];
+    wino_tiles<WAVES, NCO, CH, SRC2>(wa, lds, blockIdx.x, gridDim.x);
+}
+
+// Several mutually independent convolutions of one dependency level (the UNet++ grid at small batch: 3-6 convs of 48-400 tiles
+// each) behind ONE persistent grid: a workgroup walks its share of op 0, then of op 1, ... without a device-wide barrier in
+// between, so that the tail of one op is filled by the next one's tiles instead of idling (and a launch boundary) per op.
+constexpr int kWinoMaxGroup = 6;
+struct WinoGroupArgs {
+    WinoArgs op[kWinoMaxGroup];
+    int rot[kWinoMaxGroup];  // per-XCD rotation of the workgroup index: an op's tiles start where the previous op's ended
+    int n;
+};
+template <int WAVES, int NCO, int CH, bool SRC2>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_group_k(const WinoGroupArgs g) {
+    __shared__ f32x4 lds[2 * wino_stage_slots<WAVES, NCO, CH, SRC2>()];
+    const unsigned per = gridDim.x >> 3;  // the grid is a multiple of the 8 XCDs
+    for (int i = 0; i < g.n; ++i) {
+        const unsigned vblock = (((blockIdx.x >> 3) + per - (unsigned)g.rot[i] % per) % per) << 3 | (blockIdx.x & 7);
+        wino_tiles<WAVES, NCO, CH, SRC2>(g.op[i], lds, vblock, gridDim.x);
+        __syncthreads();  // the next op's first copies overwrite the LDS stages
+    }
+}
+
+template <int WAVES, int NCO>
+int wino_args(const ConvArgs &a, int N, WinoArgs &wa) {
+    wa = WinoArgs{a, (a.Wo + kWinoTileW - 1) / kWinoTileW, (a.Ho + 2 * WAVES - 1) / (2 * WAVES), 0};
     wa.c.NT = a.Cout / (16 * NCO);
     const long long tiles = (long long)N * wa.tiles_x * wa.tiles_y * wa.c.NT;
     if (tiles >= (1ll << 31)) return IDH_EUNSUPPORTED;
     wa.tiles = (int)tiles;
-    // persistent grid: as many workgroups as the chip holds at once (LDS-limited), a multiple of the 8 XCDs
+    return IDH_OK;
+}
+
+// persistent grid: as many workgroups as the chip holds at once (LDS-limited)
+template <int WAVES, int NCO, int CH, bool SRC2>
+long long wino_resident() {
     static int resident = 0;
     if (resident == 0) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         resident = cus > 0 ? cus : 256;
     }
-    constexpr int kLds3 = (CH / 4 * wino_plane(WAVES) + 63) / 64 * 64 + 64 * NCO * CH, kLdsP = 8 * 32 * 2 * WAVES + 64 * 2 * NCO;
-    constexpr int kLdsBytes = 2 * (SRC2 && kLdsP > kLds3 ? kLdsP : kLds3) * 16;
-    const int per_cu = kLdsBytes * 2 <= 160 * 1024 ? 2 : 1;
-    long long grid = (long long)resident * per_cu;
-    if (grid > tiles) grid = tiles >= 8 ? tiles / 8 * 8 : tiles;
+    constexpr int kLdsBytes = 2 * wino_stage_slots<WAVES, NCO, CH, SRC2>() * 16;
+    return (long long)resident * (kLdsBytes * 2 <= 160 * 1024 ? 2 : 1);
+}
+
+template <int WAVES, int NCO, int CH, bool SRC2>
+int launch_wino(const ConvArgs &a, int N, hipStream_t st) {
+    WinoArgs wa;
+    if (int rc = wino_args<WAVES, NCO>(a, N, wa)) return rc;
+    long long grid = wino_resident<WAVES, NCO, CH, SRC2>();  // a multiple of the 8 XCDs
+    if (grid > wa.tiles) grid = wa.tiles >= 8 ? wa.tiles / 8 * 8 : wa.tiles;
     hipLaunchKernelGGL((conv3x3_wino_k<WAVES, NCO, CH, SRC2>), dim3((unsigned)grid), dim3(64 * WAVES), 0, st, wa);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
+
+template <int WAVES, int NCO, int CH, bool SRC2>
+int launch_wino_group(const ConvArgs *const *as, const int *Ns, int n, hipStream_t st) {
+    WinoGroupArgs g{};
+    long long total = 0;
+    int rot = 0;
+    const long long res = wino_resident<WAVES, NCO, CH, SRC2>();
+    for (int i = 0; i < n; ++i) {
+        if (int rc = wino_args<WAVES, NCO>(*as[i], Ns[i], g.op[i])) return rc;
+        g.rot[i] = rot;
+        rot = (int)((rot + (g.op[i].tiles + 7) / 8) % (res / 8));  // tiles per XCD of this op
+        total += g.op[i].tiles;
+    }
+    g.n = n;
+    long long grid = res;
+    if (grid > total) grid = total >= 8 ? total / 8 * 8 : 8;
+    if ((grid & 7) || (res & 7)) return IDH_EUNSUPPORTED;  // the rotation assumes whole XCD octets (callers fall back to single launches)
+    hipLaunchKernelGGL((conv3x3_wino_group_k<WAVES, NCO, CH, SRC2>), dim3((unsigned)grid), dim3(64 * WAVES), 0, st, g);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }
@@ -563,6 +630,17 @@ bool wino_supported(const ConvArgs &a) {
     return s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && src2_ok && a.S == 1 && (a.Cout % 32) == 0 &&
            (long long)s.H * s.W * s.cs * 4 < (1ll << 31) && (long long)a.Ho * a.Wo * a.out_cs * 4 < (1ll << 31) &&
            (!a.res || (long long)a.Ho * a.Wo * a.res_cs * 4 < (1ll << 31)) && (long long)s.cblocks * a.Cout_pad * 1024 < (1ll << 31);
+}
+
+int wino_max_group() { return kWinoMaxGroup; }
+
+// n mutually independent Winograd convs (all with, or all without, a fused 1x1 second source) as one persistent grid
+int launch_conv_wino_group(const ConvArgs *const *as, const int *Ns, int n, hipStream_t st) {
+    if (n < 1 || n > kWinoMaxGroup) return IDH_EINVAL;
+    const bool src2 = as[0]->s[1].in != nullptr;
+    for (int i = 0; i < n; ++i)
+        if (!wino_supported(*as[i]) || (as[i]->s[1].in != nullptr) != src2) return IDH_EUNSUPPORTED;
+    return src2 ? launch_wino_group<4, 2, kWinoCH, true>(as, Ns, n, st) : launch_wino_group<4, 2, kWinoCH, false>(as, Ns, n, st);
 }
 
 int launch_conv_wino(const ConvArgs &a, int N, int rows, hipStream_t st) {

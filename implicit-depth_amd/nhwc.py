@@ -177,6 +177,8 @@ TILE_WINO = 12  # IDH_TILE_WINO of include/idh_ops.h == the op's tile_m
 WINOGRAD = True
 WINO_MIN_TILES = 128
 WINO_MIN_FILL = 0.74
+# the Winograd convs of one dependency level as ONE persistent grid (conv3x3_wino_group_k): bit-identical, fewer launch tails
+WINO_GROUP = True
 
 
 def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> bool:
@@ -621,6 +623,10 @@ class Plan:
         4-row LDS convs first, by channel tile (one ``conv3x3_lds_group_k`` grid per run of equal tiles); then, with
         ``MERGE_LEVELS``, the other members a mixed ``level_k`` launch can host (csrc/conv.hip: the stride-2 /
         1x1 direct conv with 16x64 wave tiles, bilinear x2 upsampling); everything else runs on its own."""
+        if WINO_GROUP and op.kind == OP_CONV and op.tile_m == TILE_WINO:
+            # Winograd convs of a level share one persistent grid (conv3x3_wino_group_k): plain ones, then those with a fused
+            # 1x1 source; the largest first so that the small ones fill its tail
+            return (-1, 1 if op.src[1].in_ else 0, -op.N * op.Ho * op.Wo * op.Cout)
         if op.kind == OP_CONV and op.tile_m == 9:
             return (0, op.tile_n)
         if MERGE_LEVELS and op.kind == OP_CONV and op.tile_m == 1 and op.tile_n == 4:
@@ -746,7 +752,7 @@ class PlanCache:
 def build_flags() -> tuple:
     """Module-level switches that shape a plan at build time (part of every plan-cache key: toggling one takes effect on the
     next call instead of silently replaying a plan built under the old setting)."""
-    return (FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
+    return (WINO_GROUP, FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
             SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, DEFAULT_MATH)
 
 

@@ -171,3 +171,44 @@ def test_default_plan_uses_wino_at_bench_batch():
         p = nhwc.Plan(x.device)
         p.conv(nhwc.View(x, 0, 64), conv, p.buffer(B, H, W, 64))
         assert (p.ops[0].tile_m == nhwc.TILE_WINO) == want
+
+
+def test_grouped_launch_of_a_level_is_bit_identical(wino_everywhere):
+    """independent Winograd convs of one dependency level run as ONE persistent grid (conv3x3_wino_group_k): every op keeps
+    its own tiles and arithmetic, so the results are bit-identical to one launch per op — for plain convs, for convs with a
+    fused 1x1 source, and for ops with fewer tiles than workgroups (some workgroups skip an op entirely)"""
+    nhwc = wino_everywhere
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shapes = [(2, 64, 64, 48, 64, 0), (1, 32, 64, 24, 40, 0), (2, 96, 32, 16, 32, 0), (1, 64, 64, 8, 32, 0), (2, 64, 64, 24, 64, 48), (1, 32, 96, 16, 32, 80)]
+    convs, projs, xs, x2s = [], [], [], []
+    for i, (B, cin, cout, H, W, c2) in enumerate(shapes):
+        conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
+        syn.fill_state_dict(conv, seed=11 + i)
+        convs.append(conv)
+        xs.append(torch.randn(B, H, W, cin, device="cuda", generator=g))
+        proj = nn.Conv2d(c2, cout, 1).cuda() if c2 else None
+        if proj is not None:
+            syn.fill_state_dict(proj, seed=31 + i)
+        projs.append(proj)
+        x2s.append(torch.randn(B, H, W, c2, device="cuda", generator=g) if c2 else None)
+    outs = {}
+    for group in (False, True):
+        old = nhwc.WINO_GROUP
+        nhwc.WINO_GROUP = group
+        try:
+            p = nhwc.Plan(xs[0].device)
+            bufs = []
+            for conv, proj, x, x2, (B, cin, cout, H, W, c2) in zip(convs, projs, xs, x2s, shapes):
+                o = p.buffer(B, H, W, cout)
+                p.conv(nhwc.View(x, 0, cin), conv, o, act=1, slope=0.2, x2=None if proj is None else nhwc.View(x2, 0, c2), conv2=proj)
+                bufs.append(o)
+            p.schedule()
+            assert all(op.tile_m == nhwc.TILE_WINO for op in p.ops)
+            assert p.count_launches() == (2 if group else len(shapes))  # one grid for the plain convs, one for those with a 1x1 source
+            p.run()
+            torch.cuda.synchronize()
+            outs[group] = [b.dense().clone() for b in bufs]
+        finally:
+            nhwc.WINO_GROUP = old
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
