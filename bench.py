@@ -329,12 +329,13 @@ class HotPathWorkload:
         return fl
 
     @staticmethod
-    def _kernel_family(op):
-        """rocprofv3's name of the kernel a conv op of the plan launches, from its tile codes (idh_op.tile_m / tile_n)"""
+    def _kernel_family(op, grouped=False):
+        """rocprofv3's name of the kernel a conv op of the plan launches, from its tile codes (idh_op.tile_m / tile_n);
+        `grouped`: the op shares a persistent grid with other Winograd convs of its dependency level"""
         from implicit_depth_amd import nhwc
 
         if op.tile_m == nhwc.TILE_WINO:
-            return f"conv3x3_wino_k<4, 2, 8, {'true' if op.src[1].in_ else 'false'}>"
+            return f"conv3x3_wino_{'group_' if grouped else ''}k<4, 2, 8, {'true' if op.src[1].in_ else 'false'}>"
         if op.tile_m in (10, 11):
             return "conv3x3_split_k<4, 2, 1, *>"
         if op.tile_m in (8, 9):
@@ -354,16 +355,38 @@ class HotPathWorkload:
         ent = next(iter(self.model._plans.values()))
         p = ent["plan"]
         convs = [op for op in p.ops if op.kind == nhwc.OP_CONV]
+        # idh_run_ops launches a run of consecutive Winograd convs that share a level's group id (and the kind of second source)
+        # as one conv3x3_wino_group_k grid, at most 6 at a time (csrc/conv.hip: idh_run_ops, csrc/conv_wino.hip: kWinoMaxGroup)
+        grouped, launches_of = {}, {}
+        i = 0
+        while i < len(p.ops):
+            op = p.ops[i]
+            j = i + 1
+            if op.kind == nhwc.OP_CONV and op.tile_m == nhwc.TILE_WINO and op.group:
+                while (j < len(p.ops) and j - i < 6 and p.ops[j].kind == nhwc.OP_CONV and p.ops[j].tile_m == nhwc.TILE_WINO and p.ops[j].group == op.group
+                       and bool(p.ops[j].src[1].in_) == bool(op.src[1].in_)):
+                    j += 1
+            for k in range(i, j):
+                grouped[id(p.ops[k])] = j - i > 1
+            i = j
         fams = {}
         for op in convs:
-            fams.setdefault(self._kernel_family(op), []).append(op)
+            fams.setdefault(self._kernel_family(op, grouped.get(id(op), False)), []).append(op)
         # the two families with the most algorithmic flops are timed; the slower one is the dominant kernel
         cand = sorted(fams, key=lambda k: -sum(self._conv_flops(o) for o in fams[k]))[:2]
         timed = {k: self._replay_ms(fams[k], iters) for k in cand}
         self.dominant_kernel = max(timed, key=timed.get)
         dom = fams[self.dominant_kernel]
-        dom_res = (timed[self.dominant_kernel], len(dom), sum(self._conv_flops(o) for o in dom), sum(self._conv_executed_flops(o) for o in dom))
-        all_res = (self._replay_ms(convs, iters), len(convs), sum(self._conv_flops(o) for o in convs), sum(self._conv_executed_flops(o) for o in convs))
+        def launches(ops):  # kernel launches of a replayed op list (idh_count_launches: same decisions as idh_run_ops)
+            import ctypes as C
+
+            from implicit_depth_amd import _lib
+
+            arr = (nhwc.Op * len(ops))(*ops)
+            return int(_lib.lib().idh_count_launches(C.cast(arr, C.c_void_p), len(ops)))
+
+        dom_res = (timed[self.dominant_kernel], launches(dom), sum(self._conv_flops(o) for o in dom), sum(self._conv_executed_flops(o) for o in dom))
+        all_res = (self._replay_ms(convs, iters), launches(convs), sum(self._conv_flops(o) for o in convs), sum(self._conv_executed_flops(o) for o in convs))
         return dom_res, all_res
 
     def fv_mlp_roofline(self, iters=10):
