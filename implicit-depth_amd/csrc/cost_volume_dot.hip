@@ -1068,7 +1068,7 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
 
 extern "C" const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D) {
     const int which = cv_pick_kernel(0, B, K, H, W, D);
-    return which == IDH_CV_KERNEL_WINDOW ? "cv_dot_win_k" : (which == IDH_CV_KERNEL_QUAD ? "cv_dot_quad_k" : "cv_dot_k");
+    return which == IDH_CV_KERNEL_WINDOW ? "cv_dot_win_k<false>" : (which == IDH_CV_KERNEL_QUAD ? "cv_dot_quad_k" : "cv_dot_k");
 }
 
 extern "C" int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
