@@ -553,8 +553,31 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
     const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
     unsigned long long tr_wait = 0, tr_comp = 0, tr_prolog = 0;
 #endif
+    // Task order = dispatch order: each XCD (blocks b % 8) walks one contiguous range of tiles, the plane groups of a tile
+    // back to back (they share its source maps in that XCD's L2).  A plane group's work grows with its depth — near planes have
+    // the larger parallax, most of their samples leave the source images and are skipped: 50 k ... 235 k cycles per workgroup
+    // from the nearest to the farthest quarter of 64 planes — and the dispatcher hands consecutive workgroups of an XCD to its
+    // 32 CUs in turn, so with 2, 4 or 8 plane groups a CU would only ever see ONE group (a quarter of the CUs gets all the far
+    // planes).  Rotating the group order by one every 32 workgroups gives every CU every group in turn.
     unsigned lin = idh_xcd_remap(blockIdx.x, gridDim.x);
-    const int sp = lin % a.psplit; lin /= a.psplit;
+    int sp = lin % a.psplit;
+    lin /= a.psplit;
+#ifndef IDH_ABL_DOT_NOROTATE
+    sp = (int)((sp + lin * a.psplit / 32) % a.psplit);
+#endif
+#ifdef IDH_ABL_DOT_FARFIRST_CHUNKED  // all far-plane groups of a frame's tiles first: loses the interleave (D = 96: +12 %)
+    {
+        const unsigned ntiles = (unsigned)(a.B * a.tiles_x * a.tiles_y);
+        if ((ntiles & 7) == 0) {
+            const unsigned per = ntiles >> 3, slot = blockIdx.x >> 3;
+            const unsigned frame = (unsigned)(a.tiles_x * a.tiles_y);
+            const unsigned chunk = per % frame == 0 ? frame : per;
+            const unsigned c = slot / (chunk * a.psplit), within = slot - c * chunk * a.psplit;
+            sp = a.psplit - 1 - (int)(within / chunk);
+            lin = (blockIdx.x & 7) * per + c * chunk + within % chunk;
+        }
+    }
+#endif
     const int tx = lin % a.tiles_x; lin /= a.tiles_x;
     const int ty = lin % a.tiles_y;
     const int b = lin / a.tiles_y;
@@ -955,8 +978,13 @@ static void cv_win_split(int B, int K, int H, int W, int D, int *psplit, int *un
 #define IDH_DOT_SPLIT_MIN 6144  // >= 6 rounds of 256 CUs x 4 workgroups: a tile's work varies 8x with its position (fewer, longer workgroups leave CUs idle at the tail)
 #endif
     while (per > 4 && (tiles * idh_cdiv(nunits, per) < IDH_DOT_SPLIT_MIN || (long long)(per / 4) * K > kMaxPairs)) per = 4 * idh_cdiv(per / 4, 2);
-    if (per == 4 && tiles * idh_cdiv(nunits, per) < 512) per = 2;
-    if (per == 2 && tiles * idh_cdiv(nunits, per) < 512) per = 1;
+    // small batches: 8- and 4-plane slices until the grid has two rounds of 256 CUs x 4 workgroups (measured, 96x128 map, K = 8, D = 64:
+    // B = 8: 29.2 -> 27.2 us/frame with 8-plane slices, B = 4: 39.9 -> 36.4 and B = 2: 72.8 -> 49.3 with 4-plane slices)
+    if (per == 4 && tiles * idh_cdiv(nunits, per) < 2048) per = 2;
+    if (per == 2 && tiles * idh_cdiv(nunits, per) < 2048) per = 1;
+#ifdef IDH_ABL_DOT_PER
+    per = IDH_ABL_DOT_PER;
+#endif
     *units_per_split = per;
     *psplit = idh_cdiv(nunits, per);
 }
@@ -967,8 +995,8 @@ static int cv_pick_kernel(int forced, int B, int K, int H, int W, int D, int C =
     const bool quad_ok = (long long)K * H * W * kC < (1ll << 31) && K > 0;  // 32-bit tap offsets within one (b,k) image
     const bool win_ok = quad_ok && W >= kWW && H >= kWH && W < 32768 && H < 32768 && K <= kMaxPairs;  // PlaneBox / WinEntry pack coordinates in 15 / 16 bits
     (void)D;
-    // measured (tools/perf_dot.py, 96x128 map, K=8, D=64): window 25 us/frame at B=32, 35 at B=8, 42 at B=4, 71 at B=1;
-    // quad 51 / 57 / 57 / 59 -> a single frame (48 tiles) cannot fill 256 CUs with whole tiles and stays on the quad kernel
+    // measured (tools/perf_dot.py, 96x128 map, K=8, D=64): window 18.6 us/frame at B=32, 27 at B=8, 36 at B=4, 49 at B=2, 72 at B=1;
+    // quad 51 / 57 / 57 / 58 / 58 -> a single frame (48 tiles) cannot fill 256 CUs and stays on the quad kernel
     const bool win_pays = (long long)B * idh_cdiv(W, kTileW) * idh_cdiv(H, kTileH) >= 96;
     switch (forced) {
         case 0: return (win_ok && win_pays) ? IDH_CV_KERNEL_WINDOW : (quad_ok ? IDH_CV_KERNEL_QUAD : IDH_CV_KERNEL_LANE);

@@ -70,3 +70,6 @@ if os.environ.get("IDH_PRINT_TRACE"):
     cu0 = sorted(per_cu.keys())[5]
     iv = sorted(per_cu[cu0]); base = iv[0][0]
     print("CU", cu0, "timeline (start, end) in kiloticks:", [(round((a0 - base) / 1e3), round((b0 - base) / 1e3)) for a0, b0 in iv])
+    if PS > 1:
+        bysp = t[:, :, 0, 0].view(w.B, 48, PS).mean((0, 1))
+        print("mean workgroup ticks by plane split index:", [int(x) for x in bysp], " by tile column:", [int(x) for x in t[:, :, 0, 0].view(w.B, 12, 4, PS).mean((0, 1, 3))])
