@@ -491,8 +491,9 @@ __device__ __forceinline__ WinCell cv_cell(const Sample &s, int wx0, int wy0, in
     c.ok = inside && any_w;
     c.fb = any_w && !inside;
     c.a00 = c.ok ? cy0 * kRowPitch + cx0 * 64 : 0;
-    c.dx = c.ok ? (cx1 - cx0) * 64 : 0;
-    c.dy = c.ok ? (cy1 - cy0) * kRowPitch : 0;
+    // (a masked lane reads texels 0 / 1 of rows 0 / 1: its cell is at most one texel wide — no select needed on the steps)
+    c.dx = (cx1 - cx0) * 64;
+    c.dy = (cy1 - cy0) * kRowPitch;
     return c;
 }
 __device__ __forceinline__ float cv_sample_win(const Sample &s, const WinCell &w, const unsigned char *win, const f32x2 (&c)[8]) {
@@ -578,7 +579,12 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
         }
     }
 #endif
-    const int tx = lin % a.tiles_x; lin /= a.tiles_x;
+    int tx = lin % a.tiles_x; lin /= a.tiles_x;
+#ifndef IDH_ABL_DOT_NOROTATE_TX
+    // the same for the tile columns (a tile's work depends on where it lies in the image: here 70 k ... 205 k cycles from the left to
+    // the right column): the column order of a tile row advances by one every 32 tiles, i.e. once per full turn of the plane groups
+    tx = (int)((tx + lin * a.tiles_x / 32) % a.tiles_x);
+#endif
     const int ty = lin % a.tiles_y;
     const int b = lin / a.tiles_y;
     const int nunits_all = (D + 3) >> 2;
@@ -894,7 +900,15 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
             float v = cv_sample_win(sm, wc, win, c);
 #endif
             if (__builtin_amdgcn_ballot_w64(wc.fb) != 0) {
+#ifdef IDH_ABL_DOT_EAGER_FALLBACK
                 if (wc.fb) v = cv_sample_global(sm, sb, W, c);
+#else
+                // rare: re-project behind an opaque copy of the plane index so that none of the fallback's 64-bit address
+                // arithmetic is hoisted into the common path
+                int jo = j;
+                asm volatile("" : "+s"(jo));
+                if (wc.fb) v = cv_sample_global(cv_project(depth_of(jo), qx, qy, qz, h9, h10, h11, Wf, Hf, W, H), sb, W, c);
+#endif
             }
             return v;
         };
