@@ -237,12 +237,14 @@ def test_every_kernel_matches_reference_golden(name, kernel):
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 16, 40, 70, 9), (1, 8, 16, 33, 67, 13), (3, 7, 16, 24, 64, 64), (1, 2, 16, 12, 64, 1),
-                                   (2, 16, 16, 37, 90, 6), (1, 4, 16, 21, 130, 35), (1, 16, 16, 12, 48, 130), (40, 2, 16, 16, 48, 20)])
+                                   (2, 16, 16, 37, 90, 6), (1, 4, 16, 21, 130, 35), (1, 16, 16, 12, 48, 130), (40, 2, 16, 16, 48, 20),
+                                   (12, 3, 16, 40, 160, 40), (9, 5, 16, 56, 96, 80)])
 def test_window_kernel_matches_oracle_fp64(shape):
     """Ragged tiles (maps that are not multiples of 32 x 8), D not a multiple of 16 or 4, K up to 16, views behind the
     camera and strongly rotated views, batch > 1; the smallest map the kernel takes (48 x 12) with many planes (the
     launch splits the planes over workgroups and runs the separate arg-max kernel) and a batch large enough that it
-    does not."""
+    does not; 5 x 5 and 3 x 7 tile grids over many frames with 3 and 5 plane groups (the task order rotates plane groups and
+    tile columns: every (tile, group) must still be computed exactly once)."""
     B, K, C, H, W, D = shape
     inp = syn.cost_volume_inputs(B, K, C, H, W, seed=B + K, behind_view=K - 1 if K > 2 else -1, big_rotation_view=0 if K > 3 else -1)
     cv, low, planes = _run(inp, D, KERNELS["window"])
