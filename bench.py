@@ -118,6 +118,10 @@ class WarpMatchDot:
         self.lowest = torch.empty(self.B, self.H, self.W, device=device)
         self.planes = torch.empty(self.D, device=device)
         self.dominant_kernel = self.L.idh_cost_volume_dot_kernel_name(self.B, self.K, self.H, self.W, self.D).decode()
+        # the drop-in (CostVolumeManager / HotPath) passes the optional arg-max scratch of idh_volume_opts: so does the bench
+        from implicit_depth_amd.cost_volume import volume_opts
+
+        self.opts, self._keep = volume_opts(self.B, self.K, self.C, self.H, self.W, self.D, dot_scratch_device=device)
 
     def config(self):
         return {"workload": f"{self.name}: fused plane-sweep warp+match, {self.W * 4}x{self.H * 4} image, matching map {self.W}x{self.H}, "
@@ -131,12 +135,12 @@ class WarpMatchDot:
         p, L = self._lib.ptr, self.L
         if ev is not None:
             ev[0].record()
-        rc = L.idh_cost_volume_dot_fwd(p(self.cur), p(self.src), p(self.Ks), p(self.E), p(self.invK), 0.25, 5.0,
-                                       self.B, self.K, self.C, self.H, self.W, self.D, p(self.cost), 0, p(self.lowest),
-                                       p(self.planes), self._lib.stream_ptr())
+        rc = L.idh_cost_volume_dot_ex_fwd(p(self.cur), p(self.src), p(self.Ks), p(self.E), p(self.invK), 0.25, 5.0,
+                                          self.B, self.K, self.C, self.H, self.W, self.D, p(self.cost), 0, p(self.lowest),
+                                          p(self.planes), self.opts, self._lib.stream_ptr())
         if ev is not None:
             ev[1].record()
-        self._lib.check(rc, "idh_cost_volume_dot_fwd")
+        self._lib.check(rc, "idh_cost_volume_dot_ex_fwd")
 
     def frames_per_step(self):
         return self.B

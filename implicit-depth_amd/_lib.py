@@ -30,7 +30,7 @@ class VolumeOpts(C.Structure):
 
     _fields_ = [("cur_batch_stride", C.c_int64), ("src_batch_stride", C.c_int64), ("planes", C.c_void_p),
                 ("planes_batch_stride", C.c_int64), ("planes_plane_stride", C.c_int64), ("planes_pixel_stride", C.c_int32),
-                ("kernel", C.c_int32)]
+                ("kernel", C.c_int32), ("scratch", C.c_void_p), ("scratch_floats", C.c_int64)]
 
 
 CV_KERNEL_LANE, CV_KERNEL_QUAD, CV_KERNEL_WINDOW = 1, 2, 3  # IDH_CV_KERNEL_* of include/idh.h
@@ -38,6 +38,7 @@ CV_KERNEL_LANE, CV_KERNEL_QUAD, CV_KERNEL_WINDOW = 1, 2, 3  # IDH_CV_KERNEL_* of
 
 _SIGS = {
     "idh_version": (C.c_int, []),
+    "idh_cost_volume_dot_scratch_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "idh_error_string": (C.c_char_p, [C.c_int]),
     "idh_nchw_to_nhwc_f32": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idh_nhwc_to_nchw_f32": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

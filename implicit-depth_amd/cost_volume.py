@@ -49,16 +49,24 @@ def _is_device_scalar(v) -> bool:
     return torch.is_tensor(v) and v.is_cuda
 
 
-def volume_opts(B, K, C, H, W, D, planes_bdhw: Optional[Tensor] = None, cur_batch_stride: int = 0, src_batch_stride: int = 0, kernel: int = 0):
+def volume_opts(B, K, C, H, W, D, planes_bdhw: Optional[Tensor] = None, cur_batch_stride: int = 0, src_batch_stride: int = 0, kernel: int = 0,
+                dot_scratch_device=None):
     """``idh_volume_opts`` for one launch -> (ctypes struct or None, keep-alive list).  ``planes_bdhw`` is the
     reference's ``depth_planes_bdhw`` (modules/cost_volume.py:324-347): any (B,D,H,W) fp32 device tensor; views
     that are constant over the image (``expand()``ed (B,D,1,1) / (1,D,1,1), what generate_depth_planes returns)
     are passed by stride, anything else as a dense per-pixel map."""
-    if planes_bdhw is None and not cur_batch_stride and not src_batch_stride and not kernel:
+    # dot-product volume (``dot_scratch_device`` given): scratch that lets the arg-max pass of a plane-split launch combine per-group
+    # results instead of re-reading the volume (idh_volume_opts.scratch); taken from torch's stream-ordered caching allocator
+    n_scratch = int(_lib.lib().idh_cost_volume_dot_scratch_floats(B, K, C, H, W, D)) if dot_scratch_device is not None else 0
+    if planes_bdhw is None and not cur_batch_stride and not src_batch_stride and not kernel and not n_scratch:
         return None, []
     o = _lib.VolumeOpts()
     o.cur_batch_stride, o.src_batch_stride, o.kernel = int(cur_batch_stride), int(src_batch_stride), int(kernel)
     keep = []
+    if n_scratch:
+        sc = torch.empty(n_scratch, device=dot_scratch_device, dtype=torch.float32)
+        o.scratch, o.scratch_floats = sc.data_ptr(), n_scratch
+        keep.append(sc)
     if planes_bdhw is not None:
         pl = planes_bdhw
         _lib.require_cuda_f32(pl)
@@ -133,7 +141,7 @@ class CostVolumeManager(nn.Module):
         lowest = torch.empty(B, H, W, device=dev, dtype=torch.float32)
         L = _lib.lib()
         planes_t, dmin, dmax = self._planes_arg(B, min_depth, max_depth, depth_planes_bdhw)
-        opts, keep = volume_opts(B, K, C, H, W, D, planes_t, kernel=self.__dict__.get("kernel", 0))
+        opts, keep = volume_opts(B, K, C, H, W, D, planes_t, kernel=self.__dict__.get("kernel", 0), dot_scratch_device=dev)
         planes_d = torch.empty(D, device=dev, dtype=torch.float32) if planes_t is None else None
         # keep the contiguous copies alive until the launch is enqueued (a temporary's block may be
         # recycled by the next .contiguous() before the kernel runs)

@@ -520,6 +520,7 @@ struct WinArgs {
     int B, K, H, W, D;
     int tiles_x, tiles_y, psplit, units_per_split;  // 4-plane units per workgroup: 1, 2 or a multiple of 4
     int list_bytes, planes_bytes;                   // dynamic LDS: window | run list | plane table | homographies
+    float *partial;                                 // [psplit][B N][2] (best cost, plane index) of each plane group, or null
     int cost_cs;
     CvExt ext;
 };
@@ -950,6 +951,10 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
     return;
 #endif
     if (a.lowest != nullptr && a.psplit == 1 && live) a.lowest[(size_t)b * N + p] = PLANES ? pl[(size_t)bidx * a.ext.planes_sd] : s_planes[bidx];
+    // planes split over workgroups: this group's (best cost, plane) per pixel for the combine pass (cv_argmax_partials_k) — 8 bytes
+    // instead of the pass re-reading the group's 4 D / psplit bytes of the volume
+    if (a.partial != nullptr && a.psplit > 1 && live)
+        *reinterpret_cast<float2 *>(a.partial + (((size_t)sp * a.B + b) * N + p) * 2) = make_float2(best, __builtin_bit_cast(float, bidx));
 }
 
 // lowest[b,p] = plane_{argmax_d cost[b,d,p]} (first maximum wins) for launches that split the planes over workgroups
@@ -973,6 +978,22 @@ __global__ __launch_bounds__(256) void cv_argmax_k(const float *__restrict__ cos
                 const float v = cost_cs > 0 ? cost[t * cost_cs + d] : cost[(b * D + d) * N + p];
                 if (v > best) { best = v; bi = d; }
             }
+        }
+        lowest[t] = ext.planes ? ext.planes[b * ext.planes_sb + (long long)bi * ext.planes_sd + p * ext.planes_sp] : depth_plane(bi, D, dmin, dmax);
+    }
+}
+
+// the same from the plane groups' partial results (ascending groups, strict >: the first maximum still wins)
+__global__ __launch_bounds__(256) void cv_argmax_partials_k(const float *__restrict__ partial, int psplit, int B, int N, int D, float dmin, float dmax,
+                                                            float *__restrict__ lowest, const CvExt ext) {
+    const long long total = (long long)B * N;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
+        const long long b = t / N, p = t - b * N;
+        float best = -INFINITY;
+        int bi = 0;
+        for (int g = 0; g < psplit; ++g) {
+            const float2 v = *reinterpret_cast<const float2 *>(partial + ((size_t)g * total + t) * 2);
+            if (v.x > best) { best = v.x; bi = __builtin_bit_cast(int, v.y); }
         }
         lowest[t] = ext.planes ? ext.planes[b * ext.planes_sb + (long long)bi * ext.planes_sd + p * ext.planes_sp] : depth_plane(bi, D, dmin, dmax);
     }
@@ -1062,6 +1083,8 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
         a.B = B; a.K = K; a.H = H; a.W = W; a.D = D; a.cost_cs = cost_nhwc_cs; a.ext = ext;
         a.tiles_x = idh_cdiv(W, kTileW); a.tiles_y = idh_cdiv(H, kTileH);
         cv_win_split(B, K, H, W, D, &a.psplit, &a.units_per_split);
+        // optional scratch for the arg-max over split planes (idh_volume_opts.scratch: >= idh_cost_volume_dot_scratch_floats)
+        a.partial = (opts && opts->scratch && lowest_bhw && a.psplit > 1 && opts->scratch_floats >= 2ll * a.psplit * B * H * W) ? opts->scratch : nullptr;
         a.list_bytes = ((a.units_per_split + 3) / 4) * K * kRunsPerPair * (int)sizeof(RunEntry);
         a.planes_bytes = ((D + 3) & ~3) * (int)sizeof(float);
         const size_t lds = (size_t)kWinBytes + a.list_bytes + a.planes_bytes + (size_t)K * 12 * sizeof(float);
@@ -1084,7 +1107,10 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
 #endif
             int g2 = idh_cdiv((long long)B * H * W, 256);
             if (g2 > 8192) g2 = 8192;
-            hipLaunchKernelGGL(cv_argmax_k, dim3(g2), dim3(256), 0, idh_stream(stream), cost, cost_nhwc_cs, B, H * W, D, dmin, dmax, lowest_bhw, ext);
+            if (a.partial)
+                hipLaunchKernelGGL(cv_argmax_partials_k, dim3(g2), dim3(256), 0, idh_stream(stream), a.partial, a.psplit, B, H * W, D, dmin, dmax, lowest_bhw, ext);
+            else
+                hipLaunchKernelGGL(cv_argmax_k, dim3(g2), dim3(256), 0, idh_stream(stream), cost, cost_nhwc_cs, B, H * W, D, dmin, dmax, lowest_bhw, ext);
             IDH_CHECK_LAUNCH();
         }
         return IDH_OK;
@@ -1106,6 +1132,13 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
 #undef IDH_LANE
     IDH_CHECK_LAUNCH();
     return IDH_OK;
+}
+
+extern "C" long long idh_cost_volume_dot_scratch_floats(int B, int K, int C, int H, int W, int D) {
+    if (B <= 0 || K < 0 || H <= 0 || W <= 0 || D <= 0 || cv_pick_kernel(0, B, K, H, W, D, C) != IDH_CV_KERNEL_WINDOW) return 0;
+    int psplit = 1, per = 0;
+    cv_win_split(B, K, H, W, D, &psplit, &per);
+    return psplit > 1 ? 2ll * psplit * B * H * W : 0;
 }
 
 extern "C" const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D) {

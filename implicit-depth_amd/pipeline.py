@@ -176,7 +176,7 @@ class HotPath(nn.Module):
             lowest = planes[:, 0]
         elif type(self.cost_volume) is CostVolumeManager:
             mats = [t if t.is_contiguous() else t.contiguous() for t in (src_K, src_cam_T_cur_cam, cur_invK)]  # alive until enqueued
-            opts, _keep = volume_opts(B, K, C, H, W, D, None, cbs, sbs, kernel=self.cost_volume.__dict__.get("kernel", 0))
+            opts, _keep = volume_opts(B, K, C, H, W, D, None, cbs, sbs, kernel=self.cost_volume.__dict__.get("kernel", 0), dot_scratch_device=dev)
             _lib.check(L.idh_cost_volume_dot_ex_fwd(cur_ptr, src_ptr, mats[0].data_ptr(), mats[1].data_ptr(), mats[2].data_ptr(),
                                                     self.min_depth, self.max_depth, B, K, C, H, W, D, ent["cv_in"].ptr, ent["cv_in"].cs,
                                                     lowest.data_ptr(), st["planes"].data_ptr(), opts, sp), "idh_cost_volume_dot_ex_fwd")

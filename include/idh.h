@@ -71,6 +71,11 @@ typedef struct idh_volume_opts {
     int32_t planes_pixel_stride;
     int32_t kernel; /* dot-product volume only: 0 = automatic (the launcher's choice), or force one IDH_CV_KERNEL_* —
                        a test / profiling hook so that every kernel can be checked against the same goldens */
+    float *scratch; /* dot-product volume only, optional: >= idh_cost_volume_dot_scratch_floats(...) floats of device memory.
+                       When the launch splits the depth planes over workgroups, each group leaves its (best cost, plane) per
+                       pixel here and the arg-max pass combines those instead of re-reading the whole volume (same result:
+                       first maximum wins).  NULL: no scratch, the pass reads the volume. */
+    int64_t scratch_floats;
 } idh_volume_opts;
 
 #define IDH_CV_KERNEL_LANE 1   /* cv_dot_k: one lane per sample, taps through the vector L1 */
@@ -90,7 +95,7 @@ typedef struct idh_volume_opts {
  *   cost       out: (B,D,H,W) when cost_nhwc_cs == 0 (the reference's layout), or NHWC
  *              (B,H,W,cost_nhwc_cs >= D) so the CVEncoder's first conv reads it directly
  *   lowest_bhw (B,H,W) out or NULL; planes_d (D) out or NULL
- * One launch, no workspace.
+ * One volume kernel (plus a small arg-max pass when the planes are split over workgroups), no workspace needed.
  */
 int idh_cost_volume_dot_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
                             const float *src_E_44, const float *cur_invK_44, float dmin, float dmax,
@@ -100,6 +105,9 @@ int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *src_nhwc, con
                                const float *src_E_44, const float *cur_invK_44, float dmin, float dmax,
                                int B, int K, int C, int H, int W, int D, float *cost, int cost_nhwc_cs,
                                float *lowest_bhw, float *planes_d, const idh_volume_opts *opts, void *stream);
+
+/* Floats of idh_volume_opts.scratch that make the arg-max pass of this shape cheaper (0: the launch does not split planes). */
+long long idh_cost_volume_dot_scratch_floats(int B, int K, int C, int H, int W, int D);
 
 /* Name of the kernel idh_cost_volume_dot*_fwd launches for this shape (what rocprofv3 --kernel-trace will show);
  * lets bench.py label its roofline without guessing the launcher's choice. */

@@ -306,3 +306,35 @@ def test_window_kernel_caller_planes_nhwc_output_and_strides():
         assert rel_err(out[..., :D].permute(0, 3, 1, 2).cpu(), want[0].cpu()) < 1e-6
         assert float(out[..., D:].abs().max()) == 0.0
         assert torch.equal(low, want[1])
+
+
+def test_argmax_scratch_gives_the_same_lowest():
+    """idh_volume_opts.scratch: when the window kernel splits the planes over workgroups, the arg-max pass combines the groups'
+    (best cost, plane) pairs instead of re-reading the volume — same `lowest` bit for bit (first maximum wins); a scratch that is
+    too small is ignored."""
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd.cost_volume import to_nhwc, volume_opts
+
+    B, K, C, H, W, D = 8, 4, 16, 48, 96, 64
+    L = _lib.lib()
+    n = int(L.idh_cost_volume_dot_scratch_floats(B, K, C, H, W, D))
+    assert n > 0  # this shape splits the planes
+    assert int(L.idh_cost_volume_dot_scratch_floats(1, K, C, 24, 32, D)) == 0  # a single small frame runs on the quad kernel
+    inp = {k: v.cuda() for k, v in syn.cost_volume_inputs(B, K, C, H, W, seed=3, behind_view=K - 1).items()}
+    cur, src = to_nhwc(inp["cur_feats"]), to_nhwc(inp["src_feats"])
+    Ks, E, iK = (inp[k].contiguous() for k in ("src_Ks", "src_extrinsics", "cur_invK"))
+    res = {}
+    for name, dev, shrink in (("none", None, 0), ("scratch", cur.device, 0), ("too_small", cur.device, 8)):
+        opts, keep = volume_opts(B, K, C, H, W, D, kernel=_lib.CV_KERNEL_WINDOW, dot_scratch_device=dev)
+        if shrink:
+            opts.scratch_floats -= shrink
+        cost = torch.empty(B, D, H, W, device="cuda")
+        low = torch.full((B, H, W), -1.0, device="cuda")
+        _lib.check(L.idh_cost_volume_dot_ex_fwd(cur.data_ptr(), src.data_ptr(), Ks.data_ptr(), E.data_ptr(), iK.data_ptr(), 0.25, 5.0, B, K, C, H, W, D,
+                                                cost.data_ptr(), 0, low.data_ptr(), None, opts, _lib.stream_ptr()), "dot")
+        torch.cuda.synchronize()
+        res[name] = (cost, low)
+    for name in ("scratch", "too_small"):
+        assert torch.equal(res[name][0], res["none"][0])
+        assert torch.equal(res[name][1], res["none"][1])
+    assert float(res["none"][1].min()) > 0

@@ -16,7 +16,7 @@ a = bench.parse(["--workload", "warp_match_dot", "--views", str(K), "--planes", 
 a.batch = B
 w = bench.WarpMatchDot(a, torch.device("cuda:0"), 0)
 p = _lib.ptr
-opts, _ = volume_opts(w.B, w.K, w.C, w.H, w.W, w.D, None, 0, 0, kernel=kern)
+opts, _keep = volume_opts(w.B, w.K, w.C, w.H, w.W, w.D, None, 0, 0, kernel=kern, dot_scratch_device=None if os.environ.get('IDH_NO_SCRATCH') else torch.device('cuda:0'))
 
 
 def step():
