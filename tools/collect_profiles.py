@@ -1,0 +1,47 @@
+"""Copy the summaries of a tools/final_profiles.sh run (gpurun_out/<tag>/...) into profiles/r03/, refresh profiles/pmc_traffic.json and the
+bench-line table of profiles/r03/README.md:  python tools/collect_profiles.py <tag>"""
+import glob, json, os, shutil, sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.chdir(root)
+S, D = f"gpurun_out/{tag}", "profiles/r03"
+for f in glob.glob(f"{S}/matrix/*.json"):
+    shutil.copy(f, f"{D}/matrix/")
+shutil.copy(f"{S}/bench_default.json", f"{D}/bench_hot_path_mlp_k7_gb32.json")
+for src, dst in (("prof_hot", "hot_path_mlp_gb32_kernel_stats.csv"), ("prof_dot", "warp_match_dot_gb32_kernel_stats.csv"), ("prof_temporal", "temporal_b1_d96_kernel_stats.csv")):
+    fs = glob.glob(f"{S}/{src}/**/*kernel_stats.csv", recursive=True)
+    if fs:
+        shutil.copy(fs[0], f"{D}/{dst}")
+shutil.copy(f"gpurun_out/pmc_{tag}_hot/summary.json", f"{D}/pmc_hbm_hot_path_mlp_b32.json")
+shutil.copy(f"gpurun_out/pmc_{tag}_dot/summary.json", f"{D}/pmc_hbm_warp_match_dot_b32.json")
+shutil.copy(f"gpurun_out/pmc_mfma_{tag}/summary.json", f"{D}/pmc_mfma_util_hot_path_mlp_b32.json")
+open(f"{D}/pmc_cv_dot_win_b32.txt", "w").write("".join(l for l in open(f"{S}/pmc_dot_win.txt") if "amdgpu.ids" not in l and l[:1].isupper()))
+bench = json.loads(open(f"{D}/bench_hot_path_mlp_k7_gb32.json").read().strip().splitlines()[-1])
+pt = json.load(open("profiles/pmc_traffic.json"))
+rows = json.load(open(f"{D}/pmc_hbm_hot_path_mlp_b32.json"))
+dom = [r for r in rows if r["kernel"] == bench["roofline"]["kernel"]]
+if dom:
+    pt["hot_path/mlp/b32"].update(kernel=dom[0]["kernel"], launches_profiled=dom[0]["calls"],
+                                  traffic_bytes_per_launch=(2 * dom[0]["fetch_KiB_per_call"] + dom[0]["write_KiB_per_call"]) * 1024)
+rows = json.load(open(f"{D}/pmc_hbm_warp_match_dot_b32.json"))
+w = [r for r in rows if r["kernel"].startswith("cv_dot_win_k")]
+if w:
+    pt["warp_match_dot/b32"].update(kernel=w[0]["kernel"], traffic_bytes_per_launch=(2 * w[0]["fetch_KiB_per_call"] + w[0]["write_KiB_per_call"]) * 1024)
+json.dump(pt, open("profiles/pmc_traffic.json", "w"), indent=1)
+lines = []
+for f in sorted(glob.glob(f"{D}/matrix/*.json")):
+    d = json.loads(open(f).read())
+    r = d["roofline"]
+    lines.append(f"| `{os.path.basename(f)}` | {d['value']:.1f} | {d['ms_per_step']:.3f} | `{r['kernel'][:48]}` | {r['achieved']:.1f} {r['unit']} | {r['frac']:.3f} |"
+                 + (f" {r['achieved_algorithmic']:.1f} |" if "achieved_algorithmic" in r else " |"))
+s = open(f"{D}/README.md").read()
+a = s.index("| bench line | frames/s |")
+s = s[:a] + "| bench line | frames/s | ms/step | roofline kernel | achieved | frac | algorithmic |\n|---|---|---|---|---|---|---|\n" + "\n".join(lines) + \
+    "\n\n(B=1 rows: the slower of the two timed kernel families is the 4-row direct family — grouped and level launches — which the roofline object then names.)\n"
+open(f"{D}/README.md", "w").write(s)
+r = bench["roofline"]
+print(f"bench {bench['value']:.1f} fps {bench['ms_per_step']:.2f} ms; {r['kernel']} x{r['launches_per_step']} {r['kernel_ms']*1e3:.1f} us frac {r['frac']:.3f} alg {r['achieved_algorithmic']:.1f}; conv {r['all_conv_kernels']['ms_per_step']:.2f} ms")
+wm = bench["warp_match"]
+print(f"warp_match {wm['kernel_ms']:.4f} ms frac {wm['frac']:.4f}; temporal {[round(v['value'],1) for v in bench['temporal']['sequences_per_gpu'].values()]}; k8 {bench['k8']['value']:.1f}; "
+      f"f16x3 {bench['split_precision']['value']:.1f}; fv {bench['fv_mlp']['ms']:.2f} ms; cpu {bench['cpu_baseline']['value']:.3f}")
