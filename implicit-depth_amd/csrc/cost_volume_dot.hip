@@ -421,6 +421,13 @@ struct Sample {  // one lane's bilinear cell in one source view
     int xa0, xa1, ya0, ya1;
 };
 
+// min(max(x, 0), hi) for a wave-uniform hi >= 0 as one v_med3_i32 (the compiler cannot prove 0 <= hi and emits max + min)
+__device__ __forceinline__ int cv_clamp0(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+
 __device__ __forceinline__ Sample cv_project(float depth, float qx, float qy, float qz, float h9, float h10, float h11, float Wf, float Hf, int W, int H) {
     const float cx = fmaf(depth, qx, h9);
     const float cy = fmaf(depth, qy, h10);
@@ -433,13 +440,14 @@ __device__ __forceinline__ Sample cv_project(float depth, float qx, float qy, fl
     const float x0f = floorf(sx), y0f = floorf(sy);
     const float fx = sx - x0f, fy = sy - y0f;
     const int x0 = (int)x0f, y0 = (int)y0f;
-    const float wx0 = (x0 >= 0 && x0 < W) ? 1.0f - fx : 0.f;
+    // 0 <= x0 < W as one unsigned compare; clamps as v_med3 (every vector instruction here is paid 64 planes x 8 views per pixel)
+    const float wx0 = (unsigned)x0 < (unsigned)W ? 1.0f - fx : 0.f;
     const float wx1 = (x0 + 1 < W) ? fx : 0.f;
-    const float wy0 = (y0 >= 0 && y0 < H) ? 1.0f - fy : 0.f;
+    const float wy0 = (unsigned)y0 < (unsigned)H ? 1.0f - fy : 0.f;
     const float wy1 = (y0 + 1 < H) ? fy : 0.f;
     Sample s;
-    s.xa0 = min(max(x0, 0), W - 1); s.xa1 = min(x0 + 1, W - 1);
-    s.ya0 = min(max(y0, 0), H - 1); s.ya1 = min(y0 + 1, H - 1);
+    s.xa0 = cv_clamp0(x0, W - 1); s.xa1 = min(x0 + 1, W - 1);
+    s.ya0 = cv_clamp0(y0, H - 1); s.ya1 = min(y0 + 1, H - 1);
     s.w00 = wx0 * wy0; s.w01 = wx1 * wy0; s.w10 = wx0 * wy1; s.w11 = wx1 * wy1;
     return s;
 }
@@ -486,7 +494,7 @@ struct WinCell {
 __device__ __forceinline__ WinCell cv_cell(const Sample &s, int wx0, int wy0, int wneed, int hneed) {
     const int cx0 = s.xa0 - wx0, cy0 = s.ya0 - wy0, cx1 = s.xa1 - wx0, cy1 = s.ya1 - wy0;
     const bool inside = cx0 >= 0 && cy0 >= 0 && cx1 < wneed && cy1 < hneed;
-    const bool any_w = s.w00 + s.w01 + s.w10 + s.w11 > 0.f;  // weights are >= 0
+    const bool any_w = fmaxf(__builtin_fmaxf(s.w00, s.w01), __builtin_fmaxf(s.w10, s.w11)) > 0.f;  // weights are >= 0 (v_max3 + v_max)
     WinCell c;
     c.ok = inside && any_w;
     c.fb = any_w && !inside;
@@ -817,7 +825,9 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
             acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto add_unit = [&](int u, const float4 &r) {  // acc[u] += r with a run-time u (keeps acc in registers)
+    // acc[u] += r with a run-time u: 16 selects + 16 adds keep acc in registers and the unit loop one basic block (a scalar branch on the
+    // wave-uniform u with 4 adds per arm is 28 vector instructions shorter and 8 % slower: 0.613 vs 0.566 ms)
+    auto add_unit = [&](int u, const float4 &r) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool m = (u == i);
