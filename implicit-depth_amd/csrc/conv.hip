@@ -1459,6 +1459,10 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                         int ns[kMaxGroup];
                         for (int j = 0; j < wg; ++j) { as[j] = &pcs[j].a; ns[j] = pcs[j].n_img; }
                         rc = launch_conv_wino_group(as, ns, wg, st);
+                        if (rc == IDH_EUNSUPPORTED) {  // (a device whose resident grid is not whole XCD octets): one launch per op
+                            rc = IDH_OK;
+                            for (int j = 0; j < wg && rc == IDH_OK; ++j) rc = launch_conv(pcs[j], st);
+                        }
                     }
                     used = wg;
                 } else if (mix > cnt && mix > 1) {
