@@ -106,6 +106,21 @@ def test_launch_grouping_decisions_without_a_gpu():
     assert count([lds64(1, 5), lds32(1, 6)]) == 2
     # 32 frames: members fill the chip on their own -> equal-tile LDS convs still share a grid, the rest run alone
     assert count([lds64(32, 5), lds64(32, 5), lds32(32, 5), down(32, 5)]) == 3
+    # Winograd convs of one level share a persistent grid (conv3x3_wino_group_k): plain ones together, those with a fused 1x1
+    # source together, at most six per grid; without the level's group id one launch each
+    wino = lambda N, g: _conv_op(nhwc, N, 96, 128, 64, 64, nhwc.TILE_WINO, 0, g)
+
+    def wino2(N, g):
+        op = wino(N, g)
+        s1 = op.src[1]
+        s1.in_, s1.w, s1.cs, s1.H, s1.W, s1.Cin, s1.ks, s1.stride = 0x5000, 0x6000, 128, 96, 128, 128, 1, 1
+        return op
+
+    assert count([wino(4, 7), wino(4, 7), wino(4, 7)]) == 1
+    assert count([wino(4, 0), wino(4, 0)]) == 2
+    assert count([wino(4, 7), wino(4, 7), wino2(4, 7), wino2(4, 7)]) == 2
+    assert count([wino(4, 7)] * 7) == 2
+    assert count([wino(4, 7), lds64(4, 7), lds64(4, 7)]) == 2
     # an image too large for the LDS kernels' 32-bit byte offsets (H*W*cs*4 >= 2 GiB) falls back to the direct kernel
     assert count([_conv_op(nhwc, 1, 16384, 16384, 64, 64, 8, 0, 0)]) == 1
     # validation still applies in the dry run
