@@ -1127,7 +1127,7 @@ inline int ceil16(int v) { return (v + 15) & ~15; }
 struct PreparedConv {
     ConvArgs a;
     LdsConvArgs la;
-    int lds_rows, tm, tn;  // lds_rows = 16: split-precision kernel, tm = IDH_SPLIT_* mode; 32: Winograd kernel, tn = tile rows
+    int lds_rows, tm, tn;  // lds_rows = 16: split-precision kernel, tm = IDH_SPLIT_* mode; 32: Winograd kernel, tn = tile rows; 36: Winograd F(4x4)
     int n_img;
     unsigned blocks;
     bool up;         // some source has fused x2-upsampled segments (LDS kernels only)
@@ -1211,6 +1211,14 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         pc.tn = 0;
         pc.n_img = op.N;
         pc.blocks = 0;
+    } else if (op.tile_m == IDH_TILE_WINO4) {
+        // Winograd F(4x4,3x3) kernel (conv_wino4.hip): src[0].w holds idh_pack_conv_weight_wino4 output
+        if (!wino4_supported(a)) return IDH_EUNSUPPORTED;
+        pc.lds_rows = 36;
+        pc.tm = op.tile_m;
+        pc.tn = 0;
+        pc.n_img = op.N;
+        pc.blocks = 0;
     } else if (op.tile_m == IDH_SPLIT_F16X3) {
         // split-precision kernel (conv_split.hip): src[0].w holds idh_pack_conv_weight_split output
         if (!lds_ok || a.s[0].pad_mode != IDH_PAD_ZEROS || (op.Cout % 64) || a.S != 1 || op.Wo < kSplitTile || op.Ho < 1 || (op.tile_n != 0 && op.tile_n != 8 && op.tile_n != 16))
@@ -1264,6 +1272,10 @@ int launch_conv(const PreparedConv &pc, hipStream_t st) {
     if (pc.lds_rows == 32) {
         if (t_dry_run) { ++t_launches; return IDH_OK; }
         return launch_conv_wino(pc.a, pc.n_img, pc.tn, st);
+    }
+    if (pc.lds_rows == 36) {
+        if (t_dry_run) { ++t_launches; return IDH_OK; }
+        return launch_conv_wino4(pc.a, pc.n_img, st);
     }
     if (pc.lds_rows == 8 && pc.up) IDH_LAUNCH(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 8 && pc.s2 && pc.nj == 4) IDH_LAUNCH((conv3x3_lds_k<2, false, 4, false, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);

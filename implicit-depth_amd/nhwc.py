@@ -168,7 +168,28 @@ def packed_wino_weight(conv: nn.Conv2d) -> torch.Tensor:
     return dst
 
 
+def packed_wino4_weight(conv: nn.Conv2d) -> torch.Tensor:
+    """Winograd F(4x4,3x3)-domain copy of a 3x3 Conv2d weight in the A-fragment order of csrc/conv_wino4.hip
+    (idh_pack_conv_weight_wino4); cached like ``packed_weight``."""
+    w = conv.weight
+    key = (w.data_ptr(), _lib.param_version(w), str(w.device))
+    cached = getattr(conv, "_idh_packed_wino4", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    _lib.require_cuda_f32(w)
+    L = _bind()
+    co, ci, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise _lib.IdhError("the Winograd F(4x4,3x3) kernel covers 3x3 convolutions only")
+    dst = torch.empty(L.idh_packed_wino4_weight_floats(co, ci), device=w.device, dtype=torch.float32)
+    wc = w.detach().contiguous()
+    _lib.check(L.idh_pack_conv_weight_wino4(wc.data_ptr(), dst.data_ptr(), co, ci, _lib.stream_ptr()), "idh_pack_conv_weight_wino4")
+    conv._idh_packed_wino4 = (key, dst)
+    return dst
+
+
 TILE_WINO = 12  # IDH_TILE_WINO of include/idh_ops.h == the op's tile_m
+TILE_WINO4 = 13  # IDH_TILE_WINO4
 # Winograd F(2x2,3x3) for the eligible 3x3 stride-1 layers of fp32 plans (csrc/conv_wino.hip): fp32 operands and
 # accumulation, 2.25x fewer MFMAs; measured 1.67-1.84x over the direct LDS kernel at B=32 (tools/perf_wino.py).
 # Tiles are 32 x 8 pixels x 32 channels; WINO_MIN_TILES: below this many tiles the direct kernels' finer tiles fill the
@@ -193,6 +214,26 @@ def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> b
     if Ho * Wo < WINO_MIN_FILL * (ty * 8) * (tx * 32):
         return False
     return N * ty * tx * (cout // 32) >= WINO_MIN_TILES
+
+
+# Winograd F(4x4,3x3) (csrc/conv_wino4.hip) for the LARGE plain 3x3 layers: 1.78x fewer MFMAs than F(2x2); 64 x 16 pixel x 32
+# channel tiles on one persistent workgroup per CU, so it needs >= WINO4_MIN_TILES tiles (a few per CU) and maps that fill the
+# tile grid; LeakyReLU / no activation, no fused 1x1 source (those blocks stay on F(2x2) with its P steps).
+WINOGRAD4 = True
+WINO4_MIN_TILES = 512
+WINO4_MIN_FILL = 0.85
+
+
+def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act: int) -> bool:
+    (v0, c0) = srcs[0]
+    if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 32 or isinstance(v0, CatView):
+        return False
+    if act not in (ACT_NONE, ACT_LRELU):
+        return False
+    ty, tx = -(-Ho // 16), -(-Wo // 64)
+    if Ho * Wo < WINO4_MIN_FILL * (ty * 16) * (tx * 64):
+        return False
+    return N * ty * tx * (cout // 32) >= WINO4_MIN_TILES
 
 
 SPLIT_CODE = {"f16x3": 11}  # IDH_SPLIT_F16X3 of include/idh_ops.h == the op's tile_m
@@ -383,6 +424,10 @@ class Plan:
         use_split = self.math != "fp32" and split_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode)
         use_wino = (WINOGRAD and self.math == "fp32" and norm is None and
                     wino_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode))
+        use_wino4 = (WINOGRAD4 and self.math == "fp32" and norm is None and
+                     wino4_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode, act))
+        if use_wino4:
+            use_wino = False
         for i, (v, cv) in enumerate(srcs):
             ks, st = cv.kernel_size[0], cv.stride[0]
             if v.C != cv.in_channels:
@@ -398,6 +443,8 @@ class Plan:
                 raise _lib.IdhError("a conv input whose channel count is not a multiple of 16 must be a whole zero-padded buffer")
             if use_split:  # one blob: [3x3 panels][1x1 panels of the second source][scales]
                 w = split_packed_weight(conv, self.math, conv2)
+            elif use_wino4:
+                w = packed_wino4_weight(cv)
             elif use_wino and i == 0:
                 w = packed_wino_weight(cv)
             else:
@@ -428,6 +475,8 @@ class Plan:
         M = out.N * out.H * out.W
         if use_split:
             tm, tn, split = SPLIT_CODE[self.math], choose_split_rows(out.N, out.H, out.W, conv.out_channels), 1
+        elif use_wino4:
+            tm, tn, split = TILE_WINO4, 0, 1
         elif use_wino:
             tm, tn, split = TILE_WINO, 0, 1
         elif lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
@@ -753,7 +802,7 @@ def build_flags() -> tuple:
     """Module-level switches that shape a plan at build time (part of every plan-cache key: toggling one takes effect on the
     next call instead of silently replaying a plan built under the old setting)."""
     return (WINO_GROUP, FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
-            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, DEFAULT_MATH)
+            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINO4_MIN_TILES, WINO4_MIN_FILL, DEFAULT_MATH)
 
 
 def _plan_cache(module: nn.Module) -> PlanCache:

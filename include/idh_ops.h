@@ -128,6 +128,18 @@ int idh_pack_conv_weight_split(const float *w_oihw, const float *w_1x1, void *ds
 size_t idh_packed_wino_weight_floats(int Cout, int Cin);
 int idh_pack_conv_weight_wino(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);
 
+/* Winograd F(4x4,3x3) convolution (csrc/conv_wino4.hip): 36 instead of 64 multiplications per 4x4 output pixels and input
+ * channel (1.78x fewer MFMAs than IDH_TILE_WINO), fp32 operands and accumulation, interpolation points {0, +-1/2, +-2, inf};
+ * for the large 3x3 stride-1 convs of BasicBlock (layers.py:59-95: 64->64 and 192->64 at 192x256 / 96x128).  IDH_OP_CONV with
+ * tile_m = IDH_TILE_WINO4; src[0].w = the output of idh_pack_conv_weight_wino4 (U = G g G^T per (co, ci) in MFMA A-fragment
+ * order: [Cin_pad/8][Cout/32][k-step 2][co block 2][position group 9][lane 64][4]); 64 x 16 pixel x 32 channel tiles, one
+ * persistent workgroup per CU.  Shape family: 3x3, stride 1, zero padding, Cout % 32 == 0, split_k == 1, src[1] unused (a block
+ * with a 1x1 projection stays on IDH_TILE_WINO); anything else: IDH_EUNSUPPORTED.  Error against fp64 ~2-5e-6 of the output
+ * scale (direct kernel ~1e-6, F(2x2) ~4e-7). */
+#define IDH_TILE_WINO4 13
+size_t idh_packed_wino4_weight_floats(int Cout, int Cin);
+int idh_pack_conv_weight_wino4(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);
+
 /* sizeof(idh_op) as compiled into the library (bindings assert their mirror matches). */
 size_t idh_sizeof_op(void);
 

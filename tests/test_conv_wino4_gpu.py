@@ -1,0 +1,137 @@
+"""Winograd F(4x4,3x3) conv kernel (csrc/conv_wino4.hip) vs an fp64 torch reference and vs the direct kernel.  Replaces the same
+nn.Conv2d calls as the direct kernel (reference modules/layers.py:59-95) on the large maps; fp32 operands and accumulation.
+F(4x4) amplifies fp32 rounding ~5x over the direct kernel (2-5e-6 of the output scale, interpolation points {0, +-1/2, +-2}):
+the bar per layer is 2e-5, an order of magnitude inside the 1e-4 scale-relative tolerance of BASELINE.json."""
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+import implicit_depth_amd.synthetic as syn
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def wino4_everywhere():
+    """Force the F(4x4) kernel onto every eligible layer regardless of grid size / tile fill."""
+    from implicit_depth_amd import nhwc
+
+    old = (nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL)
+    nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = True, 1, 0.0
+    yield nhwc
+    nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = old
+
+
+def _run(nhwc, conv, x_nhwc, res, act, slope, wino4, out_view=None, twice=False):
+    old = (nhwc.WINOGRAD4, nhwc.WINOGRAD)
+    nhwc.WINOGRAD4, nhwc.WINOGRAD = wino4, False
+    try:
+        p = nhwc.Plan(x_nhwc.device)
+        B, H, W, cs = x_nhwc.shape
+        out = p.buffer(B, H, W, conv.out_channels) if out_view is None else out_view
+        p.conv(nhwc.View(x_nhwc, 0, conv.in_channels), conv, out, act=act, slope=slope, res=res)
+    finally:
+        nhwc.WINOGRAD4, nhwc.WINOGRAD = old
+    assert (p.ops[0].tile_m == nhwc.TILE_WINO4) == wino4
+    p.run()
+    if twice:
+        p.run()  # persistent kernel state must not leak between launches
+    torch.cuda.synchronize()
+    return out.dense().clone()
+
+
+# (B, cin, cout, H, W, residual, act): whole tiles, ragged maps (partial tiles in both directions, odd sizes), channel counts that
+# need zero-padded input buffers (24, 112), wide outputs (NT = 3, 8), one map smaller than a tile, enough tiles that a persistent
+# workgroup walks several (the stream crosses tile boundaries), a single 16-channel block (two stages)
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 128, True, 1), (1, 24, 64, 37, 45, False, 1), (3, 112, 96, 9, 33, True, 0), (1, 192, 64, 64, 96, False, 1),
+                                   (2, 128, 256, 24, 32, True, 1), (1, 16, 32, 8, 32, False, 1), (1, 64, 32, 5, 17, True, 1), (5, 32, 64, 16, 70, False, 1),
+                                   (40, 64, 64, 48, 128, True, 1), (1, 16, 32, 16, 64, False, 0)])
+def test_wino4_conv_vs_fp64_and_direct(shape, wino4_everywhere):
+    nhwc = wino4_everywhere
+    B, cin, cout, H, W, use_res, act = shape
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
+    syn.fill_state_dict(conv, seed=cin + cout + H)
+    g = torch.Generator(device="cuda").manual_seed(H * W)
+    xb = torch.zeros(B, H, W, nhwc.ceil16(cin), device="cuda")
+    xb[..., :cin] = torch.randn(B, H, W, cin, device="cuda", generator=g)
+    rb = torch.randn(B, H, W, cout, device="cuda", generator=g) if use_res else None
+    res = nhwc.View(rb, 0, cout) if use_res else None
+    nb = min(B, 3)
+    ref = F.conv2d(xb[-nb:, ..., :cin].permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1)
+    if use_res:
+        ref = ref + rb[-nb:].permute(0, 3, 1, 2).double()
+    ref = (F.leaky_relu(ref, 0.2) if act == 1 else ref).permute(0, 2, 3, 1)
+    yw = _run(nhwc, conv, xb, res, act, 0.2, True, twice=True)
+    yd = _run(nhwc, conv, xb, res, act, 0.2, False)
+    assert torch.isfinite(yw).all()
+    assert rel_err(yw[-nb:].cpu(), ref.cpu()) < 2e-5, "F(4x4) kernel vs fp64"
+    assert rel_err(yw.cpu(), yd.cpu()) < 2e-5, "F(4x4) kernel vs direct kernel"
+
+
+def test_wino4_conv_channel_strided_views(wino4_everywhere):
+    """input = channel slice of a wider concat buffer, output = slice of another, residual strided too (torch.cat elimination)"""
+    nhwc = wino4_everywhere
+    B, H, W, cin, cout = 2, 24, 80, 64, 64
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
+    syn.fill_state_dict(conv, seed=5)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    wide_in = torch.randn(B, H, W, 160, device="cuda", generator=g)
+    wide_res = torch.randn(B, H, W, 96, device="cuda", generator=g)
+    wide_out = torch.full((B, H, W, 192), 7.0, device="cuda")
+    x, res, out = nhwc.View(wide_in, 32, cin), nhwc.View(wide_res, 16, cout), nhwc.View(wide_out, 64, cout)
+    old = nhwc.WINOGRAD
+    nhwc.WINOGRAD = False
+    try:
+        p = nhwc.Plan(wide_in.device)
+        p.conv(x, conv, out, act=1, slope=0.2, res=res)
+    finally:
+        nhwc.WINOGRAD = old
+    assert p.ops[0].tile_m == nhwc.TILE_WINO4
+    p.run()
+    torch.cuda.synchronize()
+    ref = F.conv2d(wide_in[..., 32:96].permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1)
+    ref = F.leaky_relu(ref + wide_res[..., 16:80].permute(0, 3, 1, 2).double(), 0.2).permute(0, 2, 3, 1)
+    assert rel_err(wide_out[..., 64:128].cpu(), ref.cpu()) < 2e-5
+    assert (wide_out[..., :64] == 7.0).all() and (wide_out[..., 128:] == 7.0).all(), "neighbouring channel slices must stay untouched"
+
+
+def test_wino4_not_taken_for_fused_projection_or_elu(wino4_everywhere):
+    """blocks with a 1x1 projection keep the F(2x2) kernel (its P steps), ELU layers the direct / F(2x2) kernels"""
+    nhwc = wino4_everywhere
+    conv, proj = nn.Conv2d(64, 64, 3, 1, 1).cuda(), nn.Conv2d(32, 64, 1).cuda()
+    x, x2 = torch.randn(1, 32, 64, 64, device="cuda"), torch.randn(1, 32, 64, 32, device="cuda")
+    p = nhwc.Plan(x.device)
+    p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=1, x2=nhwc.View(x2, 0, 32), conv2=proj)
+    p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=2)
+    assert all(op.tile_m != nhwc.TILE_WINO4 for op in p.ops)
+
+
+def test_networks_with_wino4_forced_match_goldens(wino4_everywhere):
+    """CVEncoder + BDDecoderPP goldens (reference outputs) with every plain 3x3 stride-1 layer on the F(4x4) kernel"""
+    from conftest import TOL
+    from implicit_depth_amd import networks as net
+
+    Hm, Wm, Dcv = 24, 32, 16
+    pyr = syn.encoder_pyramid(1, Hm * 4, Wm * 4, seed=11)
+    cvol = syn.randn((1, Dcv, Hm, Wm), 11, "cv_in")
+    cve = net.CVEncoder(num_ch_cv=Dcv, num_ch_enc=[48, 64, 160, 256], num_ch_outs=[64, 128, 256, 384])
+    syn.fill_state_dict(cve, seed=12)
+    g = load_golden("g3_cvencoder")
+    outs = cve.cuda()(cvol.cuda(), [p.cuda() for p in pyr[1:]])
+    plan = next(iter(cve.__dict__["_idh_plans"].values()))[0]
+    assert any(op.kind == 1 and op.tile_m == wino4_everywhere.TILE_WINO4 for op in plan.ops), "no layer took the F(4x4) kernel"
+    for i, o in enumerate(outs):
+        assert rel_err(o.cpu(), g[f"o{i}"]) < TOL
+    dec = net.BDDecoderPP([24, 64, 128, 256, 384])
+    syn.fill_state_dict(dec, seed=13)
+    gd = load_golden("g3_bddecoder")
+    dec_in = [pyr[0]] + [torch.as_tensor(g[f"o{i}"]) for i in range(4)]
+    out = dec.cuda()([t.cuda() for t in dec_in])
+    plan = next(iter(dec.__dict__["_idh_plans"].values()))[0]
+    assert sum(op.kind == 1 and op.tile_m == wino4_everywhere.TILE_WINO4 for op in plan.ops) >= 20
+    errs = [rel_err(out[f"feature_s{i}_b1hw"].cpu(), gd[f"s{i}"]) for i in range(4)]
+    print("F(4x4) everywhere, BDDecoderPP vs reference golden:", errs)
+    for e in errs:
+        assert e < TOL

@@ -1,4 +1,5 @@
 #!/bin/bash
+mkdir -p implicit-depth_amd/_obj/abl
 # ablation builds of the f16x3 feature-volume kernel: tools/abl_fv.sh build (here) / run (GPU box)
 cd "$(dirname "$0")/.."
 VARS="${VARS:-NOMFMA NOGATHER NOMFMA,NOGATHER}"
@@ -7,7 +8,7 @@ if [ "$1" = build ]; then
     flags=""; for f in ${v//,/ }; do flags="$flags -DIDH_ABL_$f"; done
     name=${v//,/_}
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -c implicit-depth_amd/csrc/feature_volume.hip -o /tmp/fv_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls implicit-depth_amd/_obj/*.o | grep -v feature_volume.o) /tmp/fv_$name.o -o implicit-depth_amd/lib/libidh_ablfv_$name.so && echo built $name
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls implicit-depth_amd/_obj/*.o | grep -v feature_volume.o) /tmp/fv_$name.o -o implicit-depth_amd/_obj/abl/libidh_ablfv_$name.so && echo built $name
   done
 else
   run() { python - <<'PY'
@@ -29,5 +30,5 @@ for math in ("fp32", "f16x3"):
 PY
   }
   echo "== base"; run
-  for v in $VARS; do name=${v//,/_}; echo "== $name"; IDH_LIB=$PWD/implicit-depth_amd/lib/libidh_ablfv_$name.so run; done
+  for v in $VARS; do name=${v//,/_}; echo "== $name"; IDH_LIB=$PWD/implicit-depth_amd/_obj/abl/libidh_ablfv_$name.so run; done
 fi
