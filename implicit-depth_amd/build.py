@@ -19,6 +19,9 @@ OBJDIR = os.path.join(HERE, "_obj")
 LIB = os.path.join(LIBDIR, "libidh.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# per-source extras.  conv_wino4: the SLP vectoriser packs the scalar transform FMAs into v_pk_fma_f32 behind v_mov shuffles (98 moves
+# and 3 scratch reloads per two K stages; packed fp32 math is no faster than scalar beside fp32 MFMAs on gfx950)
+EXTRA_FLAGS = {"conv_wino4.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -47,7 +50,7 @@ def build(verbose: bool = True, force: bool = False) -> str:
         o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer([s] + headers, o):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -17,9 +17,9 @@
 // Design (one wave per SIMD, 512 registers per lane):
 // * The 36 element-wise products over the input channels are 36 independent GEMMs M[pos][co, tile] = sum_ci U[pos][co, ci]
 //   V[pos][ci, tile], issued as D^T = U . V^T (weights = MFMA A operand).  Lane (n = lane & 15, h = lane >> 4) holds, as the B
-//   operand of MFMA k-step ks, channel 8c + 4ks + h of TILE n — so the lane that reads the 6x6 patch of tile n for that channel
-//   (36 ds_read_b32) transforms it IN REGISTERS (144 FMAs) and every transformed value is directly the B operand of two MFMAs
-//   (two 16-channel output blocks).  No transformed input goes through LDS.
+//   operand of MFMA k-step ks, channel 8c + 2h + ks of TILE n — so the lane that reads the 6x6 patch of tile n for that channel
+//   PAIR (36 ds_read_b64 per 8-channel stage, conflict free) transforms it IN REGISTERS (144 FMAs per channel) and every
+//   transformed value is directly the B operand of two MFMAs (two 16-channel output blocks).  No transformed input goes through LDS.
 // * A wave owns 16 tiles in a row (64 x 4 output pixels) x 32 output channels = 36 positions x 2 accumulator quads = 288
 //   accumulator registers; a workgroup = 4 waves stacked vertically (64 x 16 pixels x 32 channels), ONE workgroup per CU.
 // * K loop in stages of 8 input channels (two passes of 4 = one MFMA k-step each).  Per stage the 18 x 66 halo (32 B per texel)
@@ -27,11 +27,18 @@
 //   registers -> LDS (buffer_load_dwordx4 + ds_write_b128, three batches spread over the stage: with one wave per SIMD an
 //   LDS-DMA instruction's ~100-cycle issue stall would come straight out of the matrix pipe).  Out-of-image texels are out of
 //   the buffer descriptor's range and arrive as zeros = zero padding.  Two panel buffers + two halo buffers = 152 KiB of LDS.
-// * The transform is software-pipelined across passes with two 6x6 register sets: while pass s multiplies row xi of W(s)
-//   (horizontal transform of one row -> 6 B operands -> 12 MFMAs), column xi of the NEXT pass's patch is transformed
-//   vertically in place, and the row of W(s) just consumed is refilled with the patch of the pass after that.  The halo is
-//   therefore staged TWO stages ahead of the MFMAs, the panel one stage ahead; the stream of (tile, stage) pairs of a
-//   persistent workgroup runs across tile boundaries without refilling the pipeline.
+// * Two 6x6 register sets hold the stage's patch of the lane's two channels, and the two 1-D transforms are applied in OPPOSITE
+//   order to them: set 0 (k-step 0) rows first (as a row arrives from LDS), then column by column in pass 0, each column giving
+//   the 6 B operands of positions (0..5, nu); set 1 (k-step 1) columns first (during pass 0), then row by row in pass 1, each row
+//   giving positions (xi, 0..5) — pass 1 refills the rows of BOTH sets, as they are consumed, with the next stage's patch (one
+//   ds_read_b64 per texel).  So every iteration is 12 MFMAs + 24 transform operations + <= 6 LDS reads, written as 12 slots of
+//   "one MFMA, two vector operations, at most one LDS / global access" separated by sched_barrier: fp32 MFMA and fp32 VALU share
+//   the SIMD's datapath, but everything else (LDS, global, scalar, waits) issues in an MFMA's 32-cycle shadow only if it sits
+//   BETWEEN two MFMAs (hipcc would otherwise put the 12 MFMAs back to back and all other work between the bursts: 8.8k instead
+//   of ~6k cycles per stage).  The halo is staged TWO stages ahead of the MFMAs, the panel one stage ahead; the stream of
+//   (tile, stage) pairs of a persistent workgroup runs across tile boundaries without refilling the pipeline, and the first copies
+//   of a tile's first stage are issued BEFORE the previous tile's output stores (stores and loads retire through one in-order
+//   counter: a wait for loads issued after a store burst would wait for the burst).
 // * Epilogue: output transform (120 vector ops per channel quad) in registers, + bias + residual, activation, 16-byte NHWC
 //   stores (a lane holds 4 consecutive channels of the 4x4 pixels of its tile).
 #include <type_traits>
@@ -60,7 +67,8 @@ constexpr int kLdsBytes = 2 * kHaloBytes + 2 * kPanelBytes;  // 155648
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 // OIHW 3x3 -> U = G g G^T in A-fragment order:
-//   dst[stage c][co tile nt (32)][ks 2][cb 2][group g 9][lane 64][e 4] = U[pos = 4g + e][co = 32 nt + 16 cb + (lane & 15)][ci = 8c + 4ks + (lane >> 4)]
+//   dst[stage c][co tile nt (32)][ks 2][cb 2][group g 9][lane 64][e 4] = U[pos = 4g + e][co = 32 nt + 16 cb + (lane & 15)][ci = 8c + 2 (lane >> 4) + ks],
+//   pos = 6 nu + xi for ks = 0 and 6 xi + nu for ks = 1
 __global__ __launch_bounds__(256) void pack_wino4_weight_k(const float *__restrict__ w, float *__restrict__ dst, int Cout, int Cin, int nS, int NT) {
     const long long total = (long long)nS * NT * kPanelFloats;
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
@@ -70,11 +78,12 @@ __global__ __launch_bounds__(256) void pack_wino4_weight_k(const float *__restri
         const int cb = (int)(r & 1), ks = (int)((r >> 1) & 1);
         r >>= 2;
         const int nt = (int)(r % NT), c = (int)(r / NT);
-        const int pos = 4 * g + e, co = 32 * nt + 16 * cb + (lane & 15), ci = 8 * c + 4 * ks + (lane >> 4);
+        const int pos = 4 * g + e, co = 32 * nt + 16 * cb + (lane & 15), ci = 8 * c + 2 * (lane >> 4) + ks;
         double u = 0.0;
         if (co < Cout && ci < Cin) {
             const float *gw = w + ((size_t)co * Cin + ci) * 9;
-            const int xi = pos / 6, nu = pos % 6;
+            // k-step 0 is multiplied column by column (pos = 6 nu + xi), k-step 1 row by row (pos = 6 xi + nu): see the kernel's stage body
+            const int xi = ks == 0 ? pos % 6 : pos / 6, nu = ks == 0 ? pos / 6 : pos % 6;
             const double G[6][3] = {{1.0, 0.0, 0.0},
                                     {-8.0 / 15, -4.0 / 15, -2.0 / 15},
                                     {-8.0 / 15, 4.0 / 15, -2.0 / 15},
@@ -107,6 +116,20 @@ __device__ __forceinline__ void bt6(float &d0, float &d1, float &d2, float &d3, 
     d4 = __builtin_fmaf(-2.f, e, c);
     d5 = t5;
 }
+
+// The same transform in six steps of two operations each (in place), so that a step can sit in the shadow of one MFMA
+struct Bt6Steps {
+    float a, b, c, e, t0, t5;
+    template <int K>
+    __device__ __forceinline__ void step(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5) {
+        if constexpr (K == 0) { a = __builtin_fmaf(-4.f, d2, d4); b = __builtin_fmaf(-4.f, d1, d3); }
+        if constexpr (K == 1) { c = __builtin_fmaf(-0.25f, d2, d4); e = __builtin_fmaf(-0.25f, d1, d3); }
+        if constexpr (K == 2) { t0 = __builtin_fmaf(-4.25f, d2, d0); t5 = __builtin_fmaf(-4.25f, d3, d1); }
+        if constexpr (K == 3) { d0 = t0 + d4; d5 = t5 + d5; }
+        if constexpr (K == 4) { d1 = __builtin_fmaf(0.5f, b, a); d2 = __builtin_fmaf(-0.5f, b, a); }
+        if constexpr (K == 5) { d3 = __builtin_fmaf(2.f, e, c); d4 = __builtin_fmaf(-2.f, e, c); }
+    }
+};
 
 __device__ __forceinline__ f32x4 fma4(float s, f32x4 x, f32x4 y) {
     return (f32x4){__builtin_fmaf(s, x[0], y[0]), __builtin_fmaf(s, x[1], y[1]), __builtin_fmaf(s, x[2], y[2]), __builtin_fmaf(s, x[3], y[3])};
@@ -162,6 +185,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
         }
     }
     if (t_cur >= t_end) return;
+    // Every workgroup runs the same instruction stream on the same amount of work, so all 256 of them would hit the stages whose halo
+    // copies miss the L2 (a pixel's 64 channels are two 128-byte lines: every fourth 8-channel stage opens a new one) at the same
+    // moment — a 39 MB burst at HBM every fourth stage and nothing in between.  So the K loop is ROTATED per workgroup: stage c of a
+    // tile works on channel stage (c + rot) mod nS (a sum over channels in another order), rot = 2 x (workgroup pair index), pairs
+    // = the two channel tiles of one input tile, which share their L2 lines.
+    const int rot = (int)(((blockIdx.x >> 3) >> 1) * 2 % (unsigned)nS);
+    auto rot1 = [&](int c) { const int r = c + rot; return r >= nS ? r - nS : r; };  // c in [0, nS)
 
     struct Tile { int img, y0, x0, nt; };
     auto decode = [&](int t) {
@@ -178,8 +208,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
     // ---- global -> LDS staging ----------------------------------------------------------------------------------------------
     // Halo texel (row r 0..17, column col 0..65) lives at texel index p = (4 r + (col & 3)) * 17 + (col >> 2): the 16 tiles of a wave
     // (4 columns apart) read consecutive texels.  A texel = 32 B = two 16-byte granules (channel quads 0 / 1 of the stage), quad q
-    // in granule q ^ swz, swz = (col >> 4) & 1: a ds_read_b32 of 32 lanes (16 tiles x 2 channels) is then 2-way bank conflicted
-    // (the minimum for 8 bytes out of every 32).  Thread t copies granules t, t + 256, ..: 10 halo granules and 9 panel granules.
+    // in granule q ^ swz, swz = (col >> 5) & 1: the 32 lanes of a ds_read_b64 (16 tiles x 2 channel pairs of one quad) cover all 64
+    // banks.  Thread t copies granules t, t + 256, .. (10 of the halo: lanes 2i, 2i + 1 = the 32 contiguous bytes of one texel, i.e.
+    // one cache-line request per texel — the number of lines in flight, not bytes, is what the memory pipeline limits) and 9 of the panel.
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, nS * NT * kPanelBytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsH;
     int voffH[10];
@@ -192,15 +223,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
             const int cq = p % kSlots, rc = p / kSlots;
             const int cm = rc & 3, r = rc >> 2;
             const int col = 4 * cq + cm;
-            const int q = half ^ ((cq >> 2) & 1);
+            const int q = half ^ ((cq >> 3) & 1);
             const int iy = t.y0 - 1 + r, ix = t.x0 - 1 + col;
             const bool ok = (r < 18) & (col < 66) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
             voffH[k] = ok ? (iy * s.W + ix) * s.cs * 4 + 16 * q : kOob;
+#ifdef IDH_ABL_W4_HALFHALO
+            if (k & 1) voffH[k] = kOob;  // half the cache-line requests (timing experiment)
+#endif
         }
     };
     const int voffU = tid * 16;
     // load j of a stage: j < 9: panel granule row j of (stage cu, channel tile ntu); j >= 9: halo granule row j - 9 of stage ch
     auto ld = [&](int j, int cu, int ntu, int ch) -> f32x4 {
+#ifdef IDH_ABL_W4_NOLOAD
+        return (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+#ifdef IDH_ABL_W4_NOPANEL
+        if (j < 9) return (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+#ifdef IDH_ABL_W4_NOHALO
+        if (j >= 9) return (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
         if (j < 9) {
             const int so = __builtin_amdgcn_readfirstlane((cu * NT + ntu) * kPanelBytes + 4096 * j);
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffU, so, 0));
@@ -208,56 +251,81 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, voffH[j - 9], __builtin_amdgcn_readfirstlane(32 * ch), 0));
     };
     auto st = [&](int j, int ubuf, int hbuf, f32x4 v) {
+#ifdef IDH_ABL_W4_NOLDSW
+        asm volatile("" ::"v"(v));
+        return;
+#endif
         const int off = j < 9 ? ubuf + 4096 * j : hbuf + 4096 * (j - 9);
         *(lds_f32x4 *)(lds + off + tid * 16) = v;
     };
 
     // ---- LDS read addresses of this lane ---------------------------------------------------------------------------------------
-    // patch element (i, c) of tile n, wave row block `wave`: texel p = (4 (4 wave + i) + (c & 3)) * 17 + n + (c >> 2)
-    int rbase[2][2];  // [ks][c >> 2]
+    // patch element (i, c) of tile n, wave row block `wave`: texel p = (4 (4 wave + i) + (c & 3)) * 17 + n + (c >> 2); the lane's
+    // channel pair 2h, 2h + 1 = 8 bytes at offset 8 (h & 1) of granule (h >> 1) ^ swz
+    int rbase[2];  // [c >> 2]
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int dc = 0; dc < 2; ++dc) rbase[ks][dc] = 32 * (16 * wave * kSlots + n) + 4 * h + 16 * (ks ^ (((n + dc) >> 2) & 1));
+    for (int dc = 0; dc < 2; ++dc) rbase[dc] = 32 * (16 * wave * kSlots + n) + 16 * ((h >> 1) ^ (((n + dc) >> 3) & 1)) + 8 * (h & 1);
     const int ubase = lane * 16;
 
-    auto rd_row = [&](float (&X)[6][6], int i, int ks, int hbuf) {  // patch row i of pass ks
-#pragma unroll
-        for (int c = 0; c < 6; ++c) X[i][c] = *(lds_cfloat *)(lds + hbuf + rbase[ks][c >> 2] + 32 * ((4 * i + (c & 3)) * kSlots + (c >> 2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) volatile f32x2 lds_cf32x2;  // volatile: hipcc otherwise pairs the reads into ds_read2_b64 (half rate, 8-bit offsets -> an address register per 2 KiB)
+    auto rd_elem = [&](int i, int c, int hbuf, float &x0, float &x1) {  // patch element (i, c) of both channels
+#ifdef IDH_ABL_W4_NORAW
+        return;
+#endif
+        const f32x2 t = *(lds_cf32x2 *)(lds + hbuf + rbase[c >> 2] + 32 * ((4 * i + (c & 3)) * kSlots + (c >> 2)));
+        x0 = t[0];
+        x1 = t[1];
     };
 
+    // Developer build (-DIDH_ABL_W4_TRACE, tools/abl_wino4.sh trace): every wave logs s_memtime along its SECOND tile into ConvArgs.ws
+    // (160 x 8 bytes per wave: [0] tile start, [1 + 15 c + k] stage c < 8: k = 0 entry, 1 first operands ready, 2..13 iteration done,
+    // 14 barrier passed; [125..128] epilogue: K loop done, first copies of the next tile issued, channel block 0 / 1 stored)
+#ifdef IDH_ABL_W4_TRACE
+    unsigned long long *trace = reinterpret_cast<unsigned long long *>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 160;
+    int tile_i = 0;
+#define W4T(idx) do { if (tile_i == 1 && lane == 0) trace[(idx)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W4T(idx) do { } while (0)
+#endif
     f32x4 acc[36][NCO];
-    float A_[6][6], B_[6][6];  // the two patch / W register sets of the transform pipeline
+    float A_[6][6], B_[6][6];  // the stage's patch (then W) of the lane's even / odd channel
     float v[6];                // B operands of the row about to be multiplied
+    f32x4 stg[2][5];           // copies in flight: two batches of 5 granules
 
-    // ---- prologue: halo(0), halo(1), panel(0) of the first tile; W(0, ks 0) and the raw patch of (0, ks 1) -------------------------
+    // ---- prologue: halo(0), halo(1), panel(0) of the first tile; the raw patch of stage 0 ---------------------------------------
     Tile cur = decode(t_cur);
     set_halo_cursor(cur);
     {
         f32x4 tmp[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) tmp[j] = ld(9 + j, 0, cur.nt, 0);
+        for (int j = 0; j < 10; ++j) tmp[j] = ld(9 + j, 0, cur.nt, rot1(0));
 #pragma unroll
         for (int j = 0; j < 10; ++j) st(9 + j, kU0, kH0, tmp[j]);
 #pragma unroll
-        for (int j = 0; j < 10; ++j) tmp[j] = ld(9 + j, 0, cur.nt, 1);
+        for (int j = 0; j < 10; ++j) tmp[j] = ld(9 + j, 0, cur.nt, rot1(1));
 #pragma unroll
         for (int j = 0; j < 10; ++j) st(9 + j, kU0, kH1, tmp[j]);
 #pragma unroll
-        for (int j = 0; j < 9; ++j) tmp[j] = ld(j, 0, cur.nt, 0);
+        for (int j = 0; j < 9; ++j) tmp[j] = ld(j, rot1(0), cur.nt, 0);
 #pragma unroll
         for (int j = 0; j < 9; ++j) st(j, kU0, kH0, tmp[j]);
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rd_row(A_, i, 0, kH0);
+    for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rd_row(B_, i, 1, kH0);
+        for (int c = 0; c < 6; ++c) rd_elem(i, c, kH0, A_[i][c], B_[i][c]);
+#ifndef IDH_ABL_W4_NOXFORM
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bt6(A_[0][j], A_[1][j], A_[2][j], A_[3][j], A_[4][j], A_[5][j]);
+    for (int i = 0; i < 6; ++i) bt6(A_[i][0], A_[i][1], A_[i][2], A_[i][3], A_[i][4], A_[i][5]);  // set 0: rows first
+#endif
+    // batch 0 of the first stage's copies (panel(1), halo(2)): issued here for the first tile, before the epilogue stores for the others
+    auto issue_first = [&](const Tile &t) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) v[j] = A_[0][j];
-    bt6(v[0], v[1], v[2], v[3], v[4], v[5]);
+        for (int j = 0; j < 5; ++j) stg[0][j] = ld(j, rot1(1), t.nt, rot1(2));
+    };
+    issue_first(cur);
 
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
 
@@ -270,91 +338,142 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
         for (int p = 0; p < 36; ++p)
 #pragma unroll
             for (int j = 0; j < NCO; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        W4T(0);
 
-        // One stage S = (tile, c): multiplies W(S, 0) and W(S, 1) with panel(S) [U buffer PAR]; transforms the patches of (S, 1)
-        // and (S + 1, 0); reads the patches of (S + 1, 0 / 1) from halo(S + 1) [H buffer PAR ^ 1]; copies panel(S + 1) into U
-        // buffer PAR ^ 1 and halo(S + 2) into H buffer PAR.  nS is even, so a tile always starts at parity 0.
+        // One stage S = (tile, c): multiplies W(S) (sets A_, B_) with panel(S) [U buffer PAR]; reads the patch of S + 1 from halo(S + 1)
+        // [H buffer PAR ^ 1]; copies panel(S + 1) into U buffer PAR ^ 1 and halo(S + 2) into H buffer PAR.  nS is even (and >= 4), so a
+        // tile always starts at parity 0.  On entry: A_ = patch of S with the row transform applied, B_ = raw patch of S.
         auto stage = [&](auto parc, const int c) {
             constexpr int PAR = decltype(parc)::value;
             constexpr int kUr = PAR ? kU1 : kU0, kUw = PAR ? kU0 : kU1;
             constexpr int kHr = PAR ? kH0 : kH1, kHw = PAR ? kH1 : kH0;
             if (PAR == 0 && c + 2 == nS) set_halo_cursor(nxt);  // from here on the halo copies belong to the next tile
             const bool un = c + 1 >= nS;
-            const int cu = un ? 0 : c + 1, ntu = un ? nxt.nt : cur.nt;
-            const int ch = c + 2 >= nS ? c + 2 - nS : c + 2;
-            f32x4 stg[7];
+            const int cu = rot1(un ? 0 : c + 1), ntu = un ? nxt.nt : cur.nt;
+            const int ch = rot1(c + 2 >= nS ? c + 2 - nS : c + 2);
+            [[maybe_unused]] const int tr0 = 1 + 15 * (c < 8 ? c : 8);  // (stages >= 8 overwrite a scratch slot range that the tool ignores)
+            W4T(tr0);
             f32x4 Af[NCO][9];
-            auto rd_frag = [&](int ks, int g) {
+            auto rd_frag = [&](int ks, int g, int cb) { Af[cb][g] = *(lds_cf32x4 *)(lds + kUr + ubase + ((ks * 2 + cb) * 9 + g) * 1024); };
+            rd_frag(0, 0, 0); rd_frag(0, 0, 1); rd_frag(0, 1, 0); rd_frag(0, 1, 1);
+            if (PAR == 1 || c != 0) {  // (a tile's first stage: issued before the previous tile's epilogue)
 #pragma unroll
-                for (int cb = 0; cb < NCO; ++cb) Af[cb][g] = *(lds_cf32x4 *)(lds + kUr + ubase + ((ks * 2 + cb) * 9 + g) * 1024);
-            };
-            rd_frag(0, 0);
-            rd_frag(0, 1);
+                for (int j = 0; j < 5; ++j) stg[0][j] = ld(j, cu, ntu, ch);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) stg[1][j] = ld(5 + j, cu, ntu, ch);
+            // column 0 of set 0 -> the first B operands
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = A_[i][0];
+#ifndef IDH_ABL_W4_NOXFORM
+            bt6(v[0], v[1], v[2], v[3], v[4], v[5]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            W4T(tr0 + 1);
 #pragma unroll
             for (int it = 0; it < 12; ++it) {
-                const int pass = it / 6, xi = it % 6;
-                float(&X)[6][6] = pass == 0 ? A_ : B_;
-                float(&Y)[6][6] = pass == 0 ? B_ : A_;
-                // copies: three batches of 7 / 6 / 6 granules, issued at it = 0 / 4 / 8, written to LDS three iterations later
-                if (it == 0) {
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) stg[j] = ld(j, cu, ntu, ch);
-                }
-                if (it == 4) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) stg[j] = ld(7 + j, cu, ntu, ch);
-                }
-                if (it == 8) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) stg[j] = ld(13 + j, cu, ntu, ch);
-                }
-                // A fragments first needed by the next iteration (those of the next stage wait for its barrier)
-                if (xi == 0) rd_frag(pass, 2);
-                if (xi == 1) { rd_frag(pass, 3); rd_frag(pass, 4); }
-                if (xi == 2) rd_frag(pass, 5);
-                if (xi == 3) { rd_frag(pass, 6); rd_frag(pass, 7); }
-                if (xi == 4) rd_frag(pass, 8);
-                if (it == 5) { rd_frag(1, 0); rd_frag(1, 1); }
-                // row xi of X has been consumed (its B operands are in v): refill it with the patch of the pass after next
-                rd_row(X, xi, pass, kHr);
-                // vertical transform of column xi of the next pass's patch
-                bt6(Y[0][xi], Y[1][xi], Y[2][xi], Y[3][xi], Y[4][xi], Y[5][xi]);
-                // 12 MFMAs of row xi
-                float vc[6];
+                const int pass = it / 6, xi = it % 6;  // pass 0: xi = column of set 0; pass 1: xi = row of set 1
+                float vc[6], vn[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) vc[j] = v[j];
-                // horizontal transform of the NEXT row (row xi + 1 of X, or row 0 of Y which is complete after this iteration's column)
-                if (xi < 5) {
+                // the transform in progress in slots 0..5 (t1) and 6..11 (t2)
+                Bt6Steps t1, t2;
+                // t2 = final transform of the next line: pass 0: column xi + 1 of set 0 (after column 5: row 0 of set 1); pass 1: row xi + 1 of
+                // set 1 (after row 5: nothing — set 0's last row gets its row transform instead, and the next stage starts with column 0)
+                if (pass == 0) {
+                    if (xi < 5) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) v[j] = X[xi + 1][j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) v[j] = Y[0][j];
-                }
-                bt6(v[0], v[1], v[2], v[3], v[4], v[5]);
-#pragma unroll
-                for (int nu = 0; nu < 6; ++nu)
-#pragma unroll
-                    for (int cb = 0; cb < NCO; ++cb) {
-                        const int p = 6 * xi + nu;
-                        if (p < 32) mfma_pinned<true>(acc[p][cb], Af[cb][p >> 2][p & 3], vc[nu]);
-                        else mfma_pinned<false>(acc[p][cb], Af[cb][p >> 2][p & 3], vc[nu]);
+                        for (int i = 0; i < 6; ++i) vn[i] = A_[i][xi + 1];
                     }
-                if (it == 3) {
+                } else if (xi < 5) {
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) st(j, kUw, kHw, stg[j]);
+                    for (int j = 0; j < 6; ++j) vn[j] = B_[xi + 1][j];
                 }
-                if (it == 7) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) st(7 + j, kUw, kHw, stg[j]);
-                }
-                if (it == 11) {
+                for (int k = 0; k < 12; ++k) {
+                    // ---- the MFMA of the slot
+#ifndef IDH_ABL_W4_NOMFMA
+                    {
+                        const int cb = k & 1, l = k >> 1;             // l: index along the line being multiplied
+                        const int q = 6 * xi + l;                       // packed position (column-major in pass 0, row-major in pass 1)
+                        const int p = pass == 0 ? 6 * l + xi : q;       // accumulator = position (xi_w, nu_w) = 6 xi_w + nu_w
+                        if (p < 32) mfma_pinned<true>(acc[p][cb], Af[cb][q >> 2][q & 3], vc[l]);
+                        else mfma_pinned<false>(acc[p][cb], Af[cb][q >> 2][q & 3], vc[l]);
+                    }
+#else
+                    asm volatile("" ::"v"(vc[k >> 1]));
+#endif
+                    // ---- two transform operations
+#ifndef IDH_ABL_W4_NOXFORM
+                    if (k < 6) {
+                        auto s1 = [&](auto kc) {
+                            constexpr int K = decltype(kc)::value;
+                            if (pass == 0) t1.template step<K>(B_[0][xi], B_[1][xi], B_[2][xi], B_[3][xi], B_[4][xi], B_[5][xi]);        // set 1: columns first
+                            else if (xi >= 1) t1.template step<K>(A_[xi - 1][0], A_[xi - 1][1], A_[xi - 1][2], A_[xi - 1][3], A_[xi - 1][4], A_[xi - 1][5]);  // set 0 of S + 1: rows first
+                        };
+                        if (k == 0) s1(std::integral_constant<int, 0>{});
+                        if (k == 1) s1(std::integral_constant<int, 1>{});
+                        if (k == 2) s1(std::integral_constant<int, 2>{});
+                        if (k == 3) s1(std::integral_constant<int, 3>{});
+                        if (k == 4) s1(std::integral_constant<int, 4>{});
+                        if (k == 5) s1(std::integral_constant<int, 5>{});
+                    } else {
+                        auto s2 = [&](auto kc) {
+                            constexpr int K = decltype(kc)::value;
+                            if (it == 5) {  // row 0 of set 1 (its column transform completed in slot 5)
+                                if (K == 0) {
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) st(13 + j, kUw, kHw, stg[j]);
+                                    for (int j = 0; j < 6; ++j) vn[j] = B_[0][j];
+                                }
+                                t2.template step<K>(vn[0], vn[1], vn[2], vn[3], vn[4], vn[5]);
+                            } else if (it == 11) {  // row 5 of set 0 of S + 1 (read in slots 0..5)
+                                t2.template step<K>(A_[5][0], A_[5][1], A_[5][2], A_[5][3], A_[5][4], A_[5][5]);
+                            } else {
+                                t2.template step<K>(vn[0], vn[1], vn[2], vn[3], vn[4], vn[5]);
+                            }
+                        };
+                        if (k == 6) s2(std::integral_constant<int, 0>{});
+                        if (k == 7) s2(std::integral_constant<int, 1>{});
+                        if (k == 8) s2(std::integral_constant<int, 2>{});
+                        if (k == 9) s2(std::integral_constant<int, 3>{});
+                        if (k == 10) s2(std::integral_constant<int, 4>{});
+                        if (k == 11) s2(std::integral_constant<int, 5>{});
+                    }
+#endif
+                    // ---- at most one LDS / global access pair
+                    // pass 1, slots 0..5: row xi of both sets has been consumed (set 0 in pass 0; set 1's B operands are in vc): next stage's patch
+                    if (pass == 1 && k < 6) rd_elem(xi, k, kHr, A_[xi][k], B_[xi][k]);
+                    // A fragments first needed by the next iteration (those of the next stage wait for its barrier)
+                    {
+                        const int gi = k - 6;  // slots 6..9
+                        int g = -1;
+                        if (xi == 0 && gi < 2) g = 2;
+                        if (xi == 1) g = gi < 2 ? 3 : 4;
+                        if (xi == 2 && gi < 2) g = 5;
+                        if (xi == 3) g = gi < 2 ? 6 : 7;
+                        if (xi == 4 && gi < 2) g = 8;
+                        if (it == 5) g = gi < 2 ? 0 : 1;
+                        if (gi >= 0 && gi < 4 && g >= 0 && it != 11) rd_frag(it == 5 ? 1 : pass, g, gi & 1);
+                    }
+                    // copies: four batches of 5 / 5 / 5 / 4 granules, two in flight: batches 0 and 1 are issued at the stage start, batch b is
+                    // written to LDS in slots 0..4 of iteration 3 b + 2 and batch b + 2 issued into its registers
+                    if ((it == 2 || it == 5 || it == 8 || it == 11) && k < 5) {
+                        const int b = it / 3;
+                        if (5 * b + k < 19) {
+                            st(5 * b + k, kUw, kHw, stg[b & 1][k]);
+                            if (b < 2 && 5 * (b + 2) + k < 19) stg[b & 1][k] = ld(5 * (b + 2) + k, cu, ntu, ch);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (it != 11) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) v[j] = vn[j];
+                }
+                W4T(tr0 + 2 + it);
             }
             __syncthreads();
+            W4T(tr0 + 14);
         };
 
 #pragma unroll 1
@@ -362,15 +481,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
             stage(std::integral_constant<int, 0>{}, c);
             stage(std::integral_constant<int, 1>{}, c + 1);
         }
+        W4T(125);
+        issue_first(nxt);  // batch 0 of the next tile's first stage, ahead of this tile's output stores
 
         // ---- epilogue: Y = A^T M A per 16-channel block; lane = 4 consecutive channels of the 4x4 pixels of tile n --------------
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results (inline asm: no compiler-inserted wait states)
+        W4T(126);
+#ifdef IDH_ABL_W4_NOEPI
+#pragma unroll
+        for (int p = 0; p < 36; ++p)
+#pragma unroll
+            for (int j = 0; j < NCO; ++j) {
+                if (p < 32) asm volatile("" ::"a"(acc[p][j]));
+                else asm volatile("" ::"v"(acc[p][j]));
+            }
+#else
         {
             const int n0 = 32 * cur.nt;
             const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur.img * a.Ho * a.Wo * a.out_cs, 0, a.Ho * a.Wo * a.out_cs * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)cur.img * a.Ho * a.Wo * a.res_cs : a.out), 0,
                                                                                   a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
             const int oy0 = cur.y0 + 4 * wave, ox0 = cur.x0 + 4 * n;
+            const bool has_res = a.res != nullptr;
             // LeakyReLU / identity only (wino4_supported): v < 0 ? v * slope : v with slope = 1 for "no activation" — branch-free,
             // and no inlined expm1f per output element (ELU layers stay on the other kernels)
             const float slope_eff = a.act == IDH_ACT_LRELU ? a.slope : 1.f;
@@ -394,27 +526,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 r[4];
-                    int voff[4];
+                    int pix[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
-                        const int pix = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
-                        voff[i] = pix;
-                        r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? (pix * a.res_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0));
+                        pix[i] = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
+                        r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pix[i] >= 0 ? (pix[i] * a.res_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0));
                     }
                     f32x4 y[4];
                     at6(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], y[0], y[1], y[2], y[3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const f32x4 o = act4(y[i] + b4 + r[i]);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, voff[i] >= 0 ? (voff[i] * a.out_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0);
                     }
                 }
+                W4T(127 + cb);
             }
         }
+#endif
         if (!has_next) break;
         t_cur = t_next;
         cur = nxt;
+#ifdef IDH_ABL_W4_TRACE
+        ++tile_i;
+#endif
     }
 }
 
@@ -444,7 +585,7 @@ namespace idh_conv {
 
 bool wino4_supported(const ConvArgs &a) {
     const ConvSrc &s = a.s[0];
-    return !a.s[1].in && (a.act == IDH_ACT_NONE || a.act == IDH_ACT_LRELU) && s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && a.S == 1 && (a.Cout % 32) == 0 &&
+    return !a.s[1].in && (a.act == IDH_ACT_NONE || a.act == IDH_ACT_LRELU) && s.cblocks >= 2 && s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && a.S == 1 && (a.Cout % 32) == 0 &&
            (long long)s.H * s.W * s.cs * 4 < (1ll << 31) && (long long)a.Ho * a.Wo * a.out_cs * 4 < (1ll << 31) &&
            (!a.res || (long long)a.Ho * a.Wo * a.res_cs * 4 < (1ll << 31)) && (long long)s.cblocks * a.Cout_pad * 36 * 16 * 4 < (1ll << 31);
 }

@@ -228,7 +228,7 @@ def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act
     (v0, c0) = srcs[0]
     if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 32 or isinstance(v0, CatView):
         return False
-    if act not in (ACT_NONE, ACT_LRELU):
+    if act not in (ACT_NONE, ACT_LRELU) or c0.in_channels <= 16:  # (the copy pipeline runs two 8-channel stages ahead)
         return False
     ty, tx = -(-Ho // 16), -(-Wo // 64)
     if Ho * Wo < WINO4_MIN_FILL * (ty * 16) * (tx * 64):

@@ -44,10 +44,10 @@ def _run(nhwc, conv, x_nhwc, res, act, slope, wino4, out_view=None, twice=False)
 
 # (B, cin, cout, H, W, residual, act): whole tiles, ragged maps (partial tiles in both directions, odd sizes), channel counts that
 # need zero-padded input buffers (24, 112), wide outputs (NT = 3, 8), one map smaller than a tile, enough tiles that a persistent
-# workgroup walks several (the stream crosses tile boundaries), a single 16-channel block (two stages)
+# workgroup walks several (the stream crosses tile boundaries), the smallest channel count the kernel takes (17 -> 4 stages)
 @pytest.mark.parametrize("shape", [(2, 64, 64, 32, 128, True, 1), (1, 24, 64, 37, 45, False, 1), (3, 112, 96, 9, 33, True, 0), (1, 192, 64, 64, 96, False, 1),
-                                   (2, 128, 256, 24, 32, True, 1), (1, 16, 32, 8, 32, False, 1), (1, 64, 32, 5, 17, True, 1), (5, 32, 64, 16, 70, False, 1),
-                                   (40, 64, 64, 48, 128, True, 1), (1, 16, 32, 16, 64, False, 0)])
+                                   (2, 128, 256, 24, 32, True, 1), (1, 32, 32, 8, 32, False, 1), (1, 64, 32, 5, 17, True, 1), (5, 32, 64, 16, 70, False, 1),
+                                   (40, 64, 64, 48, 128, True, 1), (1, 17, 32, 16, 64, False, 0)])
 def test_wino4_conv_vs_fp64_and_direct(shape, wino4_everywhere):
     nhwc = wino4_everywhere
     B, cin, cout, H, W, use_res, act = shape
@@ -98,13 +98,14 @@ def test_wino4_conv_channel_strided_views(wino4_everywhere):
 
 
 def test_wino4_not_taken_for_fused_projection_or_elu(wino4_everywhere):
-    """blocks with a 1x1 projection keep the F(2x2) kernel (its P steps), ELU layers the direct / F(2x2) kernels"""
+    """blocks with a 1x1 projection keep the F(2x2) kernel (its P steps), ELU layers and <= 16 input channels the other kernels"""
     nhwc = wino4_everywhere
     conv, proj = nn.Conv2d(64, 64, 3, 1, 1).cuda(), nn.Conv2d(32, 64, 1).cuda()
     x, x2 = torch.randn(1, 32, 64, 64, device="cuda"), torch.randn(1, 32, 64, 32, device="cuda")
     p = nhwc.Plan(x.device)
     p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=1, x2=nhwc.View(x2, 0, 32), conv2=proj)
     p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=2)
+    p.conv(nhwc.View(x, 0, 16), nn.Conv2d(16, 64, 3, 1, 1).cuda(), p.buffer(1, 32, 64, 64), act=1)
     assert all(op.tile_m != nhwc.TILE_WINO4 for op in p.ops)
 
 
