@@ -69,6 +69,13 @@ def parse(argv=None):
     ap.add_argument("--no-split-line", action="store_true", help="skip the secondary split-precision measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the warp_match / temporal objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend: nccl (= RCCL over xGMI; one rank per GPU) or gloo (host-side collectives: lets several ranks share "
+                         "ONE device with --ranks-on-device, which RCCL refuses — the way the N > 1 code path is exercised on a 1-GPU box)")
+    ap.add_argument("--ranks-on-device", type=int, default=None, metavar="D",
+                    help="put every rank on cuda:D instead of cuda:LOCAL_RANK (test rig for --dist-backend gloo; never for measurements)")
+    ap.add_argument("--rank-report", default=None, metavar="DIR",
+                    help="every rank writes DIR/rank<r>.json (its shard, input checksum, device) — evidence for the N > 1 tests")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args(argv)
     if args.math is not None:
@@ -122,6 +129,11 @@ class WarpMatchDot:
         from implicit_depth_amd.cost_volume import volume_opts
 
         self.opts, self._keep = volume_opts(self.B, self.K, self.C, self.H, self.W, self.D, dot_scratch_device=device)
+
+    def input_checksum(self):
+        """float64 sum of this rank's synthetic inputs (seed = rank: ranks must differ)"""
+        t = self.host_l1 if getattr(self, "host_l1", None) is not None else self.host_inputs["src_feats"]
+        return float(t.double().sum()) + float(self.host_inputs["src_extrinsics"].double().sum())
 
     def config(self):
         return {"workload": f"{self.name}: fused plane-sweep warp+match, {self.W * 4}x{self.H * 4} image, matching map {self.W}x{self.H}, "
@@ -252,6 +264,11 @@ class HotPathWorkload:
             self.host_l1 = syn.layer1_maps(self.B, self.K, self.H, self.W, seed=rank)
             self.l1 = self.host_l1.to(device)
         self.out = None
+
+    def input_checksum(self):
+        """float64 sum of this rank's synthetic inputs (seed = rank: ranks must differ)"""
+        t = self.host_l1 if getattr(self, "host_l1", None) is not None else self.host_inputs["src_feats"]
+        return float(t.double().sum()) + float(self.host_inputs["src_extrinsics"].double().sum())
 
     def config(self):
         vol = "fused MLP feature volume (FeatureVolumeManager, implicit_depth.yaml)" if self.volume == "mlp" else "fused warp+match (dot, CostVolumeManager)"
@@ -575,8 +592,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if args.ranks_on_device is not None and args.dist_backend == "nccl" and world > 1:
+        raise SystemExit("--ranks-on-device with more than one rank needs --dist-backend gloo (RCCL refuses duplicate devices)")
+    dev_index = local_rank if args.ranks_on_device is None else args.ranks_on_device
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     # strong scaling: the global batch is fixed (32 ScanNet-shaped tuples) and sharded by frame
     global_batch = args.batch
     counts = shard_counts(global_batch, world)
@@ -584,7 +604,11 @@ def main():
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun: exercise RCCL even at N=1
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")  # host-side collectives (tensors are staged through the CPU below)
+    host_coll = use_dist and args.dist_backend == "gloo"
 
     wl = WORKLOADS[args.workload](args, device, rank)
     if wl.scaling == "weak":  # temporal: one sequence per GPU
@@ -611,7 +635,7 @@ def main():
             el = time.perf_counter() - t0
             torch.cuda.synchronize()
         per_step = [a.elapsed_time(b) for a, b in evs]
-        t = torch.tensor([el], device=device, dtype=torch.float64)
+        t = torch.tensor([el], device="cpu" if host_coll else device, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.item(), per_step
@@ -640,8 +664,19 @@ def main():
     # the path's only collective: all-gather of per-frame metric vectors (RCCL over xGMI)
     from implicit_depth_amd.dist import all_gather_metrics
 
-    m = all_gather_metrics(wl.metrics().float().contiguous(), counts=counts)
+    local_rows = wl.metrics().float().contiguous()
+    m = all_gather_metrics(local_rows.cpu() if host_coll else local_rows, counts=counts)
     frames_total = frames_per_step_total * args.steps
+    if args.rank_report:
+        os.makedirs(args.rank_report, exist_ok=True)
+        lo = sum(counts[:rank])
+        with open(os.path.join(args.rank_report, f"rank{rank}.json"), "w") as f:
+            json.dump({"rank": rank, "world": world, "device": str(device), "backend": args.dist_backend if use_dist else None,
+                       "frames": [lo, lo + counts[rank]], "input_checksum": wl.input_checksum(), "local_metric_rows": int(local_rows.shape[0]),
+                       "gathered_metric_rows": int(m.shape[0]),
+                       # (metric rows hold NaN where a score is undefined, as the reference's do: compare with NaN == NaN)
+                       "gathered_rows_match_local": bool(torch.equal(torch.nan_to_num(m[lo:lo + counts[rank]].cpu(), nan=-7.0),
+                                                                      torch.nan_to_num(local_rows.cpu(), nan=-7.0)))}, f)
 
     if rank == 0:
         if wl.bound == "hbm":
@@ -699,7 +734,11 @@ def main():
             "config": dict(wl.config(), global_batch=frames_per_step_total),
             "roofline": roof,
             "gathered_metric_rows": int(m.shape[0]),
+            "dist_backend": (args.dist_backend if use_dist else None),
         }
+        if args.ranks_on_device is not None:
+            out["note_ranks_on_device"] = (f"all {world} ranks ran on cuda:{args.ranks_on_device} (code-path exercise of the N > 1 branch on a 1-GPU box; "
+                                           "the rate is NOT a multi-GPU measurement)")
         if split is not None:
             out["split_precision"] = split
         if wl.name == "hot_path" and getattr(wl, "mlp_math", "fp32") == "fp32":

@@ -148,10 +148,15 @@ __device__ __forceinline__ void at6(f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f32x
 // through inline asm with the register file pinned per accumulator: positions 0..31 in AGPRs, positions 32..35 in VGPRs.
 // (No software hazard applies: gfx950 needs no wait states between a VALU write and an MFMA SrcA/B read, and an accumulator is
 // re-used 72 MFMAs later; the epilogue waits explicitly before it reads them.)
-template <bool AGPR>
+template <bool AGPR, bool ZERO = false>
 __device__ __forceinline__ void mfma_pinned(f32x4 &acc, float a, float b) {
-    if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    if constexpr (ZERO) {  // first product of a tile: C = 0 (no 288-register clear per tile)
+        if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+    } else {
+        if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
 }
 
 template <int NCO>
@@ -188,9 +193,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
     // Every workgroup runs the same instruction stream on the same amount of work, so all 256 of them would hit the stages whose halo
     // copies miss the L2 (a pixel's 64 channels are two 128-byte lines: every fourth 8-channel stage opens a new one) at the same
     // moment — a 39 MB burst at HBM every fourth stage and nothing in between.  So the K loop is ROTATED per workgroup: stage c of a
-    // tile works on channel stage (c + rot) mod nS (a sum over channels in another order), rot = 2 x (workgroup pair index), pairs
+    // tile works on channel stage (c + rot) mod nS (a sum over channels in another order), rot = workgroup pair index, pairs
     // = the two channel tiles of one input tile, which share their L2 lines.
-    const int rot = (int)(((blockIdx.x >> 3) >> 1) * 2 % (unsigned)nS);
+    const int rot = (int)(((blockIdx.x >> 3) >> 1) % (unsigned)nS);
     auto rot1 = [&](int c) { const int r = c + rot; return r >= nS ? r - nS : r; };  // c in [0, nS)
 
     struct Tile { int img, y0, x0, nt; };
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
 
     // Developer build (-DIDH_ABL_W4_TRACE, tools/abl_wino4.sh trace): every wave logs s_memtime along its SECOND tile into ConvArgs.ws
     // (160 x 8 bytes per wave: [0] tile start, [1 + 15 c + k] stage c < 8: k = 0 entry, 1 first operands ready, 2..13 iteration done,
-    // 14 barrier passed; [125..128] epilogue: K loop done, first copies of the next tile issued, channel block 0 / 1 stored)
+    // 14 barrier passed; [125..129] epilogue: K loop done, first copies of the next tile issued, row pass of channel block 0 / 1 done, stored)
 #ifdef IDH_ABL_W4_TRACE
     unsigned long long *trace = reinterpret_cast<unsigned long long *>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 160;
     int tile_i = 0;
@@ -334,17 +339,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
         const int t_next = t_cur + t_stride;
         const bool has_next = t_next < t_end;
         const Tile nxt = has_next ? decode(t_next) : cur;  // (past the end: re-read this tile's first stages, never used)
-#pragma unroll
-        for (int p = 0; p < 36; ++p)
-#pragma unroll
-            for (int j = 0; j < NCO; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         W4T(0);
 
         // One stage S = (tile, c): multiplies W(S) (sets A_, B_) with panel(S) [U buffer PAR]; reads the patch of S + 1 from halo(S + 1)
         // [H buffer PAR ^ 1]; copies panel(S + 1) into U buffer PAR ^ 1 and halo(S + 2) into H buffer PAR.  nS is even (and >= 4), so a
         // tile always starts at parity 0.  On entry: A_ = patch of S with the row transform applied, B_ = raw patch of S.
-        auto stage = [&](auto parc, const int c) {
+        auto stage = [&](auto parc, auto firstc, const int c) {
             constexpr int PAR = decltype(parc)::value;
+            constexpr bool FIRST = decltype(firstc)::value;  // the tile's first stage: pass 0 starts the accumulators (C = 0)
             constexpr int kUr = PAR ? kU1 : kU0, kUw = PAR ? kU0 : kU1;
             constexpr int kHr = PAR ? kH0 : kH1, kHw = PAR ? kH1 : kH0;
             if (PAR == 0 && c + 2 == nS) set_halo_cursor(nxt);  // from here on the halo copies belong to the next tile
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
             f32x4 Af[NCO][9];
             auto rd_frag = [&](int ks, int g, int cb) { Af[cb][g] = *(lds_cf32x4 *)(lds + kUr + ubase + ((ks * 2 + cb) * 9 + g) * 1024); };
             rd_frag(0, 0, 0); rd_frag(0, 0, 1); rd_frag(0, 1, 0); rd_frag(0, 1, 1);
-            if (PAR == 1 || c != 0) {  // (a tile's first stage: issued before the previous tile's epilogue)
+            if (!FIRST) {  // (a tile's first stage: issued before the previous tile's epilogue)
 #pragma unroll
                 for (int j = 0; j < 5; ++j) stg[0][j] = ld(j, cu, ntu, ch);
             }
@@ -397,8 +399,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
                         const int cb = k & 1, l = k >> 1;             // l: index along the line being multiplied
                         const int q = 6 * xi + l;                       // packed position (column-major in pass 0, row-major in pass 1)
                         const int p = pass == 0 ? 6 * l + xi : q;       // accumulator = position (xi_w, nu_w) = 6 xi_w + nu_w
-                        if (p < 32) mfma_pinned<true>(acc[p][cb], Af[cb][q >> 2][q & 3], vc[l]);
-                        else mfma_pinned<false>(acc[p][cb], Af[cb][q >> 2][q & 3], vc[l]);
+                        if (FIRST && pass == 0) {
+                            if (p < 32) mfma_pinned<true, true>(acc[p][cb], Af[cb][q >> 2][q & 3], vc[l]);
+                            else mfma_pinned<false, true>(acc[p][cb], Af[cb][q >> 2][q & 3], vc[l]);
+                        } else {
+                            if (p < 32) mfma_pinned<true>(acc[p][cb], Af[cb][q >> 2][q & 3], vc[l]);
+                            else mfma_pinned<false>(acc[p][cb], Af[cb][q >> 2][q & 3], vc[l]);
+                        }
                     }
 #else
                     asm volatile("" ::"v"(vc[k >> 1]));
@@ -465,6 +472,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef IDH_ABL_W4_TRACE
+                    if ((it == 5 || it == 6) && c == 2) W4T(130 + 12 * (it - 5) + k);  // slot stamps of two iterations of stage 2
+#endif
                 }
                 if (it != 11) {
 #pragma unroll
@@ -476,10 +486,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
             W4T(tr0 + 14);
         };
 
+        stage(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+        stage(std::integral_constant<int, 1>{}, std::false_type{}, 1);
 #pragma unroll 1
-        for (int c = 0; c < nS; c += 2) {
-            stage(std::integral_constant<int, 0>{}, c);
-            stage(std::integral_constant<int, 1>{}, c + 1);
+        for (int c = 2; c < nS; c += 2) {
+            stage(std::integral_constant<int, 0>{}, std::false_type{}, c);
+            stage(std::integral_constant<int, 1>{}, std::false_type{}, c + 1);
         }
         W4T(125);
         issue_first(nxt);  // batch 0 of the next tile's first stage, ahead of this tile's output stores
@@ -511,43 +523,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
                 for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
                 return o;
             };
+            // horizontal pass (over nu) row by row for both channel blocks; the 2 x 24 intermediate quads are parked in the AGPRs the
+            // accumulators leave
+            f32x4 b4[NCO], u[NCO][6][4];
 #pragma unroll
             for (int cb = 0; cb < NCO; ++cb) {
-                const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 16 * cb + 4 * h) * 4, 0, 0));
-                // horizontal pass (over nu) row by row; the 24 intermediate quads are parked in the AGPRs the row's accumulators leave
-                f32x4 u[6][4];
+                b4[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 16 * cb + 4 * h) * 4, 0, 0));
 #pragma unroll
                 for (int xi = 0; xi < 6; ++xi) {
-                    at6(acc[6 * xi][cb], acc[6 * xi + 1][cb], acc[6 * xi + 2][cb], acc[6 * xi + 3][cb], acc[6 * xi + 4][cb], acc[6 * xi + 5][cb], u[xi][0], u[xi][1], u[xi][2], u[xi][3]);
+                    at6(acc[6 * xi][cb], acc[6 * xi + 1][cb], acc[6 * xi + 2][cb], acc[6 * xi + 3][cb], acc[6 * xi + 4][cb], acc[6 * xi + 5][cb], u[cb][xi][0], u[cb][xi][1], u[cb][xi][2],
+                        u[cb][xi][3]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(u[xi][j]));
-                }
-                // vertical pass (over xi) per output column j: 4 pixels, finished and stored at once
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 r[4];
-                    int pix[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
-                        pix[i] = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
-                        r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-                    if (has_res) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pix[i] >= 0 ? (pix[i] * a.res_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0));
-                    }
-                    f32x4 y[4];
-                    at6(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], y[0], y[1], y[2], y[3]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 o = act4(y[i] + b4 + r[i]);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0);
-                    }
+                    for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(u[cb][xi][j]));
                 }
                 W4T(127 + cb);
             }
+            // vertical pass (over xi) per output column j: 4 pixels x 2 channel blocks, finished and stored at once — the two 64-byte halves
+            // of a pixel's 128-byte line leave back to back (stored thousands of cycles apart they reach HBM as two partial-line writes:
+            // WRITE_SIZE 1.46x the output)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 r[NCO][4], y[NCO][4];
+                int pix[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
+                    pix[i] = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
+#pragma unroll
+                    for (int cb = 0; cb < NCO; ++cb) r[cb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int cb = 0; cb < NCO; ++cb)
+                            r[cb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pix[i] >= 0 ? (pix[i] * a.res_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0));
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCO; ++cb) at6(u[cb][0][j], u[cb][1][j], u[cb][2][j], u[cb][3][j], u[cb][4][j], u[cb][5][j], y[cb][0], y[cb][1], y[cb][2], y[cb][3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int cb = 0; cb < NCO; ++cb) {
+                        const f32x4 o = act4(y[cb][i] + b4[cb] + r[cb][i]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0);
+                    }
+            }
+            W4T(129);
         }
 #endif
         if (!has_next) break;

@@ -218,17 +218,20 @@ def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> b
 
 # Winograd F(4x4,3x3) (csrc/conv_wino4.hip) for the LARGE plain 3x3 layers: 1.78x fewer MFMAs than F(2x2); 64 x 16 pixel x 32
 # channel tiles on one persistent workgroup per CU, so it needs >= WINO4_MIN_TILES tiles (a few per CU) and maps that fill the
-# tile grid; LeakyReLU / no activation, no fused 1x1 source (those blocks stay on F(2x2) with its P steps).
+# tile grid; LeakyReLU / no activation, no fused 1x1 source (those blocks stay on F(2x2) with its P steps).  Measured at B = 32
+# (tools/perf_wino4.py, profiles/r04/experiments.md): 192->64 @192x256 1.17x and @96x128 1.13x over F(2x2), 64->64 0.97-1.03x
+# (per-tile epilogue + copy costs are amortised over 8 instead of 24 K stages) -> WINO4_MIN_CIN.
 WINOGRAD4 = True
 WINO4_MIN_TILES = 512
 WINO4_MIN_FILL = 0.85
+WINO4_MIN_CIN = 128
 
 
 def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act: int) -> bool:
     (v0, c0) = srcs[0]
     if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 32 or isinstance(v0, CatView):
         return False
-    if act not in (ACT_NONE, ACT_LRELU) or c0.in_channels <= 16:  # (the copy pipeline runs two 8-channel stages ahead)
+    if act not in (ACT_NONE, ACT_LRELU) or c0.in_channels <= 16 or c0.in_channels < WINO4_MIN_CIN:  # (<= 16: the copy pipeline runs two 8-channel stages ahead)
         return False
     ty, tx = -(-Ho // 16), -(-Wo // 64)
     if Ho * Wo < WINO4_MIN_FILL * (ty * 16) * (tx * 64):
@@ -802,7 +805,7 @@ def build_flags() -> tuple:
     """Module-level switches that shape a plan at build time (part of every plan-cache key: toggling one takes effect on the
     next call instead of silently replaying a plan built under the old setting)."""
     return (WINO_GROUP, FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
-            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINO4_MIN_TILES, WINO4_MIN_FILL, DEFAULT_MATH)
+            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINO4_MIN_TILES, WINO4_MIN_FILL, WINO4_MIN_CIN, DEFAULT_MATH)
 
 
 def _plan_cache(module: nn.Module) -> PlanCache:

@@ -18,10 +18,10 @@ def wino4_everywhere():
     """Force the F(4x4) kernel onto every eligible layer regardless of grid size / tile fill."""
     from implicit_depth_amd import nhwc
 
-    old = (nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL)
-    nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = True, 1, 0.0
+    old = (nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL, nhwc.WINO4_MIN_CIN)
+    nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL, nhwc.WINO4_MIN_CIN = True, 1, 0.0, 0
     yield nhwc
-    nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = old
+    nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL, nhwc.WINO4_MIN_CIN = old
 
 
 def _run(nhwc, conv, x_nhwc, res, act, slope, wino4, out_view=None, twice=False):

@@ -183,3 +183,35 @@ def test_plan_cache_replays_alternating_batch_sizes():
         assert len(model._plans) == 3 and rel_err(y1b.cpu(), y1.cpu()) < 1e-6
     finally:
         nhwc.MERGE_LEVELS = old
+
+
+def test_bench_n2_branch_on_one_gpu_over_gloo(tmp_path):
+    """bench.py's N > 1 branch (shard, barrier, MAX all-reduce, ragged metric all-gather, rank-0 JSON) under a real launcher with
+    real kernels: two ranks share the single GPU of the box over gloo (RCCL refuses duplicate devices; the RCCL leg itself is the
+    N = 1 run of profiles/*/torchrun_n1_rccl_debug.log).  Reference analogue: sync_dist logging bd_model.py:672,685, row shape
+    test_bd.py:288-339."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rep = tmp_path / "ranks"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29613",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "7", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--ranks-on-device", "0",
+           "--no-extras", "--no-split-line", "--no-cpu-baseline", "--rank-report", str(rep)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, "rank 0 prints exactly one JSON line"
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 7 and out["gathered_metric_rows"] == 7
+    assert out["dist_backend"] == "gloo" and "note_ranks_on_device" in out and out["value"] > 0
+    ranks = [json.load(open(rep / f"rank{i}.json")) for i in range(2)]
+    assert [r_["frames"] for r_ in ranks] == [[0, 4], [4, 7]], "ragged shard: 7 frames over 2 ranks"
+    assert ranks[0]["input_checksum"] != ranks[1]["input_checksum"], "per-rank inputs differ (seed = rank)"
+    assert all(r_["gathered_rows_match_local"] and r_["gathered_metric_rows"] == 7 for r_ in ranks)
+    log = os.path.join(root, "gpurun_out", "bench_n2_gloo_one_gpu.json")
+    os.makedirs(os.path.dirname(log), exist_ok=True)
+    json.dump({"bench_line": out, "ranks": ranks}, open(log, "w"), indent=1)

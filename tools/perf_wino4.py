@@ -29,6 +29,7 @@ def build(conv, x, res, tm):
     Bn, H, W, cin = x.shape
     out = p.buffer(Bn, H, W, conv.out_channels)
     old = (nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL)
+    nhwc.WINO4_MIN_CIN = 0
     nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = tm == nhwc.TILE_WINO, tm == nhwc.TILE_WINO4, 1, 1, 0.0
     try:
         p.conv(nhwc.View(x, 0, cin), conv, out, act=1, slope=0.2, res=None if res is None else nhwc.View(res, 0, conv.out_channels))

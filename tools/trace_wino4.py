@@ -14,7 +14,7 @@ from implicit_depth_amd import nhwc
 cin, cout, H, W = [int(v) for v in sys.argv[1:5]]
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 32
 use_res = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = True, 1, 0.0
+nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL, nhwc.WINO4_MIN_CIN = True, 1, 0.0, 0
 conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda(); syn.fill_state_dict(conv, 1)
 x = torch.randn(B, H, W, cin, device="cuda")
 res = torch.randn(B, H, W, cout, device="cuda") if use_res else None
@@ -43,10 +43,18 @@ print("  iterations (median over waves/stages): " + " ".join(f"{med(d[..., 1 + i
 print("  iterations p90:                        " + " ".join(f"{np.percentile(d[..., 1 + i], 90):.0f}" for i in range(12)))
 for c in range(ns):
     print(f"  stage {c}: start {med(d[:, :, c, 0]):.0f} | " + " ".join(f"{med(d[:, :, c, 1 + i]):.0f}" for i in range(12)) + f" | barrier {med(d[:, :, c, 13]):.0f}")
+rotp = ((np.arange(blocks) >> 4) % nS) & 1
+for rp in (0, 1):
+    sel = rotp == rp
+    print(f"  workgroups with rot parity {rp}: even stages " + " ".join(f"{med(d[sel][:, :, 0:ns:2, 1 + i]):.0f}" for i in range(12)) + "   odd stages: " + " ".join(f"{med(d[sel][:, :, 1:ns:2, 1 + i]):.0f}" for i in range(12)))
+for w in range(0):
+    print(f"  wave {w}, even stages: " + " ".join(f"{med(d[:, w, 0:ns:2, 1 + i]):.0f}" for i in range(12)) + "   odd stages: " + " ".join(f"{med(d[:, w, 1:ns:2, 1 + i]):.0f}" for i in range(12)))
+sl = t[:, :, 130:154]
+print("  stage 2, slots of iteration 5 then 6 (cycles since the previous stamp): " + " ".join(f"{med(sl[:, :, i] - (sl[:, :, i - 1] if i else st[:, :, 2, 6])):.0f}" for i in range(24)))
 for par in (0, 1):
     print(f"  parity {par} stages: iterations " + " ".join(f"{med(d[:, :, par::2, 1 + i]):.0f}" for i in range(12)) + f"  barrier {med(d[:, :, par::2, 13]):.0f}")
 if nS <= 8:
-    print(f"  epilogue: K loop done -> first copies issued {med(t[:, :, 126] - t[:, :, 125]):.0f}; channel block 0 {med(t[:, :, 127] - t[:, :, 126]):.0f}; block 1 {med(t[:, :, 128] - t[:, :, 127]):.0f}"
-          f"; tile start -> first stage {med(t[:, :, 1] - t[:, :, 0]):.0f}; whole tile {med(t[:, :, 128] - t[:, :, 0]):.0f}")
+    print(f"  epilogue: K loop done -> first copies issued {med(t[:, :, 126] - t[:, :, 125]):.0f}; row pass block 0 {med(t[:, :, 127] - t[:, :, 126]):.0f}; block 1 {med(t[:, :, 128] - t[:, :, 127]):.0f}"
+          f"; column pass + stores {med(t[:, :, 129] - t[:, :, 128]):.0f}; tile start -> first stage {med(t[:, :, 1] - t[:, :, 0]):.0f}; whole tile {med(t[:, :, 129] - t[:, :, 0]):.0f}")
 else:
-    print(f"  epilogue: channel block 0 {med(t[:, :, 127] - t[:, :, 126]):.0f}; block 1 {med(t[:, :, 128] - t[:, :, 127]):.0f}; whole tile {med(t[:, :, 128] - t[:, :, 0]):.0f}")
+    print(f"  epilogue: row pass block 0 {med(t[:, :, 127] - t[:, :, 126]):.0f}; block 1 {med(t[:, :, 128] - t[:, :, 127]):.0f}; column pass + stores {med(t[:, :, 129] - t[:, :, 128]):.0f}; whole tile {med(t[:, :, 129] - t[:, :, 0]):.0f}")
