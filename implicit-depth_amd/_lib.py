@@ -30,7 +30,11 @@ class VolumeOpts(C.Structure):
 
     _fields_ = [("cur_batch_stride", C.c_int64), ("src_batch_stride", C.c_int64), ("planes", C.c_void_p),
                 ("planes_batch_stride", C.c_int64), ("planes_plane_stride", C.c_int64), ("planes_pixel_stride", C.c_int32),
-                ("kernel", C.c_int32), ("scratch", C.c_void_p), ("scratch_floats", C.c_int64)]
+                ("kernel", C.c_int32), ("scratch", C.c_void_p), ("scratch_floats", C.c_int64), ("struct_size", C.c_int64)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(VolumeOpts)
 
 
 CV_KERNEL_LANE, CV_KERNEL_QUAD, CV_KERNEL_WINDOW = 1, 2, 3  # IDH_CV_KERNEL_* of include/idh.h
@@ -38,6 +42,7 @@ CV_KERNEL_LANE, CV_KERNEL_QUAD, CV_KERNEL_WINDOW = 1, 2, 3  # IDH_CV_KERNEL_* of
 
 _SIGS = {
     "idh_version": (C.c_int, []),
+    "idh_sizeof_volume_opts": (C.c_size_t, []),
     "idh_cost_volume_dot_scratch_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "idh_error_string": (C.c_char_p, [C.c_int]),
     "idh_nchw_to_nhwc_f32": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -145,11 +150,19 @@ def invalidate_weight_caches() -> None:
     _weights_epoch += 1
 
 
+def _sd_post_hook(module, incompatible_keys) -> None:
+    """load_state_dict post-hook (a module-level function, not a closure: a module carrying it still pickles)."""
+    invalidate_weight_caches()
+
+
 def watch_state_dict_loads(module) -> None:
-    """``module.load_state_dict()`` (on the module or any parent) invalidates the caches above."""
-    if not module.__dict__.get("_idh_sd_hook"):
-        module.register_load_state_dict_post_hook(lambda m, incompatible_keys: invalidate_weight_caches())
-        module.__dict__["_idh_sd_hook"] = True
+    """``load_state_dict()`` on the module, on any parent, or on ANY of its submodules (e.g. straight into ``cost_volume.mlp`` or a
+    ``Conv2d`` inside a decoder's ``ModuleDict``) invalidates the caches above: load_state_dict runs the post-hooks of every module
+    it descends into, so the hook is registered on each of them."""
+    for m in module.modules():
+        if not m.__dict__.get("_idh_sd_hook"):
+            m.register_load_state_dict_post_hook(_sd_post_hook)
+            m.__dict__["_idh_sd_hook"] = True
 
 
 def param_version(t):

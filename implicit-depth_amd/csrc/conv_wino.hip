@@ -424,7 +424,10 @@ __device__ __forceinline__ void wino_tiles(const WinoArgs &wa, f32x4 *lds, const
 #pragma unroll
     for (int k = 0; k < kTPW; ++k) issue_next(k, false, 0, 0, 0);
     WINO_TRACE(tr_i++);
-    __syncthreads();  // (the compiler drains vmcnt before the barrier: the DMA of every wave has landed)
+    // the barrier publishes LDS bytes written by LDS-DMA: every wave's copies must have LANDED before it.  hipcc (ROCm 7.2) happens
+    // to drain vmcnt before s_barrier, but gfx950's back-off barriers do not oblige it to: say so explicitly.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     WINO_TRACE(tr_i++);
 
     int it = 0;  // K steps done by this workgroup: step `it` is computed from stage it & 1
@@ -484,6 +487,7 @@ __device__ __forceinline__ void wino_tiles(const WinoArgs &wa, f32x4 *lds, const
             }
             ++it;
             WINO_TRACE(tr_i < 61 ? tr_i++ : 61);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's LDS-DMA pieces (next stage) have landed before the barrier publishes them
             __syncthreads();
             WINO_TRACE(tr_i < 61 ? tr_i++ : 61);
         }
@@ -559,6 +563,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_wino_group_k(const Wino
     for (int i = 0; i < g.n; ++i) {
         const unsigned vblock = (((blockIdx.x >> 3) + per - (unsigned)g.rot[i] % per) % per) << 3 | (blockIdx.x & 7);
         wino_tiles<WAVES, NCO, CH, SRC2>(g.op[i], lds, vblock, gridDim.x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the trailing, unused LDS-DMA of the op's last step must not land after the next op's)
         __syncthreads();  // the next op's first copies overwrite the LDS stages
     }
 }

@@ -1094,7 +1094,8 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
         a.tiles_x = idh_cdiv(W, kTileW); a.tiles_y = idh_cdiv(H, kTileH);
         cv_win_split(B, K, H, W, D, &a.psplit, &a.units_per_split);
         // optional scratch for the arg-max over split planes (idh_volume_opts.scratch: >= idh_cost_volume_dot_scratch_floats)
-        a.partial = (opts && opts->scratch && lowest_bhw && a.psplit > 1 && opts->scratch_floats >= 2ll * a.psplit * B * H * W) ? opts->scratch : nullptr;
+        a.partial = (opts && opts->struct_size == (int64_t)sizeof(idh_volume_opts) && opts->scratch && lowest_bhw && a.psplit > 1 &&
+                     opts->scratch_floats >= 2ll * a.psplit * B * H * W) ? opts->scratch : nullptr;
         a.list_bytes = ((a.units_per_split + 3) / 4) * K * kRunsPerPair * (int)sizeof(RunEntry);
         a.planes_bytes = ((D + 3) & ~3) * (int)sizeof(float);
         const size_t lds = (size_t)kWinBytes + a.list_bytes + a.planes_bytes + (size_t)K * 12 * sizeof(float);

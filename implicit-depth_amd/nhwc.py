@@ -767,10 +767,16 @@ def math_of(module: nn.Module) -> str:
 PLAN_CACHE_ENTRIES = 4
 
 
+class ParamKey(tuple):
+    """The part of a plan-cache key that names parameter versions / build-time switches (as opposed to input shapes)."""
+
+
 class PlanCache:
     """Small LRU of execution plans (one entry = ops + all activation buffers of one input shape): an evaluation loop whose last
     batch is ragged, or a caller alternating two layouts / batch sizes, replays instead of rebuilding; the oldest entry (and its
-    buffers) goes when a fifth shape arrives."""
+    buffers) goes when a fifth shape arrives.  The LRU is for SHAPES only: an entry that differs from a new key just in its ParamKey
+    parts (weights reloaded or updated in place, a build switch toggled) can never be hit again, so it is dropped at once — a
+    checkpoint load after a warm-up forward does not double the resident activation memory."""
 
     def __init__(self, entries: int = PLAN_CACHE_ENTRIES):
         import collections
@@ -784,7 +790,14 @@ class PlanCache:
             self.d.move_to_end(key)
         return ent
 
+    @staticmethod
+    def _same_shapes(a, b) -> bool:
+        return (isinstance(a, tuple) and isinstance(b, tuple) and len(a) == len(b) and
+                all(x == y or (isinstance(x, ParamKey) and isinstance(y, ParamKey)) for x, y in zip(a, b)))
+
     def put(self, key, ent):
+        for k in [k for k in self.d if k != key and self._same_shapes(k, key)]:
+            del self.d[k]  # same shapes, stale parameters / switches
         self.d[key] = ent
         self.d.move_to_end(key)
         while len(self.d) > self.entries:
@@ -818,7 +831,7 @@ def _plan_cache(module: nn.Module) -> PlanCache:
 
 
 def _param_key(module: nn.Module):
-    return (math_of(module), build_flags()) + tuple((p.data_ptr(), _lib.param_version(p)) for p in module.parameters())
+    return ParamKey((math_of(module), build_flags()) + tuple((p.data_ptr(), _lib.param_version(p)) for p in module.parameters()))
 
 
 def _check_in(*ts):

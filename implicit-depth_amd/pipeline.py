@@ -55,7 +55,7 @@ class HotPath(nn.Module):
         matching backbone's layer1 map (B*(K+1), head_ch, H, W) in that physical layout and runs the encoder head."""
         key = (B, K, C, H, W, tuple(tuple(s) for s in enc_shapes), str(device), self.conv_math, head, head_ch,
                nhwc._param_key(self.cost_volume_net), nhwc._param_key(self.depth_decoder),
-               nhwc._param_key(self.matching_model.net[5]) + nhwc._param_key(self.matching_model.net[8]) if head else None)
+               nhwc.ParamKey(nhwc._param_key(self.matching_model.net[5]) + nhwc._param_key(self.matching_model.net[8])) if head else None)
         ent = self._plans.get(key)
         if ent is not None:
             return ent

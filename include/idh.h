@@ -76,7 +76,14 @@ typedef struct idh_volume_opts {
                        pixel here and the arg-max pass combines those instead of re-reading the whole volume (same result:
                        first maximum wins).  NULL: no scratch, the pass reads the volume. */
     int64_t scratch_floats;
+    int64_t struct_size; /* = sizeof(idh_volume_opts) of the header the caller was built against (idh_sizeof_volume_opts() tells what the
+                            library was built with).  The fields from `scratch` on were added in ABI version 101: the library honours them
+                            only when struct_size covers them, so a caller built against the version-100 header (a shorter struct) is never
+                            read past its end into a garbage scratch pointer. */
 } idh_volume_opts;
+
+/* sizeof(idh_volume_opts) as compiled into the library (bindings assert their mirror matches; idh_version() >= 101). */
+size_t idh_sizeof_volume_opts(void);
 
 #define IDH_CV_KERNEL_LANE 1   /* cv_dot_k: one lane per sample, taps through the vector L1 */
 #define IDH_CV_KERNEL_QUAD 2   /* cv_dot_quad_k: four lanes per sample, quad-coalesced taps */

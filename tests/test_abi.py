@@ -36,7 +36,7 @@ def test_error_strings_and_host_only_entry_points():
     from implicit_depth_amd import _lib
 
     L = _lib.lib()
-    assert L.idh_version() >= 100
+    assert L.idh_version() >= 101
     assert L.idh_error_string(0) == b"ok"
     assert b"workspace" in L.idh_error_string(-4)
     # argument validation happens before any launch: safe without a GPU
@@ -62,6 +62,7 @@ def test_op_descriptor_layout_matches_library():
     from implicit_depth_amd import _lib, nhwc
 
     assert ctypes.sizeof(nhwc.Op) == _lib.lib().idh_sizeof_op()
+    assert ctypes.sizeof(_lib.VolumeOpts) == _lib.lib().idh_sizeof_volume_opts() == _lib.VolumeOpts().struct_size
     assert _lib.lib().idh_packed_weight_floats(40, 24, 3) == 9 * 32 * 48
     assert _lib.lib().idh_run_ops(None, 0, None) == 0
 

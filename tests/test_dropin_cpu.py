@@ -99,3 +99,37 @@ def test_plan_cache_is_a_small_lru():
     c.put("d", "D")                    # evicts the least recently used: "b"
     assert c.get("b") is None and c.get("a") == "A" and c.get("c") == "C" and c.get("d") == "D" and len(c) == 3
     assert isinstance(nhwc.build_flags(), tuple) and nhwc.WINOGRAD in nhwc.build_flags()
+
+
+def test_plan_cache_drops_entries_with_stale_parameters():
+    """the LRU is for shapes only: a key that differs from a cached one just in its ParamKey parts replaces it at once (a checkpoint
+    load after a warm-up forward must not keep the old plan's activation buffers alive)"""
+    from implicit_depth_amd import nhwc
+
+    c = nhwc.PlanCache(entries=4)
+    pk = lambda v: nhwc.ParamKey(("fp32", ("flags",), (1234, v)))
+    c.put(("bb", (1, 16, 8, 8), "cuda:0", pk(0)), "plan v0")
+    c.put(("bb", (2, 16, 8, 8), "cuda:0", pk(0)), "other shape")
+    c.put(("bb", (1, 16, 8, 8), "cuda:0", pk(1)), "plan v1")  # same shape, new parameter version
+    assert len(c) == 2 and c.get(("bb", (1, 16, 8, 8), "cuda:0", pk(0))) is None
+    assert c.get(("bb", (1, 16, 8, 8), "cuda:0", pk(1))) == "plan v1" and c.get(("bb", (2, 16, 8, 8), "cuda:0", pk(0))) == "other shape"
+
+
+def test_state_dict_load_into_an_unwatched_child_invalidates_and_modules_pickle():
+    """load_state_dict straight into a submodule (cost_volume.mlp, a Conv2d inside a decoder's ModuleDict) under inference_mode bumps the
+    weights epoch, and the hook is a module-level function: the module still pickles"""
+    import io
+    import pickle
+
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd import networks as net
+
+    with torch.inference_mode():
+        dec = net.BDDecoderPP([24, 64, 128, 256, 384])
+    _lib.watch_state_dict_loads(dec)
+    child = next(m for m in dec.modules() if isinstance(m, torch.nn.Conv2d))
+    e0 = _lib._weights_epoch
+    with torch.inference_mode():
+        child.load_state_dict({k: v * 0.5 for k, v in child.state_dict().items()})
+    assert _lib._weights_epoch == e0 + 1
+    pickle.load(io.BytesIO(pickle.dumps(dec)))
