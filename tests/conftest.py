@@ -43,3 +43,18 @@ def chk(t):
 
 
 TOL = 1e-4  # BASELINE.json: "outputs within 1e-4 rel of reference" (scale-relative)
+
+
+def block_err(t, blocks_ref, bd, bh, bw):
+    """Largest deviation of the (bd, bh, bw)-block sums of a (1, D, H, W) tensor from the reference's (tests/golden/g_full_blocks.npz),
+    per block element and relative to the tensor's scale — catches an error confined to a few voxels BETWEEN the slice points of the
+    full-size goldens (a single voxel off by 1e-2 of the scale moves its block's figure by 1e-2 / block size)."""
+    import numpy as np
+    import torch
+
+    t = torch.as_tensor(t).detach().cpu()[0].double()
+    D, H, W = t.shape
+    b = t.reshape(D // bd, bd, H // bh, bh, W // bw, bw).sum((1, 3, 5)).numpy()
+    ref = np.asarray(blocks_ref)
+    scale = max(float(t.abs().max()), 1e-30)
+    return float(np.abs(b - ref).max()) / (bd * bh * bw) / scale

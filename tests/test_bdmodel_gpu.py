@@ -119,6 +119,11 @@ def test_full_size_bdmodel_forward_golden(volume):
               rendered_depth=cur["rendered_depth"], return_mask=True)
     pred, low = out["pred_0"].cpu(), out["lowest_cost_bhw"].cpu()
     assert rel_err(pred[:, :, ::6, ::8], g["pred_slice"]) < TOL
+    if volume == "mlp":
+        from conftest import block_err
+
+        be = block_err(pred, load_golden("g_full_blocks")["g5_full_bdmodel_mlp_pred_1x8x8"], 1, 8, 8)  # every 8x8 block of every plane
+        assert be < 5e-5, be
     s = pred.double()
     import numpy as np
 

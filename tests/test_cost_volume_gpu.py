@@ -264,6 +264,10 @@ def test_every_kernel_full_size_golden(kernel):
     inp = syn.cost_volume_inputs(B, K, C, H, W, 0)
     cv, low, _ = _run(inp, D, KERNELS[kernel])
     assert rel_err(cv[:, ::4, ::6, ::8], g["cost_slice"]) < TOL
+    from conftest import block_err
+
+    be = block_err(cv, load_golden("g_full_blocks")["g1_full_k8d64_cost_8x8x8"], 8, 8, 8)  # every 8x8x8 block, not only the slice points
+    assert be < 2e-6, be
     s = cv.double()
     np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["cost_chk"][1:], rtol=1e-4)  # the plain sum cancels to 1e-3 of |.|
     assert _lowest_mismatch(low[:, ::3, ::4], g["lowest_slice"]) < 5e-3

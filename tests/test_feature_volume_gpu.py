@@ -81,6 +81,10 @@ def test_full_size_golden():
     fv, low, planes, mask = m(**{k: v.cuda() for k, v in inp.items()}, return_mask=True)
     fv, low, mask = fv.cpu(), low.cpu(), mask.cpu()
     assert rel_err(fv[:, ::4, ::6, ::8], g["fv_slice"]) < TOL
+    from conftest import block_err
+
+    be = block_err(fv, load_golden("g_full_blocks")["g2_full_k7d64_fv_8x8x8"], 8, 8, 8)  # every 8x8x8 block, not only the slice points
+    assert be < 5e-6, be
     s = fv.double()
     np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["fv_chk"][1:], rtol=1e-4)
     assert ((low[:, ::3, ::4] - torch.as_tensor(g["lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3

@@ -93,6 +93,11 @@ def test_full_size_forward_from_layer1_map(volume):
     assert rel_err(feats[:, :, :, ::6, ::8], g["head_feats_slice"]) < TOL
     pred, low = out["pred_0"].cpu(), out["lowest_cost_bhw"].cpu()
     assert rel_err(pred[:, :, ::6, ::8], g["head_pred_slice"]) < TOL
+    if volume == "mlp":
+        from conftest import block_err
+
+        be = block_err(pred, load_golden("g_full_blocks")["g5_full_bdmodel_mlp_head_pred_1x8x8"], 1, 8, 8)  # every 8x8 block of every plane
+        assert be < 5e-5, be
     s = pred.double()
     np.testing.assert_allclose([s.abs().sum().item(), (s * s).sum().item()], g["head_pred_chk"][1:], rtol=2e-4)
     assert ((low[:, ::3, ::4] - torch.as_tensor(g["head_lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import implicit_depth_amd.synthetic as syn
-from conftest import TOL, chk, load_golden, rel_err
+from conftest import TOL, block_err, chk, load_golden, rel_err
 from oracle import cost_volume as ocv
 from oracle import networks as onet
 
@@ -41,6 +41,7 @@ def test_cost_volume_dot_full_size_checksums():
                                      inp["src_Ks"], inp["cur_invK"], 0.25, 5.0, D)
     assert rel_err(cv[:, ::4, ::6, ::8], g["cost_slice"]) < 2e-5
     np.testing.assert_allclose(chk(cv)[1:], g["cost_chk"][1:], rtol=1e-5)
+    assert block_err(cv, load_golden("g_full_blocks")["g1_full_k8d64_cost_8x8x8"], 8, 8, 8) < 2e-7  # every 8x8x8 block of the volume
     mism = (torch.as_tensor(g["lowest_slice"]) - low[:, ::3, ::4]).abs() > 1e-5
     assert mism.float().mean().item() < 5e-3
 
@@ -87,6 +88,7 @@ def test_feature_volume_full_size_checksums():
         inp["cur_invK"], 0.25, 5.0, D, w, return_mask=True)
     assert rel_err(fv[:, ::4, ::6, ::8], g["fv_slice"]) < 5e-5
     np.testing.assert_allclose(chk(fv)[1:], g["fv_chk"][1:], rtol=1e-5)
+    assert block_err(fv, load_golden("g_full_blocks")["g2_full_k7d64_fv_8x8x8"], 8, 8, 8) < 1e-6  # every 8x8x8 block of the volume
     assert ((torch.as_tensor(g["lowest_slice"]) - low[:, ::3, ::4]).abs() > 1e-5).float().mean().item() < 5e-3
     assert (mask[:, ::3, ::4] != torch.as_tensor(g["mask_slice"])).float().mean().item() < 2e-3
     assert abs(int(mask.sum()) - int(g["mask_count"])) <= 0.002 * mask.numel()
