@@ -190,7 +190,7 @@ __device__ __forceinline__ void wino_tiles(const WinoArgs &wa, f32x4 *lds, const
     int voffH[kHP], panel_so;
     const int voffP = 16 * lane;
     auto halo_piece = [&](int k) { return wave + WAVES * k < kHaloPieces ? wave + WAVES * k : wave; };  // k-th halo piece of this wave
-    auto halo_voff = [&](int j) {  // byte offset of this lane's 16 bytes of piece j: texel p = 32 j + lane / 2, plane (lane & 1) ^ swz
+    auto halo_voff = [&](int j, int lane) {  // byte offset of this lane's 16 bytes of piece j: texel p = 32 j + lane / 2, plane (lane & 1) ^ swz
         const int pt = 32 * j + (lane >> 1);
         const int row = pt / kWinoHalf, hxh = pt - row * kWinoHalf;
         const int q = (lane & 1) ^ ((hxh >> 3) & 1);
@@ -200,8 +200,13 @@ __device__ __forceinline__ void wino_tiles(const WinoArgs &wa, f32x4 *lds, const
     };
     auto set_fetch_tile = [&]() {  // from (y0, x0, cb0, img)
         rsA = BufRef{s.in + (size_t)img * s.H * s.W * s.cs, s.H * s.W * s.cs * 4};
+        // (the lane's row / column split of each piece is re-derived per tile from an opaque copy of the lane id: hoisted out of the tile
+        // loop these ~10 values do not fit beside the accumulators and come back as scratch reloads in the tile header — each of which
+        // waits, through the in-order vmcnt, for every LDS-DMA piece in flight)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
 #pragma unroll
-        for (int k = 0; k < kHP; ++k) voffH[k] = halo_voff(halo_piece(k));
+        for (int k = 0; k < kHP; ++k) voffH[k] = halo_voff(halo_piece(k), lane_o);
         panel_so = (cb0 * (4 * KS) + wave * kPanel) * 1024;
     };
     // ---- second source (P steps of 32 channels): the tile's own 32 x kRows pixels, pixel-major — slot 8 P + (plane ^ swz(P)),

@@ -29,6 +29,7 @@ def build(conv, x, res, tm, tn, proj=None, x2=None):
     Bn, H, W, cin = x.shape
     out = p.buffer(Bn, H, W, conv.out_channels)
     old_w, nhwc.WINOGRAD = nhwc.WINOGRAD, tm == nhwc.TILE_WINO
+    old4, nhwc.WINOGRAD4 = nhwc.WINOGRAD4, False  # (this tool compares F(2x2) with the direct kernel; tools/perf_wino4.py has F(4x4))
     old = nhwc.WINO_MIN_TILES
     nhwc.WINO_MIN_TILES = 1
     try:
@@ -36,6 +37,7 @@ def build(conv, x, res, tm, tn, proj=None, x2=None):
                x2=None if proj is None else nhwc.View(x2, 0, proj.in_channels), conv2=proj)
     finally:
         nhwc.WINOGRAD = old_w
+        nhwc.WINOGRAD4 = old4
         nhwc.WINO_MIN_TILES = old
     op = p.ops[0]
     if tm != nhwc.TILE_WINO:
