@@ -504,69 +504,74 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
 #pragma unroll
             for (int i = 0; i < 8 * kJmax; ++i) m[i] = 0.f;
             bool any_inb = false, any_front = false;
+            // ONE view per iteration of a run-time loop (round 4: the 16-view unrolled form kept every view's temporaries and the 32
+            // metadata slots live at once: 1.4-2.5 KB of scratch per lane).  The metadata registers keep compile-time indices: view k
+            // belongs to lane quarter k & 3, slot group k >> 2, selected by predicate.
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const float *hm = pb + kWsHom + 12 * k;
+                const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+                const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+                const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+                const float cx = fmaf(depth, qx, hm[9]);
+                const float cy = fmaf(depth, qy, hm[10]);
+                const float cz = fmaf(depth, qz, hm[11]);
+                const float z = fmaxf(cz, 1e-5f);
+                float rc = __builtin_amdgcn_rcpf(z);
+                rc = rc * fmaf(-z, rc, 2.0f);
+                const float su = cx * rc, sv = cy * rc;
+                any_inb |= (su > 2.f) & (su < Wf - 2.f) & (sv > 2.f) & (sv < Hf - 2.f);
+                any_front |= z > 0.f;
+                const float sx = fminf(fmaxf(su - 0.5f, -1.0f), Wf);
+                const float sy = fminf(fmaxf(sv - 0.5f, -1.0f), Hf);
+                const float x0f = floorf(sx), y0f = floorf(sy);
+                const float fx = sx - x0f, fy = sy - y0f;
+                const int x0 = (int)x0f, y0 = (int)y0f;
+                const float wx0 = (x0 >= 0 && x0 < a.W) ? 1.0f - fx : 0.f;
+                const float wx1 = (x0 + 1 < a.W) ? fx : 0.f;
+                const float wy0 = (y0 >= 0 && y0 < a.H) ? 1.0f - fy : 0.f;
+                const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
+                const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
+                const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
+                const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+                const float *sb = a.src + (size_t)b * a.src_bs + (size_t)k * N * kCc + 4 * q;
+                const float maskv = z > 0.f ? 1.f : 0.f;
+                float part = 0.f;
 #pragma unroll
-            for (int j = 0; j < kJmax; ++j) {
+                for (int cb = 0; cb < CB; ++cb) {
+                    const f32x4 t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kCc + 16 * cb);
+                    const f32x4 t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kCc + 16 * cb);
+                    const f32x4 t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kCc + 16 * cb);
+                    const f32x4 t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kCc + 16 * cb);
+                    f32x4 wv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = 4 * j + r;
-                    if (k < K) {
-                        const float *hm = pb + kWsHom + 12 * k;
-                        const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
-                        const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
-                        const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
-                        const float cx = fmaf(depth, qx, hm[9]);
-                        const float cy = fmaf(depth, qy, hm[10]);
-                        const float cz = fmaf(depth, qz, hm[11]);
-                        const float z = fmaxf(cz, 1e-5f);
-                        float rc = __builtin_amdgcn_rcpf(z);
-                        rc = rc * fmaf(-z, rc, 2.0f);
-                        const float su = cx * rc, sv = cy * rc;
-                        any_inb |= (su > 2.f) & (su < Wf - 2.f) & (sv > 2.f) & (sv < Hf - 2.f);
-                        any_front |= z > 0.f;
-                        const float sx = fminf(fmaxf(su - 0.5f, -1.0f), Wf);
-                        const float sy = fminf(fmaxf(sv - 0.5f, -1.0f), Hf);
-                        const float x0f = floorf(sx), y0f = floorf(sy);
-                        const float fx = sx - x0f, fy = sy - y0f;
-                        const int x0 = (int)x0f, y0 = (int)y0f;
-                        const float wx0 = (x0 >= 0 && x0 < a.W) ? 1.0f - fx : 0.f;
-                        const float wx1 = (x0 + 1 < a.W) ? fx : 0.f;
-                        const float wy0 = (y0 >= 0 && y0 < a.H) ? 1.0f - fy : 0.f;
-                        const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
-                        const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
-                        const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
-                        const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
-                        const float *sb = a.src + (size_t)b * a.src_bs + (size_t)k * N * kCc + 4 * q;
-                        const float maskv = z > 0.f ? 1.f : 0.f;
-                        float part = 0.f;
+                    for (int e = 0; e < 4; ++e) wv[e] = fmaf(w11, t11[e], fmaf(w10, t10[e], fmaf(w01, t01[e], w00 * t00[e])));
+                    // per-quarter partial of <warped, cur> in channel order: block cb's 4 channels of this quarter
+                    float pc = wv[0] * cur4[cb][0];
+                    pc = fmaf(wv[1], cur4[cb][1], pc); pc = fmaf(wv[2], cur4[cb][2], pc); pc = fmaf(wv[3], cur4[cb][3], pc);
+                    part += pc;
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) {
-                            const f32x4 t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kCc + 16 * cb);
-                            const f32x4 t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kCc + 16 * cb);
-                            const f32x4 t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kCc + 16 * cb);
-                            const f32x4 t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kCc + 16 * cb);
-                            f32x4 wv;
+                    for (int i = 0; i < kNS; ++i) {
+                        const f32x4 A = gW1[((size_t)(k * CB + cb) * kNS + i) * 64 + lane];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) wv[e] = fmaf(w11, t11[e], fmaf(w10, t10[e], fmaf(w01, t01[e], w00 * t00[e])));
-                            // per-quarter partial of <warped, cur> in channel order: block cb's 4 channels of this quarter
-                            float pc = wv[0] * cur4[cb][0];
-                            pc = fmaf(wv[1], cur4[cb][1], pc); pc = fmaf(wv[2], cur4[cb][2], pc); pc = fmaf(wv[3], cur4[cb][3], pc);
-                            part += pc;
-#pragma unroll
-                            for (int i = 0; i < kNS; ++i) {
-                                const f32x4 A = gW1[((size_t)(k * CB + cb) * kNS + i) * 64 + lane];
-#pragma unroll
-                                for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
-                            }
-                        }
-                        part += __shfl_xor(part, 16, 64);
-                        part += __shfl_xor(part, 32, 64);
-                        const float dotv = part * maskv;
-                        const bool mine = r == q;
-                        m[7 * j + 0] = mine ? maskv : m[7 * j + 0];
-                        m[7 * j + 1] = mine ? z : m[7 * j + 1];
-                        m[7 * j + 2] = mine ? dotv : m[7 * j + 2];
+                        for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
                     }
                 }
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+                const float dotv = part * maskv;
+                const bool mine = (k & 3) == q;
+                const int jk = k >> 2;
+#pragma unroll
+                for (int j = 0; j < kJmax; ++j) {
+                    const bool sel = mine && jk == j;
+                    m[7 * j + 0] = sel ? maskv : m[7 * j + 0];
+                    m[7 * j + 1] = sel ? z : m[7 * j + 1];
+                    m[7 * j + 2] = sel ? dotv : m[7 * j + 2];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kJmax; ++j) {
                 // ray / ray angle of this quarter's j-th view (cost_volume.py:630-659)
                 const int v = q + 4 * j;
                 if (j < J && v < K) {
@@ -591,6 +596,7 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
                         const f32x4 A = gW1[((size_t)(K * CB + c) * kNS + i) * 64 + lane];
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], m[4 * c + kk], acc1[i], 0, 0, 0);
+                        if (i & 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }

@@ -1,11 +1,12 @@
-"""Copy the summaries of a tools/final_profiles.sh run (gpurun_out/<tag>/...) into profiles/r03/, refresh profiles/pmc_traffic.json and the
-bench-line table of profiles/r03/README.md:  python tools/collect_profiles.py <tag>"""
+"""Copy the summaries of a tools/final_profiles.sh run (gpurun_out/<tag>/...) into profiles/<round>/, refresh profiles/pmc_traffic.json and the
+bench-line table of profiles/<round>/README.md:  python tools/collect_profiles.py <tag> [round = r04]"""
 import glob, json, os, shutil, sys
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(root)
-S, D = f"gpurun_out/{tag}", "profiles/r03"
+S, D = f"gpurun_out/{tag}", f"profiles/{sys.argv[2] if len(sys.argv) > 2 else 'r04'}"
+os.makedirs(f"{D}/matrix", exist_ok=True)
 for f in glob.glob(f"{S}/matrix/*.json"):
     shutil.copy(f, f"{D}/matrix/")
 shutil.copy(f"{S}/bench_default.json", f"{D}/bench_hot_path_mlp_k7_gb32.json")
