@@ -326,9 +326,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
     for (int i = 0; i < 6; ++i) bt6(A_[i][0], A_[i][1], A_[i][2], A_[i][3], A_[i][4], A_[i][5]);  // set 0: rows first
 #endif
     // batch 0 of the first stage's copies (panel(1), halo(2)): issued here for the first tile, before the epilogue stores for the others
+    // Copy batches of a stage: 5 / 5 / 5 / 4 granules in load order (panel rows 0..8, then halo rows 0..9)
+    auto batch_j = [](int b, int k) { return 5 * b + k; };
+    auto batch_n = [](int b) { return b == 3 ? 4 : 5; };
     auto issue_first = [&](const Tile &t) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) stg[0][j] = ld(j, rot1(1), t.nt, rot1(2));
+        for (int k = 0; k < 5; ++k) stg[0][k] = ld(batch_j(0, k), rot1(1), t.nt, rot1(2));
     };
     issue_first(cur);
 
@@ -360,10 +363,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
             rd_frag(0, 0, 0); rd_frag(0, 0, 1); rd_frag(0, 1, 0); rd_frag(0, 1, 1);
             if (!FIRST) {  // (a tile's first stage: issued before the previous tile's epilogue)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) stg[0][j] = ld(j, cu, ntu, ch);
+                for (int k = 0; k < 5; ++k) stg[0][k] = ld(batch_j(0, k), cu, ntu, ch);
             }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) stg[1][j] = ld(5 + j, cu, ntu, ch);
+            for (int k = 0; k < 5; ++k) stg[1][k] = ld(batch_j(1, k), cu, ntu, ch);
             // column 0 of set 0 -> the first B operands
 #pragma unroll
             for (int i = 0; i < 6; ++i) v[i] = A_[i][0];
@@ -463,17 +466,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
                         if (gi >= 0 && gi < 4 && g >= 0 && it != 11) rd_frag(it == 5 ? 1 : pass, g, gi & 1);
                     }
                     // copies: four batches of 5 / 5 / 5 / 4 granules, two in flight: batches 0 and 1 are issued at the stage start, batch b is
-                    // written to LDS in slots 0..4 of iteration 3 b + 2 and batch b + 2 issued into its registers
-                    if ((it == 2 || it == 5 || it == 8 || it == 11) && k < 5) {
+                    // written to LDS in slots 0..4 of iteration 3 b + 2 and batch b + 2 issued into its registers.  (Measured and rejected,
+                    // profiles/r04/experiments.md: halo batches first with a 6-8 iteration lead; the reload one iteration after the write.)
+                    if ((it == 2 || it == 5 || it == 8 || it == 11) && k < batch_n(it / 3)) {
                         const int b = it / 3;
-                        if (5 * b + k < 19) {
-                            st(5 * b + k, kUw, kHw, stg[b & 1][k]);
-                            if (b < 2 && 5 * (b + 2) + k < 19) stg[b & 1][k] = ld(5 * (b + 2) + k, cu, ntu, ch);
-                        }
+                        st(batch_j(b, k), kUw, kHw, stg[b & 1][k]);
+                        if (b < 2 && k < batch_n(b + 2)) stg[b & 1][k] = ld(batch_j(b + 2, k), cu, ntu, ch);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #ifdef IDH_ABL_W4_TRACE
-                    if ((it == 5 || it == 6) && c == 2) W4T(130 + 12 * (it - 5) + k);  // slot stamps of two iterations of stage 2
+                    if ((it == 6 || it == 7) && c == 2) W4T(130 + 12 * (it - 6) + k);  // slot stamps of two iterations of stage 2
 #endif
                 }
                 if (it != 11) {

@@ -50,7 +50,7 @@ for rp in (0, 1):
 for w in range(0):
     print(f"  wave {w}, even stages: " + " ".join(f"{med(d[:, w, 0:ns:2, 1 + i]):.0f}" for i in range(12)) + "   odd stages: " + " ".join(f"{med(d[:, w, 1:ns:2, 1 + i]):.0f}" for i in range(12)))
 sl = t[:, :, 130:154]
-print("  stage 2, slots of iteration 5 then 6 (cycles since the previous stamp): " + " ".join(f"{med(sl[:, :, i] - (sl[:, :, i - 1] if i else st[:, :, 2, 6])):.0f}" for i in range(24)))
+print("  stage 2, slots of iteration 6 then 7 (cycles since the previous stamp): " + " ".join(f"{med(sl[:, :, i] - (sl[:, :, i - 1] if i else st[:, :, 2, 7])):.0f}" for i in range(24)))
 for par in (0, 1):
     print(f"  parity {par} stages: iterations " + " ".join(f"{med(d[:, :, par::2, 1 + i]):.0f}" for i in range(12)) + f"  barrier {med(d[:, :, par::2, 13]):.0f}")
 if nS <= 8:
