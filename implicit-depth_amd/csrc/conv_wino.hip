@@ -350,17 +350,25 @@ __device__ __forceinline__ void wino_tiles(const WinoArgs &wa, f32x4 *lds, const
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
+#ifdef IDH_ABL_WINO_SCALARXF
+            // scalar adds instead of v_pk_add_f32 (tools/micro/mfma_pk_valu.hip: a packed fp32 instruction costs ~3x a scalar one beside fp32 MFMAs)
+            auto vadd = [](vec a, vec b) { vec o; for (int e = 0; e < KS; ++e) { float t = a[e] + b[e]; asm("" : "+v"(t)); o[e] = t; } return o; };
+            auto vsub = [](vec a, vec b) { vec o; for (int e = 0; e < KS; ++e) { float t = a[e] - b[e]; asm("" : "+v"(t)); o[e] = t; } return o; };
+#else
+            auto vadd = [](vec a, vec b) { return a + b; };
+            auto vsub = [](vec a, vec b) { return a - b; };
+#endif
 #ifndef IDH_ABL_WINO_NOXFORM
             if (nu == 0) {  // B^T d: rows combined for this xi
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
-                    r[x] = xi == 0 ? d[0][x] - d[2][x] : xi == 1 ? d[1][x] + d[2][x] : xi == 2 ? d[2][x] - d[1][x] : d[1][x] - d[3][x];
+                    r[x] = xi == 0 ? vsub(d[0][x], d[2][x]) : xi == 1 ? vadd(d[1][x], d[2][x]) : xi == 2 ? vsub(d[2][x], d[1][x]) : vsub(d[1][x], d[3][x]);
             }
 #endif
 #ifdef IDH_ABL_WINO_NOXFORM
             const vec v = d[xi][nu];
 #else
-            const vec v = nu == 0 ? r[0] - r[2] : nu == 1 ? r[1] + r[2] : nu == 2 ? r[2] - r[1] : r[1] - r[3];
+            const vec v = nu == 0 ? vsub(r[0], r[2]) : nu == 1 ? vadd(r[1], r[2]) : nu == 2 ? vsub(r[2], r[1]) : vsub(r[1], r[3]);
 #endif
 #pragma unroll
             for (int k = 0; k < KS; ++k)
