@@ -568,6 +568,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
 #pragma unroll
                     for (int cb = 0; cb < NCO; ++cb) {
                         const f32x4 o = act4(y[cb][i] + b4[cb] + r[cb][i]);
+#ifdef IDH_ABL_W4_NOSTORE
+                        asm volatile("" ::"v"(o));
+                        continue;
+#endif
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 16 * cb + 4 * h) * 4 : kOob, 0, 0);
                     }
             }
@@ -580,6 +584,294 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
 #ifdef IDH_ABL_W4_TRACE
         ++tile_i;
 #endif
+    }
+}
+
+// =====================================================================================================================================
+// Second F(4x4) kernel: the input transform SHARED through LDS, two workgroups per CU (conv3x3_wino4s_k).
+//
+// conv3x3_wino4_k above needs 288 accumulators per wave = one wave per SIMD, and everything a second wave would cover — the epilogue
+// (20 % of a 64-channel tile), copy waits, barriers — is exposed.  Here a wave owns ONE 16-channel block (36 positions x 4 = 144
+// accumulator registers, all AGPRs; <= 112 VGPRs -> two waves per SIMD from two independent workgroups), and the 4 waves of a
+// workgroup = the 4 output-channel blocks of a 64-channel tile share the transformed input of 16 tiles (64 x 4 pixels) through LDS:
+// * per 8-channel stage every wave computes ONE 3x3 quadrant of the 6x6 transformed patch for all 16 tiles x 8 channels (lane (n, h):
+//   tile n, channels 2h, 2h+1; 36 conflict-free ds_read_b64 of the raw halo; the partial transforms need 6 + 6 operations per column /
+//   row instead of 12: 108 vector operations per wave and stage for 72 MFMAs = 1.5 per MFMA against 2 in conv3x3_wino4_k) and writes it
+//   to V[k-step][lane][position] (positions quadrant-major: a reader's 36 values are 9 conflict-free ds_read_b128);
+// * the MFMA B operands are read back from V by all four waves; the A operands (this wave's 16 output channels, 36 KiB per 64 channels
+//   and stage in all) come straight from global memory / L2 as fragments, one 1 KiB row per 4 MFMAs, packed in read order;
+// * the halo (6 x 66 texels x 32 B per stage) arrives by LDS-DMA two stages ahead of the MFMAs (the other workgroup covers the issue
+//   stall); LDS per workgroup: 2 halo + 2 V buffers = 62 KiB.
+// Stage S: transform(S + 1): halo(S + 1) -> V(S + 1); MFMA(S): V(S) x panel(S); DMA halo(S + 2); one barrier.
+constexpr int kSHaloBytes = 1024 * 16;            // 6 rows x 4 column phases x 17 quads x 32 B = 13056 B, rounded up to 16 DMA pieces
+constexpr int kSVBytes = 2 * 64 * 36 * 4;          // V of one stage: 2 k-steps x 64 lanes x 36 positions
+constexpr int kSH0 = 0, kSH1 = kSHaloBytes, kSV0 = 2 * kSHaloBytes, kSV1 = 2 * kSHaloBytes + kSVBytes;
+constexpr int kSLdsBytes = 2 * kSHaloBytes + 2 * kSVBytes;  // 69632
+constexpr int kSPanelFloats = 36 * 16 * 8;        // one stage's weights of one 16-channel block
+
+// position order of V / the packed weights / the accumulators: quadrant-major, p' = 9 (2 a + b) + 3 (xi % 3) + (nu % 3) with xi = 3 a + .., nu = 3 b + ..
+__host__ __device__ constexpr int w4s_xi(int pp) { return 3 * ((pp / 9) >> 1) + (pp % 9) / 3; }
+__host__ __device__ constexpr int w4s_nu(int pp) { return 3 * ((pp / 9) & 1) + (pp % 9) % 3; }
+
+// OIHW 3x3 -> U = G g G^T as A fragments: dst[stage c][co block cb (16)][ks 2][g 9][lane 64][e 4] = U[p' = 4g + e][co = 16 cb + (lane & 15)][ci = 8c + 2 (lane >> 4) + ks]
+__global__ __launch_bounds__(256) void pack_wino4s_weight_k(const float *__restrict__ w, float *__restrict__ dst, int Cout, int Cin, int nS, int nCB) {
+    const long long total = (long long)nS * nCB * kSPanelFloats;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += gridDim.x * 256ll) {
+        const int e = (int)(t & 3), lane = (int)((t >> 2) & 63);
+        long long r = t >> 8;
+        const int g = (int)(r % 9); r /= 9;
+        const int ks = (int)(r & 1); r >>= 1;
+        const int cb = (int)(r % nCB), c = (int)(r / nCB);
+        const int pp = 4 * g + e, co = 16 * cb + (lane & 15), ci = 8 * c + 2 * (lane >> 4) + ks;
+        double u = 0.0;
+        if (co < Cout && ci < Cin) {
+            const float *gw = w + ((size_t)co * Cin + ci) * 9;
+            const int xi = w4s_xi(pp), nu = w4s_nu(pp);
+            const double G[6][3] = {{1.0, 0.0, 0.0}, {-8.0 / 15, -4.0 / 15, -2.0 / 15}, {-8.0 / 15, 4.0 / 15, -2.0 / 15},
+                                    {1.0 / 30, 1.0 / 15, 2.0 / 15}, {1.0 / 30, -1.0 / 15, 2.0 / 15}, {0.0, 0.0, 1.0}};
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) u += G[xi][a] * (double)gw[a * 3 + b] * G[nu][b];
+        }
+        dst[t] = (float)u;
+    }
+}
+
+// half of the 1-D input transform: outputs 0..2 (HI = false) or 3..5 (HI = true) of B^T (d0..d5): 6 operations
+template <bool HI>
+__device__ __forceinline__ void bt3(float d0, float d1, float d2, float d3, float d4, float d5, float &o0, float &o1, float &o2) {
+    if constexpr (!HI) {
+        const float a = __builtin_fmaf(-4.f, d2, d4), b = __builtin_fmaf(-4.f, d1, d3);
+        o0 = __builtin_fmaf(-4.25f, d2, d0) + d4;
+        o1 = __builtin_fmaf(0.5f, b, a);
+        o2 = __builtin_fmaf(-0.5f, b, a);
+    } else {
+        const float c = __builtin_fmaf(-0.25f, d2, d4), e = __builtin_fmaf(-0.25f, d1, d3);
+        o0 = __builtin_fmaf(2.f, e, c);
+        o1 = __builtin_fmaf(-2.f, e, c);
+        o2 = __builtin_fmaf(-4.25f, d3, d1) + d5;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
+    __shared__ __attribute__((aligned(16))) char lds_raw[kSLdsBytes];
+    lds_char *lds = (lds_char *)lds_raw;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) volatile f32x2 lds_cf32x2;
+    typedef __attribute__((address_space(3))) float lds_float;
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    const ConvArgs &a = wa.c;
+    const ConvSrc &s = a.s[0];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, h = lane >> 4;
+    const int nS = s.cblocks * 2;  // stages of 8 input channels
+    const int NT = a.NT;           // 64-channel tiles
+    const int nCB = 4 * NT;        // 16-channel blocks of the packed weights
+
+    // persistent workgroup over an XCD-contiguous range of tiles (channel tile fastest)
+    const int T = wa.tiles;
+    int t_cur, t_end, t_stride;
+    {
+        const unsigned vblock = blockIdx.x, vgrid = gridDim.x;
+        if ((vgrid & 7) == 0) {
+            const int xcd = vblock & 7;
+            t_stride = vgrid >> 3;
+            t_cur = (int)((long long)T * xcd / 8) + (int)(vblock >> 3);
+            t_end = (int)((long long)T * (xcd + 1) / 8);
+        } else {
+            t_cur = vblock; t_end = T; t_stride = vgrid;
+        }
+    }
+    if (t_cur >= t_end) return;
+    struct Tile { int img, y0, x0, nt; };
+    auto decode = [&](int t) {
+        unsigned blk = (unsigned)t;
+        Tile r;
+        r.nt = blk % NT; blk /= NT;
+        const int tx = blk % wa.tiles_x; blk /= wa.tiles_x;
+        const int ty = blk % wa.tiles_y;
+        r.img = blk / wa.tiles_y;
+        r.y0 = ty * 4; r.x0 = tx * 64;
+        return r;
+    };
+
+    // ---- halo copies by LDS-DMA: texel (row r 0..5, column col 0..65) at index p = (4 r + (col & 3)) * 17 + (col >> 2), 32 B per texel, quad q in
+    // granule q ^ swz, swz = (col >> 5) & 1 (as in conv3x3_wino4_k).  16 pieces of 64 granules per stage: wave w copies pieces w, w + 4, w + 8, w + 12.
+    __amdgpu_buffer_rsrc_t rsH;
+    int voffH[4];
+    auto set_halo_cursor = [&](const Tile &t) {
+        rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)t.img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // (re-derived per tile: see conv_wino.hip)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int G = 64 * (wave + 4 * k) + lane_o;
+            const int p = G >> 1, half = G & 1;
+            const int cq = p % kSlots, rc = p / kSlots;
+            const int cm = rc & 3, r = rc >> 2;
+            const int col = 4 * cq + cm;
+            const int q = half ^ ((cq >> 3) & 1);
+            const int iy = t.y0 - 1 + r, ix = t.x0 - 1 + col;
+            const bool ok = (r < 6) & (col < 66) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            voffH[k] = ok ? (iy * s.W + ix) * s.cs * 4 + 16 * q : kOob;
+        }
+    };
+    auto dma_halo = [&](int k, int hbuf, int ch) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void *)(lds + __builtin_amdgcn_readfirstlane(hbuf + 1024 * (wave + 4 * k))), 16, voffH[k],
+                                                 __builtin_amdgcn_readfirstlane(32 * ch), 0, 0);
+    };
+
+    // ---- this lane's raw-patch read base: element (i, c) of tile n: texel p = (4 i + (c & 3)) * 17 + n + (c >> 2); channels 2h, 2h+1
+    int rbase[2];
+#pragma unroll
+    for (int dc = 0; dc < 2; ++dc) rbase[dc] = 32 * n + 16 * ((h >> 1) ^ (((n + dc) >> 3) & 1)) + 8 * (h & 1);
+    const int vbase = lane * 144;  // V[ks][lane][36]: 144 B per lane (36-dword stride: conflict-free ds_read_b128)
+    const int qa = wave >> 1, qb = wave & 1;  // this wave's quadrant of positions: xi = 3 qa .., nu = 3 qb ..
+
+    // transform of the stage whose halo is in `hbuf` -> this wave's quadrant of V in `vbuf`
+    auto transform = [&](auto hic, auto hjc, int hbuf, int vbuf) {
+        constexpr bool HI_I = decltype(hic)::value, HI_J = decltype(hjc)::value;
+        float W0[3][6], W1[3][6];  // vertical partial (3 of the 6 rows) of the two channels
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float d0[6], d1[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const f32x2 t = *(lds_cf32x2 *)(lds + hbuf + rbase[c >> 2] + 32 * ((4 * i + (c & 3)) * kSlots + (c >> 2)));
+                d0[i] = t[0]; d1[i] = t[1];
+            }
+            bt3<HI_I>(d0[0], d0[1], d0[2], d0[3], d0[4], d0[5], W0[0][c], W0[1][c], W0[2][c]);
+            bt3<HI_I>(d1[0], d1[1], d1[2], d1[3], d1[4], d1[5], W1[0][c], W1[1][c], W1[2][c]);
+        }
+        const int q = 2 * (HI_I ? 1 : 0) + (HI_J ? 1 : 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float o0[3], o1[3];
+            bt3<HI_J>(W0[r][0], W0[r][1], W0[r][2], W0[r][3], W0[r][4], W0[r][5], o0[0], o0[1], o0[2]);
+            bt3<HI_J>(W1[r][0], W1[r][1], W1[r][2], W1[r][3], W1[r][4], W1[r][5], o1[0], o1[1], o1[2]);
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                *(lds_float *)(lds + vbuf + vbase + 4 * (9 * q + 3 * r + cc)) = o0[cc];                  // k-step 0: channel 2h
+                *(lds_float *)(lds + vbuf + 64 * 144 + vbase + 4 * (9 * q + 3 * r + cc)) = o1[cc];      // k-step 1: channel 2h + 1
+            }
+        }
+    };
+    auto transform_q = [&](int hbuf, int vbuf) {  // (wave-uniform 4-way dispatch, once per stage)
+        if (qa == 0 && qb == 0) transform(std::false_type{}, std::false_type{}, hbuf, vbuf);
+        else if (qa == 0) transform(std::false_type{}, std::true_type{}, hbuf, vbuf);
+        else if (qb == 0) transform(std::true_type{}, std::false_type{}, hbuf, vbuf);
+        else transform(std::true_type{}, std::true_type{}, hbuf, vbuf);
+    };
+
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, nS * nCB * kSPanelFloats * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
+    const int voffA = lane * 16;
+
+    // ---- prologue: halo(0), halo(1) of the first tile; V(0)
+    Tile cur = decode(t_cur);
+    set_halo_cursor(cur);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_halo(k, kSH0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_halo(k, kSH1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    transform_q(kSH0, kSV0);
+    __syncthreads();
+
+    f32x4 acc[36];
+#pragma unroll 1
+    for (;;) {
+        const int t_next = t_cur + t_stride;
+        const bool has_next = t_next < t_end;
+        const Tile nxt = has_next ? decode(t_next) : cur;
+#pragma unroll
+        for (int p = 0; p < 36; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int cbw = 4 * cur.nt + wave;  // this wave's 16-channel block
+
+        auto stage = [&](auto parc, const int c) {
+            constexpr int PAR = decltype(parc)::value;
+            constexpr int kVr = PAR ? kSV1 : kSV0, kVw = PAR ? kSV0 : kSV1;
+            constexpr int kHr = PAR ? kSH0 : kSH1, kHw = PAR ? kSH1 : kSH0;
+            if (PAR == 0 && c + 2 == nS) set_halo_cursor(nxt);
+            const int ch = c + 2 >= nS ? c + 2 - nS : c + 2;
+            // halo(S + 2) -> the buffer halo(S) has left
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dma_halo(k, kHw, ch);
+            // MFMA(S): A fragments from global memory in a rolling window, B fragments from V(S)
+            const int aso = __builtin_amdgcn_readfirstlane((c * nCB + cbw) * (kSPanelFloats * 4));
+            f32x4 Af[18], Bf[18];
+            auto ldA = [&](int j) { Af[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffA, aso + 1024 * j, 0)); };
+            auto ldB = [&](int j) { Bf[j] = *(lds_cf32x4 *)(lds + kVr + (j / 9) * (64 * 144) + vbase + 16 * (j % 9)); };
+            constexpr int kAheadA = 6, kAheadB = 2;
+#pragma unroll
+            for (int j = 0; j < kAheadA; ++j) ldA(j);
+#pragma unroll
+            for (int j = 0; j < kAheadB; ++j) ldB(j);
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                if (j + kAheadA < 18) ldA(j + kAheadA);
+                if (j + kAheadB < 18) ldB(j + kAheadB);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * (j % 9) + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[j][e], Bf[j][e], acc[4 * (j % 9) + e], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // transform(S + 1): halo(S + 1) -> V(S + 1)
+            transform_q(kHr, kVw);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this stage's LDS-DMA pieces have landed before the barrier publishes them
+            __syncthreads();
+        };
+#pragma unroll 1
+        for (int c = 0; c < nS; c += 2) {
+            stage(std::integral_constant<int, 0>{}, c);
+            stage(std::integral_constant<int, 1>{}, c + 1);
+        }
+
+        // ---- epilogue: Y = A^T M A; lane = 4 consecutive channels of the 4x4 pixels of tile n (64 x 4 pixel strip: tile n = columns 4n..4n+3)
+        {
+            const int n0 = 16 * cbw;
+            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur.img * a.Ho * a.Wo * a.out_cs, 0, a.Ho * a.Wo * a.out_cs * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)cur.img * a.Ho * a.Wo * a.res_cs : a.out), 0,
+                                                                                  a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
+            const int oy0 = cur.y0, ox0 = cur.x0 + 4 * n;
+            const bool has_res = a.res != nullptr;
+            const float slope_eff = a.act == IDH_ACT_LRELU ? a.slope : 1.f;
+            const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 4 * h) * 4, 0, 0));
+            // M[xi][nu] = acc[p'(xi, nu)]
+            auto M = [&](int xi, int nu) -> f32x4 & { return acc[9 * (2 * (xi / 3) + nu / 3) + 3 * (xi % 3) + nu % 3]; };
+            f32x4 u[6][4];
+#pragma unroll
+            for (int xi = 0; xi < 6; ++xi) at6(M(xi, 0), M(xi, 1), M(xi, 2), M(xi, 3), M(xi, 4), M(xi, 5), u[xi][0], u[xi][1], u[xi][2], u[xi][3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 r[4], y[4];
+                int pix[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
+                    pix[i] = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
+                    r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pix[i] >= 0 ? (pix[i] * a.res_cs + n0 + 4 * h) * 4 : kOob, 0, 0));
+                }
+                at6(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], y[0], y[1], y[2], y[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 o = y[i] + b4 + r[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
+                }
+            }
+        }
+        if (!has_next) break;
+        t_cur = t_next;
+        cur = nxt;
     }
 }
 
@@ -614,6 +906,25 @@ bool wino4_supported(const ConvArgs &a) {
            (!a.res || (long long)a.Ho * a.Wo * a.res_cs * 4 < (1ll << 31)) && (long long)s.cblocks * a.Cout_pad * 36 * 16 * 4 < (1ll << 31);
 }
 
+bool wino4s_supported(const ConvArgs &a) {
+    return wino4_supported(a) && (a.Cout % 64) == 0 && (long long)a.s[0].cblocks * a.Cout_pad * 36 * 16 * 4 < (1ll << 31);
+}
+
+// shared-transform variant: 64 x 4 pixel x 64 channel tiles, two persistent workgroups per CU
+int launch_conv_wino4s(const ConvArgs &a, int N, hipStream_t st) {
+    if (!wino4s_supported(a)) return IDH_EUNSUPPORTED;
+    Wino4Args wa{a, (a.Wo + 63) / 64, (a.Ho + 3) / 4, 0};
+    wa.c.NT = a.Cout / 64;
+    const long long tiles = (long long)N * wa.tiles_x * wa.tiles_y * wa.c.NT;
+    if (tiles >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    wa.tiles = (int)tiles;
+    long long grid = 2ll * wino4_cus();
+    if (grid > wa.tiles) grid = wa.tiles >= 8 ? wa.tiles / 8 * 8 : wa.tiles;
+    hipLaunchKernelGGL(conv3x3_wino4s_k, dim3((unsigned)grid), dim3(256), 0, st, wa);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
+
 int launch_conv_wino4(const ConvArgs &a, int N, hipStream_t st) {
     if (!wino4_supported(a)) return IDH_EUNSUPPORTED;
     Wino4Args wa;
@@ -626,6 +937,22 @@ int launch_conv_wino4(const ConvArgs &a, int N, hipStream_t st) {
 }
 
 }  // namespace idh_conv
+
+extern "C" size_t idh_packed_wino4s_weight_floats(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)((Cin + 15) & ~15) * ((Cout + 15) & ~15) * 36;
+}
+
+extern "C" int idh_pack_conv_weight_wino4s(const float *w, float *dst, int Cout, int Cin, void *stream) {
+    if (!w || !dst || Cout <= 0 || Cin <= 0) return IDH_EINVAL;
+    const int nS = ((Cin + 15) / 16) * 2, nCB = (Cout + 15) / 16;
+    const long long total = (long long)nS * nCB * kSPanelFloats;
+    int grid = idh_cdiv(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_wino4s_weight_k, dim3(grid), dim3(256), 0, idh_stream(stream), w, dst, Cout, Cin, nS, nCB);
+    IDH_CHECK_LAUNCH();
+    return IDH_OK;
+}
 
 extern "C" size_t idh_packed_wino4_weight_floats(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;

@@ -139,6 +139,13 @@ int idh_pack_conv_weight_wino(const float *w_oihw, float *dst, int Cout, int Cin
 #define IDH_TILE_WINO4 13
 size_t idh_packed_wino4_weight_floats(int Cout, int Cin);
 int idh_pack_conv_weight_wino4(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);
+/* The same F(4x4,3x3) arithmetic with the input transform shared through LDS by the four 16-channel waves of a 64-channel tile
+ * (conv3x3_wino4s_k: 64 x 4 pixel x 64 channel tiles, two workgroups per CU): tile_m = IDH_TILE_WINO4S, src[0].w from
+ * idh_pack_conv_weight_wino4s ([Cin_pad/8][Cout_pad/16][k-step 2][position group 9][lane 64][4], positions quadrant-major); the shape
+ * family of IDH_TILE_WINO4 with Cout % 64 == 0. */
+#define IDH_TILE_WINO4S 14
+size_t idh_packed_wino4s_weight_floats(int Cout, int Cin);
+int idh_pack_conv_weight_wino4s(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);
 
 /* sizeof(idh_op) as compiled into the library (bindings assert their mirror matches). */
 size_t idh_sizeof_op(void);
