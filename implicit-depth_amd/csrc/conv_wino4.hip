@@ -658,7 +658,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef const __attribute__((address_space(3))) volatile f32x2 lds_cf32x2;
     typedef __attribute__((address_space(3))) float lds_float;
-    typedef __attribute__((address_space(3))) void lds_void;
 
     const ConvArgs &a = wa.c;
     const ConvSrc &s = a.s[0];
@@ -666,9 +665,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, h = lane >> 4;
-    const int nS = s.cblocks * 2;  // stages of 8 input channels
-    const int NT = a.NT;           // 64-channel tiles
-    const int nCB = 4 * NT;        // 16-channel blocks of the packed weights
+    const int ty = n >> 3, tx = n & 7;  // the 16 tiles of a workgroup: 2 rows x 8 columns of 4x4 pixels = 32 x 8 pixels
+    const int nS = s.cblocks * 2;       // stages of 8 input channels
+    const int NT = a.NT;                // 64-channel tiles
+    const int nCB = 4 * NT;             // 16-channel blocks of the packed weights
 
     // persistent workgroup over an XCD-contiguous range of tiles (channel tile fastest)
     const int T = wa.tiles;
@@ -690,43 +690,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
         unsigned blk = (unsigned)t;
         Tile r;
         r.nt = blk % NT; blk /= NT;
-        const int tx = blk % wa.tiles_x; blk /= wa.tiles_x;
-        const int ty = blk % wa.tiles_y;
+        const int txi = blk % wa.tiles_x; blk /= wa.tiles_x;
+        const int tyi = blk % wa.tiles_y;
         r.img = blk / wa.tiles_y;
-        r.y0 = ty * 4; r.x0 = tx * 64;
+        r.y0 = tyi * 8; r.x0 = txi * 32;
         return r;
     };
 
-    // ---- halo copies by LDS-DMA: texel (row r 0..5, column col 0..65) at index p = (4 r + (col & 3)) * 17 + (col >> 2), 32 B per texel, quad q in
-    // granule q ^ swz, swz = (col >> 5) & 1 (as in conv3x3_wino4_k).  16 pieces of 64 granules per stage: wave w copies pieces w, w + 4, w + 8, w + 12.
+    // ---- halo copies (global -> registers -> LDS: 4 granules per thread and stage).  Texel (row r 0..9, column col 0..33), r = 4 R + rm, col = 4 cq + cm,
+    // lives at index p = ((4 rm + cm) * 3 + R) * 9 + cq; 32 B per texel, channel quad q in granule q ^ (R & 1): the 16 tiles of a wave read, for a
+    // given patch element, a 2 x 8 block of (R, cq) whose 16-byte granules fall into 16 different bank groups (conflict-free ds_read_b64).
     __amdgpu_buffer_rsrc_t rsH;
     int voffH[4];
     auto set_halo_cursor = [&](const Tile &t) {
         rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)t.img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));  // (re-derived per tile: see conv_wino.hip)
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));  // (re-derived per tile rather than spilled: see conv_wino.hip)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int G = 64 * (wave + 4 * k) + lane_o;
+            const int G = tid_o + 256 * k;
             const int p = G >> 1, half = G & 1;
-            const int cq = p % kSlots, rc = p / kSlots;
-            const int cm = rc & 3, r = rc >> 2;
-            const int col = 4 * cq + cm;
-            const int q = half ^ ((cq >> 3) & 1);
+            const int cq = p % 9, pr = p / 9;
+            const int R = pr % 3, plane = pr / 3;
+            const int rm = plane >> 2, cm = plane & 3;
+            const int r = 4 * R + rm, col = 4 * cq + cm;
+            const int q = half ^ (R & 1);
             const int iy = t.y0 - 1 + r, ix = t.x0 - 1 + col;
-            const bool ok = (r < 6) & (col < 66) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
+            const bool ok = (plane < 16) & (r < 10) & (col < 34) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
             voffH[k] = ok ? (iy * s.W + ix) * s.cs * 4 + 16 * q : kOob;
         }
     };
-    auto dma_halo = [&](int k, int hbuf, int ch) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void *)(lds + __builtin_amdgcn_readfirstlane(hbuf + 1024 * (wave + 4 * k))), 16, voffH[k],
-                                                 __builtin_amdgcn_readfirstlane(32 * ch), 0, 0);
+    auto ld_halo = [&](int k, int ch) -> f32x4 {
+#ifdef IDH_ABL_W4S_NODMA
+        return (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, voffH[k], __builtin_amdgcn_readfirstlane(32 * ch), 0));
     };
 
-    // ---- this lane's raw-patch read base: element (i, c) of tile n: texel p = (4 i + (c & 3)) * 17 + n + (c >> 2); channels 2h, 2h+1
-    int rbase[2];
+    // ---- this lane's raw-patch read bases: element (i, c) of tile (ty, tx): texel p = ((4 (i & 3) + (c & 3)) * 3 + ty + (i >> 2)) * 9 + tx + (c >> 2); channels 2h, 2h+1
+    int rbase[2];  // [i >> 2]
 #pragma unroll
-    for (int dc = 0; dc < 2; ++dc) rbase[dc] = 32 * n + 16 * ((h >> 1) ^ (((n + dc) >> 3) & 1)) + 8 * (h & 1);
+    for (int di = 0; di < 2; ++di) rbase[di] = 32 * (9 * ty + tx) + 16 * ((h >> 1) ^ ((ty + di) & 1)) + 8 * (h & 1);
     const int vbase = lane * 144;  // V[ks][lane][36]: 144 B per lane (36-dword stride: conflict-free ds_read_b128)
     const int qa = wave >> 1, qb = wave & 1;  // this wave's quadrant of positions: xi = 3 qa .., nu = 3 qb ..
 
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
             float d0[6], d1[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const f32x2 t = *(lds_cf32x2 *)(lds + hbuf + rbase[c >> 2] + 32 * ((4 * i + (c & 3)) * kSlots + (c >> 2)));
+                const f32x2 t = *(lds_cf32x2 *)(lds + hbuf + rbase[i >> 2] + 32 * (((4 * (i & 3) + (c & 3)) * 3 + (i >> 2)) * 9 + (c >> 2)));
                 d0[i] = t[0]; d1[i] = t[1];
             }
             bt3<HI_I>(d0[0], d0[1], d0[2], d0[3], d0[4], d0[5], W0[0][c], W0[1][c], W0[2][c]);
@@ -759,6 +763,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
         }
     };
     auto transform_q = [&](int hbuf, int vbuf) {  // (wave-uniform 4-way dispatch, once per stage)
+#ifdef IDH_ABL_W4S_NOXFORM
+        return;
+#endif
         if (qa == 0 && qb == 0) transform(std::false_type{}, std::false_type{}, hbuf, vbuf);
         else if (qa == 0) transform(std::false_type{}, std::true_type{}, hbuf, vbuf);
         else if (qb == 0) transform(std::true_type{}, std::false_type{}, hbuf, vbuf);
@@ -768,15 +775,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, nS * nCB * kSPanelFloats * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
     const int voffA = lane * 16;
+    // A fragments: a ring of kRing rows that runs across stage and tile boundaries: row j of a stage is consumed from Af[j % kRing] and the
+    // register reloaded at once with the row kRing further on (24 MFMAs = ~0.8k cycles of lookahead)
+    constexpr int kRing = 6;  // (divides 18)
+    f32x4 Af[kRing];
+    auto ldA = [&](int slot, int so) {
+#ifdef IDH_ABL_W4S_NOA
+        Af[slot] = (f32x4){1.f, 2.f, 3.f, 4.f};
+        return;
+#endif
+        Af[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffA, so, 0));
+    };
 
-    // ---- prologue: halo(0), halo(1) of the first tile; V(0)
+    // ---- prologue: halo(0), halo(1) of the first tile; V(0); the first 9 A rows
     Tile cur = decode(t_cur);
     set_halo_cursor(cur);
+    {
+        f32x4 t0[4], t1[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dma_halo(k, kSH0, 0);
+        for (int k = 0; k < 4; ++k) { t0[k] = ld_halo(k, 0); t1[k] = ld_halo(k, 1); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dma_halo(k, kSH1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int k = 0; k < 4; ++k) {
+            *(lds_f32x4 *)(lds + kSH0 + 4096 * k + tid * 16) = t0[k];
+            *(lds_f32x4 *)(lds + kSH1 + 4096 * k + tid * 16) = t1[k];
+        }
+    }
+    {
+        const int so0 = (4 * cur.nt + wave) * (kSPanelFloats * 4);
+#pragma unroll
+        for (int j = 0; j < kRing; ++j) ldA(j, __builtin_amdgcn_readfirstlane(so0 + 1024 * j));
+    }
     __syncthreads();
     transform_q(kSH0, kSV0);
     __syncthreads();
@@ -797,30 +825,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
             constexpr int kHr = PAR ? kSH0 : kSH1, kHw = PAR ? kSH1 : kSH0;
             if (PAR == 0 && c + 2 == nS) set_halo_cursor(nxt);
             const int ch = c + 2 >= nS ? c + 2 - nS : c + 2;
-            // halo(S + 2) -> the buffer halo(S) has left
+            // halo(S + 2): loads now, LDS writes after the MFMAs (the buffer halo(S) has left)
+            f32x4 stg[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dma_halo(k, kHw, ch);
-            // MFMA(S): A fragments from global memory in a rolling window, B fragments from V(S)
+            for (int k = 0; k < 4; ++k) stg[k] = ld_halo(k, ch);
+            // MFMA(S): A rows from the ring, B fragments from V(S)
             const int aso = __builtin_amdgcn_readfirstlane((c * nCB + cbw) * (kSPanelFloats * 4));
-            f32x4 Af[18], Bf[18];
-            auto ldA = [&](int j) { Af[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffA, aso + 1024 * j, 0)); };
+            const bool last = c + 1 >= nS;
+            const int aso_n = __builtin_amdgcn_readfirstlane(last ? (4 * nxt.nt + wave) * (kSPanelFloats * 4) : aso + nCB * (kSPanelFloats * 4));  // next stage (next tile: its stage 0)
+            f32x4 Bf[18];
+#ifdef IDH_ABL_W4S_NOB
+            auto ldB = [&](int j) { Bf[j] = (f32x4){1.f, 2.f, 3.f, 4.f}; };
+#else
             auto ldB = [&](int j) { Bf[j] = *(lds_cf32x4 *)(lds + kVr + (j / 9) * (64 * 144) + vbase + 16 * (j % 9)); };
-            constexpr int kAheadA = 6, kAheadB = 2;
-#pragma unroll
-            for (int j = 0; j < kAheadA; ++j) ldA(j);
+#endif
+            constexpr int kAheadB = 2;
 #pragma unroll
             for (int j = 0; j < kAheadB; ++j) ldB(j);
 #pragma unroll
             for (int j = 0; j < 18; ++j) {
-                if (j + kAheadA < 18) ldA(j + kAheadA);
                 if (j + kAheadB < 18) ldB(j + kAheadB);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * (j % 9) + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[j][e], Bf[j][e], acc[4 * (j % 9) + e], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[4 * (j % 9) + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[j % kRing][e], Bf[j][e], acc[4 * (j % 9) + e], 0, 0, 0);
+                ldA(j % kRing, j + kRing < 18 ? aso + 1024 * (j + kRing) : aso_n + 1024 * (j + kRing - 18));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // transform(S + 1): halo(S + 1) -> V(S + 1)
+            // halo(S + 2) into the buffer halo(S) left one barrier ago; then transform(S + 1): halo(S + 1) -> V(S + 1)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(lds_f32x4 *)(lds + kHw + 4096 * k + tid * 16) = stg[k];
             transform_q(kHr, kVw);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this stage's LDS-DMA pieces have landed before the barrier publishes them
             __syncthreads();
         };
 #pragma unroll 1
@@ -829,13 +862,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
             stage(std::integral_constant<int, 1>{}, c + 1);
         }
 
-        // ---- epilogue: Y = A^T M A; lane = 4 consecutive channels of the 4x4 pixels of tile n (64 x 4 pixel strip: tile n = columns 4n..4n+3)
+        // ---- epilogue: Y = A^T M A; lane = 4 consecutive channels of the 4x4 pixels of tile (ty, tx)
+#ifdef IDH_ABL_W4S_NOEPI
+#pragma unroll
+        for (int p = 0; p < 36; ++p) asm volatile("" ::"v"(acc[p]));
+#else
         {
             const int n0 = 16 * cbw;
             const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur.img * a.Ho * a.Wo * a.out_cs, 0, a.Ho * a.Wo * a.out_cs * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)cur.img * a.Ho * a.Wo * a.res_cs : a.out), 0,
                                                                                   a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
-            const int oy0 = cur.y0, ox0 = cur.x0 + 4 * n;
+            const int oy0 = cur.y0 + 4 * ty, ox0 = cur.x0 + 4 * tx;
             const bool has_res = a.res != nullptr;
             const float slope_eff = a.act == IDH_ACT_LRELU ? a.slope : 1.f;
             const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 4 * h) * 4, 0, 0));
@@ -869,6 +906,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
                 }
             }
         }
+#endif
         if (!has_next) break;
         t_cur = t_next;
         cur = nxt;
@@ -910,10 +948,10 @@ bool wino4s_supported(const ConvArgs &a) {
     return wino4_supported(a) && (a.Cout % 64) == 0 && (long long)a.s[0].cblocks * a.Cout_pad * 36 * 16 * 4 < (1ll << 31);
 }
 
-// shared-transform variant: 64 x 4 pixel x 64 channel tiles, two persistent workgroups per CU
+// shared-transform variant: 32 x 8 pixel x 64 channel tiles, two persistent workgroups per CU
 int launch_conv_wino4s(const ConvArgs &a, int N, hipStream_t st) {
     if (!wino4s_supported(a)) return IDH_EUNSUPPORTED;
-    Wino4Args wa{a, (a.Wo + 63) / 64, (a.Ho + 3) / 4, 0};
+    Wino4Args wa{a, (a.Wo + 31) / 32, (a.Ho + 7) / 8, 0};
     wa.c.NT = a.Cout / 64;
     const long long tiles = (long long)N * wa.tiles_x * wa.tiles_y * wa.c.NT;
     if (tiles >= (1ll << 31)) return IDH_EUNSUPPORTED;
