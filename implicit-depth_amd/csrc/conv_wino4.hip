@@ -600,13 +600,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_k(const Wino4Args wa) {
 //   to V[k-step][lane][position] (positions quadrant-major: a reader's 36 values are 9 conflict-free ds_read_b128);
 // * the MFMA B operands are read back from V by all four waves; the A operands (this wave's 16 output channels, 36 KiB per 64 channels
 //   and stage in all) come straight from global memory / L2 as fragments, one 1 KiB row per 4 MFMAs, packed in read order;
-// * the halo (6 x 66 texels x 32 B per stage) arrives by LDS-DMA two stages ahead of the MFMAs (the other workgroup covers the issue
-//   stall); LDS per workgroup: 2 halo + 2 V buffers = 62 KiB.
-// Stage S: transform(S + 1): halo(S + 1) -> V(S + 1); MFMA(S): V(S) x panel(S); DMA halo(S + 2); one barrier.
-constexpr int kSHaloBytes = 1024 * 16;            // 6 rows x 4 column phases x 17 quads x 32 B = 13056 B, rounded up to 16 DMA pieces
+// * the halo (10 x 34 texels) is copied through registers in PAIRS of stages (64 contiguous bytes per texel and load: 16 cache lines per wave
+//   instruction instead of 32), all of it during the even stage, into three rotating 32-B-per-texel planes: halo(S) lives in plane S mod 3;
+//   LDS per workgroup: 3 halo planes + 2 V buffers = 76.9 KiB (two workgroups per CU).
+// Even stage S: loads halo(S + 2), halo(S + 3); MFMA(S): V(S) x panel(S); transform(S + 1): halo(S + 1) -> V(S + 1); one barrier.
+constexpr int kSPlane = 432 * 32 + 128;            // 16 (row, column) phases x 3 x 9 texel slots x 32 B (+ 128: consecutive planes land on the other half of the banks)
 constexpr int kSVBytes = 2 * 64 * 36 * 4;          // V of one stage: 2 k-steps x 64 lanes x 36 positions
-constexpr int kSH0 = 0, kSH1 = kSHaloBytes, kSV0 = 2 * kSHaloBytes, kSV1 = 2 * kSHaloBytes + kSVBytes;
-constexpr int kSLdsBytes = 2 * kSHaloBytes + 2 * kSVBytes;  // 69632
+constexpr int kSV0 = 3 * kSPlane, kSV1 = 3 * kSPlane + kSVBytes;
+constexpr int kSLdsBytes = 3 * kSPlane + 2 * kSVBytes;  // 78720
 constexpr int kSPanelFloats = 36 * 16 * 8;        // one stage's weights of one 16-channel block
 
 // position order of V / the packed weights / the accumulators: quadrant-major, p' = 9 (2 a + b) + 3 (xi % 3) + (nu % 3) with xi = 3 a + .., nu = 3 b + ..
@@ -636,19 +637,45 @@ __global__ __launch_bounds__(256) void pack_wino4s_weight_k(const float *__restr
     }
 }
 
-// half of the 1-D input transform: outputs 0..2 (HI = false) or 3..5 (HI = true) of B^T (d0..d5): 6 operations
+// half of the 1-D input transform B^T: outputs 0..2 (HI = false; they do not involve d5) or 3..5 (HI = true; no d0) of the 5 inputs
+// x0..x4 = d0..d4 (d1..d5): 6 operations
 template <bool HI>
-__device__ __forceinline__ void bt3(float d0, float d1, float d2, float d3, float d4, float d5, float &o0, float &o1, float &o2) {
+__device__ __forceinline__ void bt3(float x0, float x1, float x2, float x3, float x4, float &o0, float &o1, float &o2) {
     if constexpr (!HI) {
-        const float a = __builtin_fmaf(-4.f, d2, d4), b = __builtin_fmaf(-4.f, d1, d3);
-        o0 = __builtin_fmaf(-4.25f, d2, d0) + d4;
+        const float a = __builtin_fmaf(-4.f, x2, x4), b = __builtin_fmaf(-4.f, x1, x3);
+        o0 = __builtin_fmaf(-4.25f, x2, x0) + x4;
         o1 = __builtin_fmaf(0.5f, b, a);
         o2 = __builtin_fmaf(-0.5f, b, a);
     } else {
-        const float c = __builtin_fmaf(-0.25f, d2, d4), e = __builtin_fmaf(-0.25f, d1, d3);
+        const float c = __builtin_fmaf(-0.25f, x1, x3), e = __builtin_fmaf(-0.25f, x0, x2);
         o0 = __builtin_fmaf(2.f, e, c);
         o1 = __builtin_fmaf(-2.f, e, c);
-        o2 = __builtin_fmaf(-4.25f, d3, d1) + d5;
+        o2 = __builtin_fmaf(-4.25f, x2, x0) + x4;
+    }
+}
+// the same half transform fed ONE input at a time (k = 0..4), state (s0, s1, s2): the column pass of the streamed transform
+template <bool HI, int K>
+__device__ __forceinline__ void bt3_step(float w, float &s0, float &s1, float &s2) {
+    if constexpr (!HI) {
+        if constexpr (K == 0) s0 = w;
+        if constexpr (K == 1) s1 = w;
+        if constexpr (K == 2) { s0 = __builtin_fmaf(-4.25f, w, s0); s2 = w; }
+        if constexpr (K == 3) s1 = __builtin_fmaf(-4.f, s1, w);                                // b = d3 - 4 d1
+        if constexpr (K == 4) { s0 = s0 + w; s2 = __builtin_fmaf(-4.f, s2, w); }               // a = d4 - 4 d2
+    } else {
+        if constexpr (K == 0) { s0 = w; s2 = w; }
+        if constexpr (K == 1) s1 = w;
+        if constexpr (K == 2) { s2 = __builtin_fmaf(-4.25f, w, s2); s0 = __builtin_fmaf(-0.25f, s0, w); }  // e = d3 - d1 / 4
+        if constexpr (K == 3) s1 = __builtin_fmaf(-0.25f, s1, w);                              // c = d4 - d2 / 4
+        if constexpr (K == 4) s2 = s2 + w;
+    }
+}
+template <bool HI>
+__device__ __forceinline__ void bt3_finish(float s0, float s1, float s2, float &o0, float &o1, float &o2) {
+    if constexpr (!HI) {
+        o0 = s0; o1 = __builtin_fmaf(0.5f, s1, s2); o2 = __builtin_fmaf(-0.5f, s1, s2);
+    } else {
+        o0 = __builtin_fmaf(2.f, s0, s1); o1 = __builtin_fmaf(-2.f, s0, s1); o2 = s2;
     }
 }
 
@@ -697,34 +724,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
         return r;
     };
 
-    // ---- halo copies (global -> registers -> LDS: 4 granules per thread and stage).  Texel (row r 0..9, column col 0..33), r = 4 R + rm, col = 4 cq + cm,
-    // lives at index p = ((4 rm + cm) * 3 + R) * 9 + cq; 32 B per texel, channel quad q in granule q ^ (R & 1): the 16 tiles of a wave read, for a
-    // given patch element, a 2 x 8 block of (R, cq) whose 16-byte granules fall into 16 different bank groups (conflict-free ds_read_b64).
+    // ---- halo copies (global -> registers -> LDS), a pair of stages (16 channels = 64 B per texel) at a time.  Texel (row r 0..9, column col 0..33),
+    // r = 4 R + rm, col = 4 cq + cm, has LDS index p = ((4 rm + cm) * 3 + R) * 9 + cq.  Thread t copies granule gr = t & 3 (4 lanes per texel: 16 cache
+    // lines per wave load) of texel (row 2 k + (t >> 7), column (t >> 2) & 31) in copy k = 0..4 (the address advances by two image rows per copy), and
+    // threads 0..79 copy columns 32, 33 of the ten rows in copy 5.  Rows above / below the image fall outside the buffer (zeros); columns outside it
+    // are masked per lane.  Granules 0, 1 (the even stage's 8 channels) go to one plane, 2, 3 to the next; within a plane a texel has 32 B and its
+    // channel quad q sits in granule q ^ (R & 1): the 16 tiles of a wave read, for a given patch element, a 2 x 8 block of (R, cq) whose 16-byte
+    // granules fall into 16 different bank groups (conflict-free ds_read_b64).
     __amdgpu_buffer_rsrc_t rsH;
-    int voffH[4];
+    int voffH0, voffH1;
+    const int row_pair = s.W * s.cs * 8;  // bytes of two image rows
     auto set_halo_cursor = [&](const Tile &t) {
         rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)t.img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));  // (re-derived per tile rather than spilled: see conv_wino.hip)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int G = tid_o + 256 * k;
-            const int p = G >> 1, half = G & 1;
-            const int cq = p % 9, pr = p / 9;
-            const int R = pr % 3, plane = pr / 3;
-            const int rm = plane >> 2, cm = plane & 3;
-            const int r = 4 * R + rm, col = 4 * cq + cm;
-            const int q = half ^ (R & 1);
-            const int iy = t.y0 - 1 + r, ix = t.x0 - 1 + col;
-            const bool ok = (plane < 16) & (r < 10) & (col < 34) & ((unsigned)iy < (unsigned)s.H) & ((unsigned)ix < (unsigned)s.W);
-            voffH[k] = ok ? (iy * s.W + ix) * s.cs * 4 + 16 * q : kOob;
+        const int gr = tid_o & 3;
+        {
+            const int iy = t.y0 - 1 + (tid_o >> 7), ix = t.x0 - 1 + ((tid_o >> 2) & 31);
+            voffH0 = (unsigned)ix < (unsigned)s.W ? (iy * s.W + ix) * s.cs * 4 + 16 * gr : kOob;
+        }
+        {
+            const int e = tid_o >> 2;
+            const int iy = t.y0 - 1 + (e >> 1), ix = t.x0 + 31 + (e & 1);
+            voffH1 = (e < 20) & (ix < s.W) & ((unsigned)iy < (unsigned)s.H) ? (iy * s.W + ix) * s.cs * 4 + 16 * gr : kOob;
         }
     };
-    auto ld_halo = [&](int k, int ch) -> f32x4 {
+    auto ld_halo = [&](int k, int ch) -> f32x4 {  // ch: the pair's first stage
 #ifdef IDH_ABL_W4S_NODMA
         return (f32x4){0.f, 0.f, 0.f, 0.f};
 #endif
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, voffH[k], __builtin_amdgcn_readfirstlane(32 * ch), 0));
+        if (k < 5)  // (the row advance goes into the VECTOR offset: the scalar offset takes no part in the buffer range check)
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, (int)((unsigned)voffH0 + (unsigned)(k * row_pair)), __builtin_amdgcn_readfirstlane(32 * ch), 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, voffH1, __builtin_amdgcn_readfirstlane(32 * ch), 0));
+    };
+    // LDS address of copy k of this thread in the plane pair (offA: granules 0, 1; offB: granules 2, 3)
+    int wdst0, wdst1;
+    {
+        const int wq = tid & 1, rr = tid >> 7, col = (tid >> 2) & 31;
+        wdst0 = 32 * (108 * rr + 27 * (col & 3) + (col >> 2)) + 16 * wq;
+        const int e = tid >> 2, r = e >> 1;
+        wdst1 = 32 * (((4 * (r & 3) + (e & 1)) * 3 + (r >> 2)) * 9 + 8) + 16 * (wq ^ ((r >> 2) & 1));
+    }
+    const bool wselB = (tid >> 1) & 1;
+    auto st_halo = [&](int k, f32x4 v, int offA, int offB) {
+        const int off = wselB ? offB : offA;
+        if (k < 5) *(lds_f32x4 *)(lds + ((off + wdst0) ^ (((k >> 1) & 1) << 4)) + 32 * (216 * (k & 1) + 9 * (k >> 1))) = v;  // row 2k + rr: rm = 2 (k & 1) + rr, R = k >> 1
+        else if (tid < 80) *(lds_f32x4 *)(lds + off + wdst1) = v;
     };
 
     // ---- this lane's raw-patch read bases: element (i, c) of tile (ty, tx): texel p = ((4 (i & 3) + (c & 3)) * 3 + ty + (i >> 2)) * 9 + tx + (c >> 2); channels 2h, 2h+1
@@ -734,27 +779,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
     const int vbase = lane * 144;  // V[ks][lane][36]: 144 B per lane (36-dword stride: conflict-free ds_read_b128)
     const int qa = wave >> 1, qb = wave & 1;  // this wave's quadrant of positions: xi = 3 qa .., nu = 3 qb ..
 
-    // transform of the stage whose halo is in `hbuf` -> this wave's quadrant of V in `vbuf`
-    auto transform = [&](auto hic, auto hjc, int hbuf, int vbuf) {
+    // transform of the stage whose halo is in the plane at `hoff` -> this wave's quadrant of V in `vbuf`.  The quadrant needs a 5 x 5 part of the
+    // 6 x 6 patch only; it is streamed column by column (the next column's 5 reads in flight under the row pass of the current one).
+    auto transform = [&](auto hic, auto hjc, int hoff, int vbuf) {
         constexpr bool HI_I = decltype(hic)::value, HI_J = decltype(hjc)::value;
-        float W0[3][6], W1[3][6];  // vertical partial (3 of the 6 rows) of the two channels
+        constexpr int I0 = HI_I ? 1 : 0, J0 = HI_J ? 1 : 0;
+        const int rb[2] = {rbase[0] + hoff, rbase[1] + hoff};
+        auto rd = [&](int i, int c) -> f32x2 { return *(lds_cf32x2 *)(lds + rb[i >> 2] + 32 * (((4 * (i & 3) + (c & 3)) * 3 + (i >> 2)) * 9 + (c >> 2))); };
+        f32x2 d[2][5];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            float d0[6], d1[6];
+        for (int k = 0; k < 5; ++k) d[0][k] = rd(I0 + k, J0);
+        float S[3][2][3];  // [row of the quadrant][channel][state]
+        auto column = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            if (K + 1 < 5) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const f32x2 t = *(lds_cf32x2 *)(lds + hbuf + rbase[i >> 2] + 32 * (((4 * (i & 3) + (c & 3)) * 3 + (i >> 2)) * 9 + (c >> 2)));
-                d0[i] = t[0]; d1[i] = t[1];
+                for (int k = 0; k < 5; ++k) d[(K + 1) & 1][k] = rd(I0 + k, J0 + K + 1);
             }
-            bt3<HI_I>(d0[0], d0[1], d0[2], d0[3], d0[4], d0[5], W0[0][c], W0[1][c], W0[2][c]);
-            bt3<HI_I>(d1[0], d1[1], d1[2], d1[3], d1[4], d1[5], W1[0][c], W1[1][c], W1[2][c]);
-        }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                float w[3];
+                bt3<HI_I>(d[K & 1][0][ch], d[K & 1][1][ch], d[K & 1][2][ch], d[K & 1][3][ch], d[K & 1][4][ch], w[0], w[1], w[2]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) bt3_step<HI_J, K>(w[r], S[r][ch][0], S[r][ch][1], S[r][ch][2]);
+            }
+        };
+        column(std::integral_constant<int, 0>{});
+        column(std::integral_constant<int, 1>{});
+        column(std::integral_constant<int, 2>{});
+        column(std::integral_constant<int, 3>{});
+        column(std::integral_constant<int, 4>{});
         const int q = 2 * (HI_I ? 1 : 0) + (HI_J ? 1 : 0);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             float o0[3], o1[3];
-            bt3<HI_J>(W0[r][0], W0[r][1], W0[r][2], W0[r][3], W0[r][4], W0[r][5], o0[0], o0[1], o0[2]);
-            bt3<HI_J>(W1[r][0], W1[r][1], W1[r][2], W1[r][3], W1[r][4], W1[r][5], o1[0], o1[1], o1[2]);
+            bt3_finish<HI_J>(S[r][0][0], S[r][0][1], S[r][0][2], o0[0], o0[1], o0[2]);
+            bt3_finish<HI_J>(S[r][1][0], S[r][1][1], S[r][1][2], o1[0], o1[1], o1[2]);
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) {
                 *(lds_float *)(lds + vbuf + vbase + 4 * (9 * q + 3 * r + cc)) = o0[cc];                  // k-step 0: channel 2h
@@ -762,14 +822,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
             }
         }
     };
-    auto transform_q = [&](int hbuf, int vbuf) {  // (wave-uniform 4-way dispatch, once per stage)
+    auto transform_q = [&](int hoff, int vbuf) {  // (wave-uniform 4-way dispatch, once per stage)
 #ifdef IDH_ABL_W4S_NOXFORM
         return;
 #endif
-        if (qa == 0 && qb == 0) transform(std::false_type{}, std::false_type{}, hbuf, vbuf);
-        else if (qa == 0) transform(std::false_type{}, std::true_type{}, hbuf, vbuf);
-        else if (qb == 0) transform(std::true_type{}, std::false_type{}, hbuf, vbuf);
-        else transform(std::true_type{}, std::true_type{}, hbuf, vbuf);
+        if (qa == 0 && qb == 0) transform(std::false_type{}, std::false_type{}, hoff, vbuf);
+        else if (qa == 0) transform(std::false_type{}, std::true_type{}, hoff, vbuf);
+        else if (qb == 0) transform(std::true_type{}, std::false_type{}, hoff, vbuf);
+        else transform(std::true_type{}, std::true_type{}, hoff, vbuf);
     };
 
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, nS * nCB * kSPanelFloats * 4, 0x00020000);
@@ -787,18 +847,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
         Af[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffA, so, 0));
     };
 
-    // ---- prologue: halo(0), halo(1) of the first tile; V(0); the first 9 A rows
+    // ---- prologue: halo(0), halo(1) of the first tile into planes 0, 1; V(0); the first kRing A rows
     Tile cur = decode(t_cur);
     set_halo_cursor(cur);
-    {
-        f32x4 t0[4], t1[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { t0[k] = ld_halo(k, 0); t1[k] = ld_halo(k, 1); }
+    for (int b = 0; b < 2; ++b) {
+        f32x4 t0[3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            *(lds_f32x4 *)(lds + kSH0 + 4096 * k + tid * 16) = t0[k];
-            *(lds_f32x4 *)(lds + kSH1 + 4096 * k + tid * 16) = t1[k];
-        }
+        for (int k = 0; k < 3; ++k) t0[k] = ld_halo(3 * b + k, 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st_halo(3 * b + k, t0[k], 0, kSPlane);
     }
     {
         const int so0 = (4 * cur.nt + wave) * (kSPanelFloats * 4);
@@ -806,12 +864,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
         for (int j = 0; j < kRing; ++j) ldA(j, __builtin_amdgcn_readfirstlane(so0 + 1024 * j));
     }
     __syncthreads();
-    transform_q(kSH0, kSV0);
+    transform_q(0, kSV0);
     __syncthreads();
+    int pl0 = 0, pl1 = kSPlane, pl2 = 2 * kSPlane;  // LDS offsets of the planes of halo(S), halo(S + 1), halo(S + 2) (rotated every stage)
 
+    // Developer build (-DIDH_ABL_W4S_TRACE, tools/abl_wino4.sh traces): every wave logs s_memtime along its SECOND tile into ConvArgs.ws (80 x 8 bytes
+    // per wave: [0] tile start, [1 + 8 c + k] stage c < 8: k = 0 entry, 1 halo loads issued, 2/3/4 MFMA rows 0-5 / 6-11 / 12-17 issued, 5 halo written,
+    // 6 transformed, 7 barrier passed; [70] epilogue start, [71] stored)
+#ifdef IDH_ABL_W4S_TRACE
+    unsigned long long *trace = reinterpret_cast<unsigned long long *>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 80;
+    int tile_i = 0;
+#define W4ST(idx) do { if (tile_i == 1 && lane == 0) trace[(idx)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W4ST(idx) do { } while (0)
+#endif
     f32x4 acc[36];
 #pragma unroll 1
     for (;;) {
+        W4ST(0);
         const int t_next = t_cur + t_stride;
         const bool has_next = t_next < t_end;
         const Tile nxt = has_next ? decode(t_next) : cur;
@@ -822,13 +892,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
         auto stage = [&](auto parc, const int c) {
             constexpr int PAR = decltype(parc)::value;
             constexpr int kVr = PAR ? kSV1 : kSV0, kVw = PAR ? kSV0 : kSV1;
-            constexpr int kHr = PAR ? kSH0 : kSH1, kHw = PAR ? kSH1 : kSH0;
-            if (PAR == 0 && c + 2 == nS) set_halo_cursor(nxt);
-            const int ch = c + 2 >= nS ? c + 2 - nS : c + 2;
-            // halo(S + 2): loads now, LDS writes after the MFMAs (the buffer halo(S) has left)
-            f32x4 stg[4];
+            const int tr0 = c < 8 ? 1 + 8 * c : 72;
+            W4ST(tr0);
+            // even stage: halo(S + 2) -> plane pl2, halo(S + 3) -> plane pl0 (halo(S) left it one barrier ago); two batches of 3 copies
+            f32x4 stg[3];
+            int ch = 0;
+            if (PAR == 0) {
+                if (c + 2 == nS) set_halo_cursor(nxt);
+                ch = c + 2 >= nS ? c + 2 - nS : c + 2;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) stg[k] = ld_halo(k, ch);
+                for (int k = 0; k < 3; ++k) stg[k] = ld_halo(k, ch);
+            }
+            W4ST(tr0 + 1);
             // MFMA(S): A rows from the ring, B fragments from V(S)
             const int aso = __builtin_amdgcn_readfirstlane((c * nCB + cbw) * (kSPanelFloats * 4));
             const bool last = c + 1 >= nS;
@@ -848,13 +923,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[4 * (j % 9) + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[j % kRing][e], Bf[j][e], acc[4 * (j % 9) + e], 0, 0, 0);
                 ldA(j % kRing, j + kRing < 18 ? aso + 1024 * (j + kRing) : aso_n + 1024 * (j + kRing - 18));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // halo(S + 2) into the buffer halo(S) left one barrier ago; then transform(S + 1): halo(S + 1) -> V(S + 1)
+                if (PAR == 0 && j == 8) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *(lds_f32x4 *)(lds + kHw + 4096 * k + tid * 16) = stg[k];
-            transform_q(kHr, kVw);
+                    for (int k = 0; k < 3; ++k) st_halo(k, stg[k], pl2, pl0);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) stg[k] = ld_halo(3 + k, ch);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef IDH_ABL_W4S_TRACE
+                if (j % 6 == 5) W4ST(tr0 + 2 + j / 6);
+#endif
+            }
+            if (PAR == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) st_halo(3 + k, stg[k], pl2, pl0);
+            }
+            W4ST(tr0 + 5);
+            // transform(S + 1): halo(S + 1) -> V(S + 1)
+            transform_q(pl1, kVw);
+            W4ST(tr0 + 6);
             __syncthreads();
+            W4ST(tr0 + 7);
+            const int t0 = pl0; pl0 = pl1; pl1 = pl2; pl2 = t0;
         };
 #pragma unroll 1
         for (int c = 0; c < nS; c += 2) {
@@ -863,6 +953,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
         }
 
         // ---- epilogue: Y = A^T M A; lane = 4 consecutive channels of the 4x4 pixels of tile (ty, tx)
+        W4ST(70);
 #ifdef IDH_ABL_W4S_NOEPI
 #pragma unroll
         for (int p = 0; p < 36; ++p) asm volatile("" ::"v"(acc[p]));
@@ -907,9 +998,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
             }
         }
 #endif
+        W4ST(71);
         if (!has_next) break;
         t_cur = t_next;
         cur = nxt;
+#ifdef IDH_ABL_W4S_TRACE
+        ++tile_i;
+#endif
     }
 }
 
