@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
     const int voffA = lane * 16;
     // A fragments: a ring of kRing rows that runs across stage and tile boundaries: row j of a stage is consumed from Af[j % kRing] and the
     // register reloaded at once with the row kRing further on (24 MFMAs = ~0.8k cycles of lookahead)
-    constexpr int kRing = 6;  // (divides 18)
+    constexpr int kRing = 3;  // (divides 18)
     f32x4 Af[kRing];
     auto ldA = [&](int slot, int so) {
 #ifdef IDH_ABL_W4S_NOA
@@ -865,6 +865,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
     }
     __syncthreads();
     transform_q(0, kSV0);
+    // even stage S: halo(S + 2) -> plane pl2, halo(S + 3) -> plane pl0 (halo(S) left it one barrier ago), in a batch of 2 and one of 4 copies; at its entry
+    // stg[] holds the first batch in flight
+    f32x4 stg[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) stg[k] = ld_halo(k, 2);
     __syncthreads();
     int pl0 = 0, pl1 = kSPlane, pl2 = 2 * kSPlane;  // LDS offsets of the planes of halo(S), halo(S + 1), halo(S + 2) (rotated every stage)
 
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
 #ifdef IDH_ABL_W4S_TRACE
     unsigned long long *trace = reinterpret_cast<unsigned long long *>(a.ws) + ((size_t)blockIdx.x * 4 + wave) * 80;
     int tile_i = 0;
-#define W4ST(idx) do { if (tile_i == 1 && lane == 0) trace[(idx)] = __builtin_readcyclecounter(); } while (0)
+#define W4ST(idx) do { if (tile_i == 1 && lane == 0 && (idx) >= 0) trace[(idx)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define W4ST(idx) do { } while (0)
 #endif
@@ -892,17 +897,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
         auto stage = [&](auto parc, const int c) {
             constexpr int PAR = decltype(parc)::value;
             constexpr int kVr = PAR ? kSV1 : kSV0, kVw = PAR ? kSV0 : kSV1;
-            const int tr0 = c < 8 ? 1 + 8 * c : 72;
+            const int tr0 = c < 8 ? 1 + 8 * c : -100;
             W4ST(tr0);
-            // even stage: halo(S + 2) -> plane pl2, halo(S + 3) -> plane pl0 (halo(S) left it one barrier ago); two batches of 3 copies
-            f32x4 stg[3];
-            int ch = 0;
-            if (PAR == 0) {
-                if (c + 2 == nS) set_halo_cursor(nxt);
-                ch = c + 2 >= nS ? c + 2 - nS : c + 2;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) stg[k] = ld_halo(k, ch);
-            }
+            const int ch = c + 2 >= nS ? c + 2 - nS : c + 2;  // (even stages)
             W4ST(tr0 + 1);
             // MFMA(S): A rows from the ring, B fragments from V(S)
             const int aso = __builtin_amdgcn_readfirstlane((c * nCB + cbw) * (kSPanelFloats * 4));
@@ -925,9 +922,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
                 ldA(j % kRing, j + kRing < 18 ? aso + 1024 * (j + kRing) : aso_n + 1024 * (j + kRing - 18));
                 if (PAR == 0 && j == 8) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) st_halo(k, stg[k], pl2, pl0);
+                    for (int k = 0; k < 2; ++k) st_halo(k, stg[k], pl2, pl0);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) stg[k] = ld_halo(3 + k, ch);
+                    for (int k = 0; k < 4; ++k) stg[k] = ld_halo(2 + k, ch);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #ifdef IDH_ABL_W4S_TRACE
@@ -936,7 +933,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4s_k(const Wino4Args wa) {
             }
             if (PAR == 0) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) st_halo(3 + k, stg[k], pl2, pl0);
+                for (int k = 0; k < 4; ++k) st_halo(2 + k, stg[k], pl2, pl0);
+            } else {
+                // first half of the next even stage's copies (halo(E + 2), halo(E + 3), E = c + 1 or stage 0 of the next tile), issued HERE: loads complete in
+                // order, so an A row issued after a copy cannot be used before the copy is back from HBM (~3k cycles); rows 0..5 of a stage use A rows
+                // issued before this point
+                if (c + 3 == nS) set_halo_cursor(nxt);
+                const int chn = c + 3 >= nS ? c + 3 - nS : c + 3;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) stg[k] = ld_halo(k, chn);
             }
             W4ST(tr0 + 5);
             // transform(S + 1): halo(S + 1) -> V(S + 1)
