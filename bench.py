@@ -345,9 +345,9 @@ class HotPathWorkload:
         from implicit_depth_amd import nhwc
 
         if op.tile_m == nhwc.TILE_WINO4:
-            # Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile over whole 64 x 16 pixel tiles (= SQ_INSTS_MFMA x 2048: PMC 42.47 M
+            # Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile over whole 32 x 8 pixel tiles (= SQ_INSTS_MFMA x 2048: PMC 42.47 M
             # for 192->64 @192x256 x 32, profiles/r04/pmc_wino4_vs_wino2_192to64.txt)
-            pix4 = op.N * (-(-op.Ho // 16) * 16) * (-(-op.Wo // 64) * 64)
+            pix4 = op.N * (-(-op.Ho // 8) * 8) * (-(-op.Wo // 32) * 32)
             return 2 * (pix4 // 16) * 36 * (-(-op.src[0].Cin // 16) * 16) * op.Cout
         if op.tile_m != nhwc.TILE_WINO:
             return HotPathWorkload._conv_flops(op)
@@ -364,7 +364,7 @@ class HotPathWorkload:
         from implicit_depth_amd import nhwc
 
         if op.tile_m == nhwc.TILE_WINO4:
-            return "conv3x3_wino4_k<2>"
+            return "conv3x3_wino4_k"
         if op.tile_m == nhwc.TILE_WINO:
             return f"conv3x3_wino_{'group_' if grouped else ''}k<4, 2, 8, {'true' if op.src[1].in_ else 'false'}>"
         if op.tile_m in (10, 11):

@@ -55,8 +55,6 @@ _SIGS = {
     "idh_pack_conv_weight_wino": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_void_p]),
     "idh_packed_wino4_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "idh_pack_conv_weight_wino4": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_void_p]),
-    "idh_packed_wino4s_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
-    "idh_pack_conv_weight_wino4s": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_void_p]),
     "idh_sizeof_op": (C.c_size_t, []),
     "idh_run_ops": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "idh_count_launches": (C.c_int, [C.c_void_p, C.c_int]),

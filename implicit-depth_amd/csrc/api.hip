@@ -1,6 +1,6 @@
 #include "idh_common.h"
 
-extern "C" int idh_version(void) { return 101; }  // 101: idh_volume_opts.scratch / scratch_floats / struct_size; Winograd F(4x4) conv
+extern "C" int idh_version(void) { return 102; }  // 101: idh_volume_opts.scratch / scratch_floats / struct_size; 102: Winograd F(4x4) conv (IDH_TILE_WINO4)
 extern "C" size_t idh_sizeof_volume_opts(void) { return sizeof(idh_volume_opts); }
 
 extern "C" const char *idh_error_string(int code) {

@@ -1211,13 +1211,6 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         pc.tn = 0;
         pc.n_img = op.N;
         pc.blocks = 0;
-    } else if (op.tile_m == IDH_TILE_WINO4S) {
-        if (!wino4s_supported(a)) return IDH_EUNSUPPORTED;
-        pc.lds_rows = 37;
-        pc.tm = op.tile_m;
-        pc.tn = 0;
-        pc.n_img = op.N;
-        pc.blocks = 0;
     } else if (op.tile_m == IDH_TILE_WINO4) {
         // Winograd F(4x4,3x3) kernel (conv_wino4.hip): src[0].w holds idh_pack_conv_weight_wino4 output
         if (!wino4_supported(a)) return IDH_EUNSUPPORTED;
@@ -1283,10 +1276,6 @@ int launch_conv(const PreparedConv &pc, hipStream_t st) {
     if (pc.lds_rows == 36) {
         if (t_dry_run) { ++t_launches; return IDH_OK; }
         return launch_conv_wino4(pc.a, pc.n_img, st);
-    }
-    if (pc.lds_rows == 37) {
-        if (t_dry_run) { ++t_launches; return IDH_OK; }
-        return launch_conv_wino4s(pc.a, pc.n_img, st);
     }
     if (pc.lds_rows == 8 && pc.up) IDH_LAUNCH(conv3x3_lds_up_k<2>, dim3(pc.blocks), dim3(256), 0, st, pc.la);
     else if (pc.lds_rows == 8 && pc.s2 && pc.nj == 4) IDH_LAUNCH((conv3x3_lds_k<2, false, 4, false, true>), dim3(pc.blocks), dim3(256), 0, st, pc.la);

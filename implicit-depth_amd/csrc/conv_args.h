@@ -70,11 +70,8 @@ int launch_conv_wino(const ConvArgs &a, int N, int rows, hipStream_t st);  // ro
 int wino_max_group();
 int launch_conv_wino_group(const ConvArgs *const *as, const int *Ns, int n, hipStream_t st);  // independent convs, one persistent grid
 
-// conv_wino4.hip: Winograd F(4x4,3x3) on the fp32 matrix cores (3x3 stride 1, zero padding, ONE source, Cout % 32 == 0; large maps)
+// conv_wino4.hip: Winograd F(4x4,3x3) on the fp32 matrix cores (3x3 stride 1, zero padding, ONE source, Cout % 64 == 0, Cin > 16)
 bool wino4_supported(const ConvArgs &a);
 int launch_conv_wino4(const ConvArgs &a, int N, hipStream_t st);
-// ... and its shared-transform variant (two workgroups per CU; Cout % 64 == 0)
-bool wino4s_supported(const ConvArgs &a);
-int launch_conv_wino4s(const ConvArgs &a, int N, hipStream_t st);
 
 }  // namespace idh_conv

@@ -188,28 +188,8 @@ def packed_wino4_weight(conv: nn.Conv2d) -> torch.Tensor:
     return dst
 
 
-def packed_wino4s_weight(conv: nn.Conv2d) -> torch.Tensor:
-    """F(4x4,3x3)-domain weights in the A-fragment order of conv3x3_wino4s_k (idh_pack_conv_weight_wino4s); cached like ``packed_weight``."""
-    w = conv.weight
-    key = (w.data_ptr(), _lib.param_version(w), str(w.device))
-    cached = getattr(conv, "_idh_packed_wino4s", None)
-    if cached is not None and cached[0] == key:
-        return cached[1]
-    _lib.require_cuda_f32(w)
-    L = _bind()
-    co, ci, kh, kw = w.shape
-    if (kh, kw) != (3, 3):
-        raise _lib.IdhError("the Winograd F(4x4,3x3) kernel covers 3x3 convolutions only")
-    dst = torch.empty(L.idh_packed_wino4s_weight_floats(co, ci), device=w.device, dtype=torch.float32)
-    wc = w.detach().contiguous()
-    _lib.check(L.idh_pack_conv_weight_wino4s(wc.data_ptr(), dst.data_ptr(), co, ci, _lib.stream_ptr()), "idh_pack_conv_weight_wino4s")
-    conv._idh_packed_wino4s = (key, dst)
-    return dst
-
-
 TILE_WINO = 12  # IDH_TILE_WINO of include/idh_ops.h == the op's tile_m
 TILE_WINO4 = 13  # IDH_TILE_WINO4
-TILE_WINO4S = 14  # IDH_TILE_WINO4S
 # Winograd F(2x2,3x3) for the eligible 3x3 stride-1 layers of fp32 plans (csrc/conv_wino.hip): fp32 operands and
 # accumulation, 2.25x fewer MFMAs; measured 1.67-1.84x over the direct LDS kernel at B=32 (tools/perf_wino.py).
 # Tiles are 32 x 8 pixels x 32 channels; WINO_MIN_TILES: below this many tiles the direct kernels' finer tiles fill the
@@ -236,29 +216,25 @@ def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> b
     return N * ty * tx * (cout // 32) >= WINO_MIN_TILES
 
 
-# Winograd F(4x4,3x3) (csrc/conv_wino4.hip) for the LARGE plain 3x3 layers: 1.78x fewer MFMAs than F(2x2); 64 x 16 pixel x 32
-# channel tiles on one persistent workgroup per CU, so it needs >= WINO4_MIN_TILES tiles (a few per CU) and maps that fill the
-# tile grid; LeakyReLU / no activation, no fused 1x1 source (those blocks stay on F(2x2) with its P steps).  Measured at B = 32
-# (tools/perf_wino4.py, profiles/r04/experiments.md): 192->64 @192x256 1.17x and @96x128 1.13x over F(2x2), 64->64 0.97-1.03x
-# (per-tile epilogue + copy costs are amortised over 8 instead of 24 K stages) -> WINO4_MIN_CIN.
+# Winograd F(4x4,3x3) (csrc/conv_wino4.hip, conv3x3_wino4_k) for the plain 3x3 layers: 1.78x fewer MFMAs than F(2x2); 32 x 8 pixel x 64
+# channel tiles on two persistent workgroups per CU.  Measured against F(2x2) (tools/perf_wino4.py, profiles/r04/perf_wino4_final.txt):
+# 1.17-1.43x at B = 32 on every eligible layer of the network; it wins or ties down to ~192 tiles (B = 8 @48x64, B = 2 @192x256) and
+# loses below (96 tiles: 0.67-0.8x) -> WINO4_MIN_TILES.  Layers with a fused 1x1 projection, ELU or a normalised source stay on F(2x2).
 WINOGRAD4 = True
-WINO4_MIN_TILES = 512
+WINO4_MIN_TILES = 192
 WINO4_MIN_FILL = 0.85
-WINO4_MIN_CIN = 128
-# the shared-transform variant (conv3x3_wino4s_k: two workgroups per CU, 64 x 4 x 64-channel tiles) instead of conv3x3_wino4_k where Cout % 64 == 0
-WINOGRAD4S = False
 
 
 def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act: int) -> bool:
     (v0, c0) = srcs[0]
-    if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 32 or isinstance(v0, CatView):
+    if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64 or isinstance(v0, CatView):
         return False
-    if act not in (ACT_NONE, ACT_LRELU) or c0.in_channels <= 16 or c0.in_channels < WINO4_MIN_CIN:  # (<= 16: the copy pipeline runs two 8-channel stages ahead)
+    if act not in (ACT_NONE, ACT_LRELU) or c0.in_channels <= 16:  # (<= 16: the copy pipeline runs a pair of 8-channel stages ahead)
         return False
-    ty, tx = -(-Ho // 16), -(-Wo // 64)
-    if Ho * Wo < WINO4_MIN_FILL * (ty * 16) * (tx * 64):
+    ty, tx = -(-Ho // 8), -(-Wo // 32)
+    if Ho * Wo < WINO4_MIN_FILL * (ty * 8) * (tx * 32):
         return False
-    return N * ty * tx * (cout // 32) >= WINO4_MIN_TILES
+    return N * ty * tx * (cout // 64) >= WINO4_MIN_TILES
 
 
 SPLIT_CODE = {"f16x3": 11}  # IDH_SPLIT_F16X3 of include/idh_ops.h == the op's tile_m
@@ -468,8 +444,6 @@ class Plan:
                 raise _lib.IdhError("a conv input whose channel count is not a multiple of 16 must be a whole zero-padded buffer")
             if use_split:  # one blob: [3x3 panels][1x1 panels of the second source][scales]
                 w = split_packed_weight(conv, self.math, conv2)
-            elif use_wino4 and WINOGRAD4S and conv.out_channels % 64 == 0:
-                w = packed_wino4s_weight(cv)
             elif use_wino4:
                 w = packed_wino4_weight(cv)
             elif use_wino and i == 0:
@@ -503,7 +477,7 @@ class Plan:
         if use_split:
             tm, tn, split = SPLIT_CODE[self.math], choose_split_rows(out.N, out.H, out.W, conv.out_channels), 1
         elif use_wino4:
-            tm, tn, split = (TILE_WINO4S if WINOGRAD4S and conv.out_channels % 64 == 0 else TILE_WINO4), 0, 1
+            tm, tn, split = TILE_WINO4, 0, 1
         elif use_wino:
             tm, tn, split = TILE_WINO, 0, 1
         elif lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
@@ -842,7 +816,7 @@ def build_flags() -> tuple:
     """Module-level switches that shape a plan at build time (part of every plan-cache key: toggling one takes effect on the
     next call instead of silently replaying a plan built under the old setting)."""
     return (WINO_GROUP, FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
-            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINO4_MIN_TILES, WINO4_MIN_FILL, WINO4_MIN_CIN, WINOGRAD4S, DEFAULT_MATH)
+            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINO4_MIN_TILES, WINO4_MIN_FILL, DEFAULT_MATH)
 
 
 def _plan_cache(module: nn.Module) -> PlanCache:

@@ -128,24 +128,19 @@ int idh_pack_conv_weight_split(const float *w_oihw, const float *w_1x1, void *ds
 size_t idh_packed_wino_weight_floats(int Cout, int Cin);
 int idh_pack_conv_weight_wino(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);
 
-/* Winograd F(4x4,3x3) convolution (csrc/conv_wino4.hip): 36 instead of 64 multiplications per 4x4 output pixels and input
- * channel (1.78x fewer MFMAs than IDH_TILE_WINO), fp32 operands and accumulation, interpolation points {0, +-1/2, +-2, inf};
- * for the large 3x3 stride-1 convs of BasicBlock (layers.py:59-95: 64->64 and 192->64 at 192x256 / 96x128).  IDH_OP_CONV with
- * tile_m = IDH_TILE_WINO4; src[0].w = the output of idh_pack_conv_weight_wino4 (U = G g G^T per (co, ci) in MFMA A-fragment
- * order: [Cin_pad/8][Cout/32][k-step 2][co block 2][position group 9][lane 64][4]); 64 x 16 pixel x 32 channel tiles, one
- * persistent workgroup per CU.  Shape family: 3x3, stride 1, zero padding, Cout % 32 == 0, split_k == 1, src[1] unused (a block
- * with a 1x1 projection stays on IDH_TILE_WINO); anything else: IDH_EUNSUPPORTED.  Error against fp64 ~2-5e-6 of the output
- * scale (direct kernel ~1e-6, F(2x2) ~4e-7). */
+/* Winograd F(4x4,3x3) convolution (csrc/conv_wino4.hip, conv3x3_wino4_k): 36 instead of 64 multiplications per 4x4 output pixels
+ * and input channel (1.78x fewer MFMAs than IDH_TILE_WINO), fp32 operands and accumulation, interpolation points {0, +-1/2, +-2, inf};
+ * for the plain 3x3 stride-1 convs of BasicBlock / the decoders (layers.py:59-95, networks.py:20-215).  IDH_OP_CONV with
+ * tile_m = IDH_TILE_WINO4; src[0].w = the output of idh_pack_conv_weight_wino4 (U = G g G^T per (co, ci) in MFMA A-fragment order:
+ * [Cin_pad/8][Cout_pad/16][k-step 2][position group 9][lane 64][4], positions quadrant-major, ci = 8 stage + 2 (lane >> 4) + k-step);
+ * 32 x 8 pixel x 64 channel tiles, the input transform shared through LDS by the four 16-channel waves of a tile, two persistent
+ * workgroups per CU.  Shape family: 3x3, stride 1, zero padding, Cin > 16, Cout % 64 == 0, split_k == 1, act NONE / LRELU, src[1]
+ * unused (a block with a 1x1 projection stays on IDH_TILE_WINO); anything else: IDH_EUNSUPPORTED.  Error against fp64 ~2-7e-6 of
+ * the output scale (direct kernel ~1e-6, F(2x2) ~4e-7).  (ABI 101 had a register-transform kernel under this code with another
+ * weight layout and code 14 for this one; 102 keeps one kernel, one code.) */
 #define IDH_TILE_WINO4 13
 size_t idh_packed_wino4_weight_floats(int Cout, int Cin);
 int idh_pack_conv_weight_wino4(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);
-/* The same F(4x4,3x3) arithmetic with the input transform shared through LDS by the four 16-channel waves of a 64-channel tile
- * (conv3x3_wino4s_k: 64 x 4 pixel x 64 channel tiles, two workgroups per CU): tile_m = IDH_TILE_WINO4S, src[0].w from
- * idh_pack_conv_weight_wino4s ([Cin_pad/8][Cout_pad/16][k-step 2][position group 9][lane 64][4], positions quadrant-major); the shape
- * family of IDH_TILE_WINO4 with Cout % 64 == 0. */
-#define IDH_TILE_WINO4S 14
-size_t idh_packed_wino4s_weight_floats(int Cout, int Cin);
-int idh_pack_conv_weight_wino4s(const float *w_oihw, float *dst, int Cout, int Cin, void *stream);
 
 /* sizeof(idh_op) as compiled into the library (bindings assert their mirror matches). */
 size_t idh_sizeof_op(void);

@@ -219,7 +219,8 @@ def test_fused_upsample_concat_is_bit_identical_to_materialised():
     pyr = syn.encoder_pyramid(2, 256, 384, seed=5, channels=(24, 64, 128, 256, 384))
     feats = [t.cuda() for t in pyr]
     old = nhwc.FUSE_UPSAMPLE, nhwc.FUSED_UP_ROWS
-    old_wino, nhwc.WINOGRAD = nhwc.WINOGRAD, False  # bit-identity holds kernel by kernel: a materialised concat would take the Winograd kernel
+    old_wino, nhwc.WINOGRAD = nhwc.WINOGRAD, False  # bit-identity holds kernel by kernel: a materialised concat would take a Winograd kernel
+    old_wino4, nhwc.WINOGRAD4 = nhwc.WINOGRAD4, False
     try:
         outs = {}
         for fuse, rows in ((False, 8), (True, 8), (True, 4)):
@@ -233,6 +234,7 @@ def test_fused_upsample_concat_is_bit_identical_to_materialised():
     finally:
         nhwc.FUSE_UPSAMPLE, nhwc.FUSED_UP_ROWS = old
         nhwc.WINOGRAD = old_wino
+        nhwc.WINOGRAD4 = old_wino4
         dec.__dict__.pop("_idh_plans", None)
     for key in ((True, 8), (True, 4)):
         for k, v in outs[(False, 8)].items():

@@ -3,16 +3,13 @@
 # meaningless; only their timing is read (profiles/r04/experiments.md).
 cd "$(dirname "$0")/.."
 mkdir -p implicit-depth_amd/_obj/abl
-VARS="${VARS:-NOEPI NOXFORM NOLOAD NOLDSW NORAW NOMFMA NOEPI,NOXFORM,NOLOAD,NORAW}"
+VARS="${VARS:-NOXFORM NOEPI NOA NOB NOHALO NOA,NOB,NOXFORM,NOHALO}"
 if [ "$1" = build ]; then
   for v in $VARS; do
-    name=${v//,/_}; defs=""; for d in ${v//,/ }; do defs="$defs -DIDH_ABL_W4_$d -DIDH_ABL_W4S_$d"; done
+    name=${v//,/_}; defs=""; for d in ${v//,/ }; do defs="$defs -DIDH_ABL_W4_$d"; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $defs -fno-slp-vectorize -c implicit-depth_amd/csrc/conv_wino4.hip -o /tmp/w4_$name.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls implicit-depth_amd/_obj/*.o | grep -v conv_wino4.o) /tmp/w4_$name.o -o implicit-depth_amd/_obj/abl/libidh_ablw4_$name.so && echo built $name
   done
-elif [ "$1" = traces ]; then
-  shift
-  IDH_LIB=$PWD/implicit-depth_amd/_obj/abl/libidh_ablw4_TRACE.so python tools/trace_wino4s.py "$@" 2>&1 | grep -v amdgpu.ids
 elif [ "$1" = trace ]; then
   shift
   IDH_LIB=$PWD/implicit-depth_amd/_obj/abl/libidh_ablw4_TRACE.so python tools/trace_wino4.py "$@" 2>&1 | grep -v amdgpu.ids

@@ -13,8 +13,7 @@ x = torch.randn(B, H, W, cin, device="cuda")
 p = nhwc.Plan(x.device)
 out = p.buffer(B, H, W, cout)
 nhwc.WINOGRAD, nhwc.WINO_MIN_TILES = tm == nhwc.TILE_WINO, 1  # Winograd kernel: the plan packs Winograd-domain weights
-nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL, nhwc.WINO4_MIN_CIN = tm in (nhwc.TILE_WINO4, nhwc.TILE_WINO4S), 1, 0.0, 0
-nhwc.WINOGRAD4S = tm == nhwc.TILE_WINO4S
+nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = tm == nhwc.TILE_WINO4, 1, 0.0
 p.conv(nhwc.View(x, 0, cin), conv, out, act=1)
 op = p.ops[0]; op.tile_m, op.tile_n, op.split_k = tm, tn, split
 if split > 1:

@@ -19,7 +19,7 @@ LAYERS = [(64, 64, 192, 256, 0), (64, 64, 192, 256, 1), (192, 64, 192, 256, 0), 
 sel = os.environ.get("LAYERS")
 if sel:
     LAYERS = [LAYERS[int(i)] for i in sel.split(",")]
-VARIANTS = [("direct8", 8), ("wino2", nhwc.TILE_WINO), ("wino4", nhwc.TILE_WINO4), ("wino4s", nhwc.TILE_WINO4S)]
+VARIANTS = [("direct8", 8), ("wino2", nhwc.TILE_WINO), ("wino4", nhwc.TILE_WINO4)]
 if os.environ.get("VARIANTS"):
     VARIANTS = [v for v in VARIANTS if v[0] in os.environ["VARIANTS"].split(",")]
 
@@ -29,14 +29,11 @@ def build(conv, x, res, tm):
     Bn, H, W, cin = x.shape
     out = p.buffer(Bn, H, W, conv.out_channels)
     old = (nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL)
-    nhwc.WINO4_MIN_CIN = 0
-    nhwc.WINOGRAD4S = tm == nhwc.TILE_WINO4S
-    nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = tm == nhwc.TILE_WINO, tm in (nhwc.TILE_WINO4, nhwc.TILE_WINO4S), 1, 1, 0.0
+    nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = tm == nhwc.TILE_WINO, tm == nhwc.TILE_WINO4, 1, 1, 0.0
     try:
         p.conv(nhwc.View(x, 0, cin), conv, out, act=1, slope=0.2, res=None if res is None else nhwc.View(res, 0, conv.out_channels))
     finally:
         nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = old
-        nhwc.WINOGRAD4S = False
     op = p.ops[0]
     if tm == 8:
         op.tile_m, op.tile_n = 8, 0
