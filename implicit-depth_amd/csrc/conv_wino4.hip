@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
         {
             const int e = tid_o >> 2;
             const int iy = t.y0 - 1 + (e >> 1), ix = t.x0 + 31 + (e & 1);
-            voffH1 = (e < 20) & (ix < s.W) & ((unsigned)iy < (unsigned)s.H) ? (iy * s.W + ix) * s.cs * 4 + 16 * gr : kOob;
+            voffH1 = ((e < 20) & (ix < s.W) & ((unsigned)iy < (unsigned)s.H)) ? (iy * s.W + ix) * s.cs * 4 + 16 * gr : kOob;
         }
     };
     auto ld_halo = [&](int k, int ch) -> f32x4 {  // ch: the pair's first stage
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
         auto stage = [&](auto parc, const int c) {
             constexpr int PAR = decltype(parc)::value;
             constexpr int kVr = PAR ? kV1 : kV0, kVw = PAR ? kV0 : kV1;
-            const int tr0 = c < 8 ? 1 + 8 * c : -100;
+            [[maybe_unused]] const int tr0 = c < 8 ? 1 + 8 * c : -100;
             W4T(tr0);
             const int ch = c + 2 >= nS ? c + 2 - nS : c + 2;  // (even stages)
             W4T(tr0 + 1);
