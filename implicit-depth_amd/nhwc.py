@@ -217,11 +217,14 @@ def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> b
 
 
 # Winograd F(4x4,3x3) (csrc/conv_wino4.hip, conv3x3_wino4_k) for the plain 3x3 layers: 1.78x fewer MFMAs than F(2x2); 32 x 8 pixel x 64
-# channel tiles on two persistent workgroups per CU.  Measured against F(2x2) (tools/perf_wino4.py, profiles/r04/perf_wino4_final.txt):
-# 1.17-1.43x at B = 32 on every eligible layer of the network; it wins or ties down to ~192 tiles (B = 8 @48x64, B = 2 @192x256) and
-# loses below (96 tiles: 0.67-0.8x) -> WINO4_MIN_TILES.  Layers with a fused 1x1 projection, ELU or a normalised source stay on F(2x2).
+# channel tiles on two persistent workgroups per CU (512 slots).  Measured against F(2x2) (tools/perf_wino4.py, profiles/r04/perf_wino4_final.txt):
+# 1.11-1.39x at B = 32 on every eligible layer of the network.  Layer by layer it wins or ties down to ~192 tiles and loses below
+# (96 tiles: 0.6-0.8x), but inside a whole step the threshold that never loses is 384 (bench.py --batch 1 / 4 / 8 / 16 with 192:
+# -5 / -4 / 0 / +1 %; with 384: 0 / +2 / +6 / +7 %; profiles/r04/experiments.md): below it the F(2x2) convs of a UNet++ level share ONE
+# grouped launch, which a half-filled grid of F(4x4) tiles does not beat.  Layers with a fused 1x1 projection, ELU or a normalised source
+# stay on F(2x2).
 WINOGRAD4 = True
-WINO4_MIN_TILES = 192
+WINO4_MIN_TILES = 384
 WINO4_MIN_FILL = 0.85
 
 
