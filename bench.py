@@ -734,6 +734,12 @@ def main():
                                          "achieved_algorithmic": all_fl / (all_ms * 1e-3) / 1e12, "launches_per_step": all_n, "ms_per_step": all_ms,
                                          "executed_flops_per_step": all_ex, "algorithmic_flops_per_step": all_fl},
                     "step_ms_hip_events": kernel_ms}
+            if wl.dominant_kernel == "conv3x3_wino4_k":
+                # F(4x4) executes 36/64 of the multiplies F(2x2) needs for the same outputs: `frac` (matrix-pipe utilisation) is not comparable
+                # with earlier rounds' F(2x2) figure; this is the same time priced with the flops conv3x3_wino_k would execute for these launches
+                roof["f2x2_equivalent"] = {"achieved": achieved * 64 / 36, "frac": achieved * 64 / 36 / peak,
+                                           "note": "the dominant launches priced with Winograd F(2x2)'s executed flops (64 instead of 36 multiplies per 4x4 outputs "
+                                                   "and channel pair): comparable with rounds 2-3's roofline.frac of conv3x3_wino_k (0.674)"}
             if math != "fp32":
                 roof["peak_note"] = (f"fp32-equivalent flops; peak = {MFMA_16BIT_PEAK_TFLOPS:.0f} TFLOP/s dense 16-bit MFMA / "
                                      "3 products per MAC; the fp32-MFMA peak is 157.3")

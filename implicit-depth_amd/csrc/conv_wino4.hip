@@ -309,8 +309,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
     const int voffA = lane * 16;
     // A fragments: a ring of kRing rows that runs across stage and tile boundaries: row j of a stage is consumed from Af[j % kRing] and the
-    // register reloaded at once with the row kRing further on (24 MFMAs = ~0.8k cycles of lookahead)
-    constexpr int kRing = 3;  // (divides 18)
+    // register reloaded at once with the row kRing further on (12 MFMAs of lookahead)
+#ifndef IDH_W4_RING
+#define IDH_W4_RING 3
+#endif
+    constexpr int kRing = IDH_W4_RING;  // (divides 18; measured 1: -7 ... -39 %, 2: 0 ... -12 %, 6: -6 ... -9 %: more rows in flight cost more at the issue of the other loads than they hide)
     f32x4 Af[kRing];
     auto ldA = [&](int slot, int so) {
 #ifdef IDH_ABL_W4_NOA
@@ -332,7 +335,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
         for (int k = 0; k < 3; ++k) st_halo(3 * b + k, t0[k], 0, kPlane);
     }
     {
-        const int so0 = (4 * cur.nt + wave) * (kPanelFloats * 4);
+#ifdef IDH_ABL_W4_SAMEA  // (timing experiment: every wave reads channel block 0's fragments: what would sharing the A rows in L1 be worth?)
+#define W4_CB(x) 0
+#else
+#define W4_CB(x) (x)
+#endif
+        const int so0 = W4_CB(4 * cur.nt + wave) * (kPanelFloats * 4);
 #pragma unroll
         for (int j = 0; j < kRing; ++j) ldA(j, __builtin_amdgcn_readfirstlane(so0 + 1024 * j));
     }
@@ -375,9 +383,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
             const int ch = c + 2 >= nS ? c + 2 - nS : c + 2;  // (even stages)
             W4T(tr0 + 1);
             // MFMA(S): A rows from the ring, B fragments from V(S)
-            const int aso = __builtin_amdgcn_readfirstlane((c * nCB + cbw) * (kPanelFloats * 4));
+            const int aso = __builtin_amdgcn_readfirstlane((c * nCB + W4_CB(cbw)) * (kPanelFloats * 4));
             const bool last = c + 1 >= nS;
-            const int aso_n = __builtin_amdgcn_readfirstlane(last ? (4 * nxt.nt + wave) * (kPanelFloats * 4) : aso + nCB * (kPanelFloats * 4));  // next stage (next tile: its stage 0)
+            const int aso_n = __builtin_amdgcn_readfirstlane(last ? W4_CB(4 * nxt.nt + wave) * (kPanelFloats * 4) : aso + nCB * (kPanelFloats * 4));  // next stage (next tile: its stage 0)
             f32x4 Bf[18];
 #ifdef IDH_ABL_W4_NOB
             auto ldB = [&](int j) { Bf[j] = (f32x4){1.f, 2.f, 3.f, 4.f}; };
