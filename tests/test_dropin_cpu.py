@@ -133,3 +133,40 @@ def test_state_dict_load_into_an_unwatched_child_invalidates_and_modules_pickle(
         child.load_state_dict({k: v * 0.5 for k, v in child.state_dict().items()})
     assert _lib._weights_epoch == e0 + 1
     pickle.load(io.BytesIO(pickle.dumps(dec)))
+
+
+def test_winograd_kernel_selection_rules():
+    """nhwc.wino4_eligible / wino_eligible (host logic, no kernel runs): F(4x4) takes the plain 3x3 stride-1 zero-padded layers with
+    Cout % 64 == 0, > 16 input channels, LeakyReLU / no activation and >= WINO4_MIN_TILES tiles of 32 x 8 pixels x 64 channels that fill
+    the map; blocks with a fused 1x1 projection, ELU layers, narrow outputs and small grids are left to F(2x2) / the direct kernels
+    (the thresholds are measured: profiles/r04/experiments.md 1b)."""
+    from torch import nn
+
+    from implicit_depth_amd import nhwc
+
+    class V:  # what the rules read of a view
+        pass
+
+    c64, c192, c16 = nn.Conv2d(64, 64, 3, 1, 1), nn.Conv2d(192, 64, 3, 1, 1), nn.Conv2d(16, 64, 3, 1, 1)
+    proj, s2, c32 = nn.Conv2d(32, 64, 1), nn.Conv2d(64, 64, 3, 2, 1), nn.Conv2d(64, 32, 3, 1, 1)
+    Z, L, E = nhwc.PAD_ZEROS, nhwc.ACT_LRELU, 2
+    assert nhwc.WINO4_MIN_TILES == 384 and nhwc.WINOGRAD4
+    # bench batch: every level down to 24x32 (32 * 3 * 1 * 4 = 384 tiles at 256 channels)
+    assert nhwc.wino4_eligible([(V(), c64)], 64, 32, 192, 256, Z, L)
+    assert nhwc.wino4_eligible([(V(), c192)], 64, 32, 96, 128, Z, nhwc.ACT_NONE)
+    assert nhwc.wino4_eligible([(V(), nn.Conv2d(256, 256, 3, 1, 1))], 256, 32, 24, 32, Z, L)
+    # tile count: B = 8 @96x128 has 8 * 12 * 4 = 384, B = 4 has 192; one frame never qualifies
+    assert nhwc.wino4_eligible([(V(), c64)], 64, 8, 96, 128, Z, L) and not nhwc.wino4_eligible([(V(), c64)], 64, 4, 96, 128, Z, L)
+    assert not nhwc.wino4_eligible([(V(), c64)], 64, 1, 192, 256, Z, L)
+    # shape family
+    assert not nhwc.wino4_eligible([(V(), c64), (V(), proj)], 64, 32, 192, 256, Z, L), "fused projection"
+    assert not nhwc.wino4_eligible([(V(), c64)], 64, 32, 192, 256, Z, E), "ELU"
+    assert not nhwc.wino4_eligible([(V(), c16)], 64, 32, 192, 256, Z, L), "<= 16 input channels"
+    assert not nhwc.wino4_eligible([(V(), c32)], 32, 32, 192, 256, Z, L), "Cout % 64"
+    assert not nhwc.wino4_eligible([(V(), s2)], 64, 32, 96, 128, Z, L), "stride 2"
+    assert not nhwc.wino4_eligible([(V(), c64)], 64, 32, 192, 256, nhwc.PAD_ZEROS + 1, L), "replicate padding"
+    # tile fill: a 12x16 map covers 12 * 16 of 16 * 32 tile pixels
+    assert not nhwc.wino4_eligible([(V(), nn.Conv2d(384, 384, 3, 1, 1))], 384, 64, 12, 16, Z, L)
+    # what F(4x4) leaves goes to F(2x2) where that one's own rules hold
+    assert nhwc.wino_eligible([(V(), c64), (V(), proj)], 64, 32, 192, 256, Z)
+    assert nhwc.wino_eligible([(V(), c64)], 64, 4, 96, 128, Z) and not nhwc.wino_eligible([(V(), c64)], 64, 1, 24, 32, Z)
