@@ -348,7 +348,10 @@ class HotPathWorkload:
             # Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile over whole 32 x 8 pixel tiles (= SQ_INSTS_MFMA x 2048: PMC 42.47 M
             # for 192->64 @192x256 x 32, profiles/r04/pmc_wino4_vs_wino2_192to64.txt)
             pix4 = op.N * (-(-op.Ho // 8) * 8) * (-(-op.Wo // 32) * 32)
-            return 2 * (pix4 // 16) * 36 * (-(-op.src[0].Cin // 16) * 16) * op.Cout
+            fl4 = 2 * (pix4 // 16) * 36 * (-(-op.src[0].Cin // 16) * 16) * op.Cout
+            if op.src[1].in_:  # the fused 1x1 projection: pixel-domain MFMAs in 16-channel chunks
+                fl4 += 2 * pix4 * (-(-op.src[1].Cin // 16) * 16) * op.Cout
+            return fl4
         if op.tile_m != nhwc.TILE_WINO:
             return HotPathWorkload._conv_flops(op)
         pix = op.N * (-(-op.Ho // 8) * 8) * (-(-op.Wo // 32) * 32)
@@ -364,7 +367,7 @@ class HotPathWorkload:
         from implicit_depth_amd import nhwc
 
         if op.tile_m == nhwc.TILE_WINO4:
-            return "conv3x3_wino4_k"
+            return f"conv3x3_wino4_k<{'true' if op.src[1].in_ else 'false'}>"
         if op.tile_m == nhwc.TILE_WINO:
             return f"conv3x3_wino_{'group_' if grouped else ''}k<4, 2, 8, {'true' if op.src[1].in_ else 'false'}>"
         if op.tile_m in (10, 11):
@@ -734,7 +737,7 @@ def main():
                                          "achieved_algorithmic": all_fl / (all_ms * 1e-3) / 1e12, "launches_per_step": all_n, "ms_per_step": all_ms,
                                          "executed_flops_per_step": all_ex, "algorithmic_flops_per_step": all_fl},
                     "step_ms_hip_events": kernel_ms}
-            if wl.dominant_kernel == "conv3x3_wino4_k":
+            if wl.dominant_kernel == "conv3x3_wino4_k<false>":
                 # F(4x4) executes 36/64 of the multiplies F(2x2) needs for the same outputs: `frac` (matrix-pipe utilisation) is not comparable
                 # with earlier rounds' F(2x2) figure; this is the same time priced with the flops conv3x3_wino_k would execute for these launches
                 roof["f2x2_equivalent"] = {"achieved": achieved * 64 / 36, "frac": achieved * 64 / 36 / peak,

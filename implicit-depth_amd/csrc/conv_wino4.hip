@@ -152,6 +152,9 @@ __device__ __forceinline__ void bt3_finish(float s0, float s1, float s2, float &
     }
 }
 
+// SRC2: BasicBlock's 1x1 projection of a second tensor (layers.py:86-92), accumulated in the PIXEL domain after the output transform (the epilogue's
+// "P phase" below)
+template <bool SRC2>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
     __shared__ __attribute__((aligned(16))) char lds_raw[kLdsBytes];
     lds_char *lds = (lds_char *)lds_raw;
@@ -458,28 +461,102 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
             f32x4 u[6][4];
 #pragma unroll
             for (int xi = 0; xi < 6; ++xi) at6(M(xi, 0), M(xi, 1), M(xi, 2), M(xi, 3), M(xi, 4), M(xi, 5), u[xi][0], u[xi][1], u[xi][2], u[xi][3]);
+            if constexpr (!SRC2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 r[4], y[4];
-                int pix[4];
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 r[4], y[4];
+                    int pix[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
-                    pix[i] = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
-                    r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < 4; ++i) {
+                        const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
+                        pix[i] = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
+                        r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pix[i] >= 0 ? (pix[i] * a.res_cs + n0 + 4 * h) * 4 : kOob, 0, 0));
+                    }
+                    at6(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], y[0], y[1], y[2], y[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 o = y[i] + b4 + r[i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
+                    }
                 }
-                if (has_res) {
+            } else {
+                // ---- P phase: Y[pixel] += W1 . x2[pixel] as MFMAs in the pixel domain.  After the output transform a lane holds, for each of the 16 pixels
+                // of its tile, channels 4h..4h+3: exactly the C layout of a 16 (channels) x 16 (tiles) MFMA block per pixel.  x2 goes through LDS in chunks of
+                // 16 channels x 256 pixels (16 KiB), double-buffered in what is free at this point: buffer 0 = the V buffer the last stage left (the other one
+                // holds the next tile's V(0)), buffer 1 = the two free halo planes (pl0: the next tile's halo(0), already transformed; pl2), 8 KiB = two channel
+                // quads in each.  Layout [channel-quad half][pixel of the tile][quad & 1][tile n] x 16 B: a wave's B operand of a pixel is one conflict-free
+                // ds_read_b128.  One barrier per chunk: chunk m + 1 is written while chunk m is multiplied.  The 1x1 weights are read from the direct
+                // kernels' layout [ci / 4][Cout][4] (idh_pack_conv_weight), one 16-byte fragment per lane and chunk.
+                f32x4 Y[16];  // [4 i + j]
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pix[i] >= 0 ? (pix[i] * a.res_cs + n0 + 4 * h) * 4 : kOob, 0, 0));
+                for (int j = 0; j < 4; ++j) at6(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], Y[j], Y[4 + j], Y[8 + j], Y[12 + j]);
+                const ConvSrc &s2 = a.s[1];
+                const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s2.in + (size_t)cur.img * s2.H * s2.W * s2.cs), 0, s2.H * s2.W * s2.cs * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s2.w), 0, s2.cblocks * 4 * a.Cout_pad * 16, 0x00020000);
+                // copies: thread t, round r: pixel (row 2 r + (t >> 7), column (t >> 2) & 31) of the 32 x 8 tile group, channel quad t & 3 (64 contiguous bytes per
+                // pixel); its tile is 8 (r >> 1) + (column >> 2), its pixel of the tile 4 (2 (r & 1) + (t >> 7)) + (column & 3)
+                int voffX[4];
+                const int hq = tid & 3, xx = (tid >> 2) & 31, t7 = tid >> 7;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int iy = cur.y0 + 2 * r + t7, ix = cur.x0 + xx;
+                    voffX[r] = ((iy < s2.H) & (ix < s2.W)) ? (iy * s2.W + ix) * s2.cs * 4 + 16 * hq : kOob;
                 }
-                at6(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], y[0], y[1], y[2], y[3]);
+                const int wrel = 512 * (4 * t7 + (xx & 3)) + ((hq & 1) * 16 + (xx >> 2)) * 16;  // + 4096 (r & 1) + 128 (r >> 1)
+                const int rrel = ((h & 1) * 16 + n) * 16;                                         // + 512 pixel
+                int wb_cur = kV1 + 8192 * (hq >> 1) + wrel, wb_nxt = ((hq >> 1) ? pl2 : pl0) + wrel;
+                int rb_cur = kV1 + 8192 * (h >> 1) + rrel, rb_nxt = ((h >> 1) ? pl2 : pl0) + rrel;
+                const int nM = s2.cblocks;
+                const int voffW = ((h * a.Cout_pad) + n0 + n) * 16;
+                auto ld_x = [&](f32x4 (&xs)[4], int m) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 o = y[i] + b4 + r[i];
+                    for (int r = 0; r < 4; ++r) xs[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voffX[r], __builtin_amdgcn_readfirstlane(64 * m), 0));
+                };
+                auto st_x = [&](const f32x4 (&xs)[4], int wb) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
+                    for (int r = 0; r < 4; ++r) *(lds_f32x4 *)(lds + wb + 4096 * (r & 1) + 128 * (r >> 1)) = xs[r];
+                };
+                auto ld_w = [&](int m) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW1, voffW, __builtin_amdgcn_readfirstlane(m * 4 * a.Cout_pad * 16), 0)); };
+                f32x4 xs[4];
+                ld_x(xs, 0);
+                f32x4 Aw = ld_w(0);
+                st_x(xs, wb_cur);
+                ld_x(xs, nM > 1 ? 1 : 0);
+                __syncthreads();
+#pragma unroll 1
+                for (int m = 0; m < nM; ++m) {
+                    const f32x4 Acur = Aw;
+                    Aw = ld_w(m + 1 < nM ? m + 1 : m);
+                    st_x(xs, wb_nxt);                    // chunk m + 1 (its buffer was last read in iteration m - 1, one barrier ago)
+                    ld_x(xs, m + 2 < nM ? m + 2 : m);   // (tail iterations reload a chunk they do not use: harmless)
+#pragma unroll
+                    for (int pp = 0; pp < 16; ++pp) {
+                        const f32x4 Bx = *(lds_cf32x4 *)(lds + rb_cur + 512 * pp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Y[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(Acur[e], Bx[e], Y[pp], 0, 0, 0);
+                    }
+                    __syncthreads();
+                    int t = wb_cur; wb_cur = wb_nxt; wb_nxt = t;
+                    t = rb_cur; rb_cur = rb_nxt; rb_nxt = t;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
+                        const int pix = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
+                        f32x4 o = Y[4 * i + j] + b4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix >= 0 ? (pix * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
+                    }
                 }
             }
         }
@@ -510,7 +587,11 @@ namespace idh_conv {
 
 bool wino4_supported(const ConvArgs &a) {
     const ConvSrc &s = a.s[0];
-    return !a.s[1].in && (a.act == IDH_ACT_NONE || a.act == IDH_ACT_LRELU) && s.cblocks >= 2 && s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && a.S == 1 && (a.Cout % 64) == 0 &&
+    const ConvSrc &s1 = a.s[1];
+    // second source: a 1x1 stride-1 projection of a tensor of the output's size (weights in idh_pack_conv_weight's layout), no residual beside it
+    const bool src2_ok = !s1.in || (s1.ks == 1 && s1.stride == 1 && !s1.up_in[0] && !s1.norm && s1.H == a.Ho && s1.W == a.Wo && !a.res &&
+                                    (long long)s1.H * s1.W * s1.cs * 4 < (1ll << 31) && (long long)s1.cblocks * a.Cout_pad * 64 < (1ll << 31));
+    return src2_ok && (a.act == IDH_ACT_NONE || a.act == IDH_ACT_LRELU) && s.cblocks >= 2 && s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && a.S == 1 && (a.Cout % 64) == 0 &&
            (long long)s.H * s.W * s.cs * 4 < (1ll << 30) && (long long)a.Ho * a.Wo * a.out_cs * 4 < (1ll << 31) &&  // (input: the halo offsets advance by up to 8 rows past an out-of-range marker)
            (!a.res || (long long)a.Ho * a.Wo * a.res_cs * 4 < (1ll << 31)) && (long long)s.cblocks * a.Cout_pad * 36 * 16 * 4 < (1ll << 31);
 }
@@ -525,7 +606,8 @@ int launch_conv_wino4(const ConvArgs &a, int N, hipStream_t st) {
     wa.tiles = (int)tiles;
     long long grid = 2ll * wino4_cus();
     if (grid > wa.tiles) grid = wa.tiles >= 8 ? wa.tiles / 8 * 8 : wa.tiles;
-    hipLaunchKernelGGL(conv3x3_wino4_k, dim3((unsigned)grid), dim3(256), 0, st, wa);
+    if (a.s[1].in) hipLaunchKernelGGL(conv3x3_wino4_k<true>, dim3((unsigned)grid), dim3(256), 0, st, wa);
+    else hipLaunchKernelGGL(conv3x3_wino4_k<false>, dim3((unsigned)grid), dim3(256), 0, st, wa);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }

@@ -224,14 +224,19 @@ def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> b
 # grouped launch, which a half-filled grid of F(4x4) tiles does not beat.  Layers with a fused 1x1 projection, ELU or a normalised source
 # stay on F(2x2).
 WINOGRAD4 = True
+WINOGRAD4_PROJ = True  # ... also for the blocks with a fused 1x1 projection (conv3x3_wino4_k<true>)
 WINO4_MIN_TILES = 384
 WINO4_MIN_FILL = 0.85
 
 
 def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act: int) -> bool:
     (v0, c0) = srcs[0]
-    if len(srcs) != 1 or c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64 or isinstance(v0, CatView):
+    if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64 or isinstance(v0, CatView):
         return False
+    if len(srcs) > 1:  # fused second source: BasicBlock's 1x1 stride-1 projection (accumulated in the pixel domain after the output transform)
+        (v1, c1) = srcs[1]
+        if not WINOGRAD4_PROJ or len(srcs) > 2 or c1.kernel_size[0] != 1 or c1.stride[0] != 1 or isinstance(v1, CatView):
+            return False
     if act not in (ACT_NONE, ACT_LRELU) or c0.in_channels <= 16:  # (<= 16: the copy pipeline runs a pair of 8-channel stages ahead)
         return False
     ty, tx = -(-Ho // 8), -(-Wo // 32)
@@ -428,7 +433,7 @@ class Plan:
         use_split = self.math != "fp32" and split_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode)
         use_wino = (WINOGRAD and self.math == "fp32" and norm is None and
                     wino_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode))
-        use_wino4 = (WINOGRAD4 and self.math == "fp32" and norm is None and
+        use_wino4 = (WINOGRAD4 and self.math == "fp32" and norm is None and (x2 is None or res is None) and
                      wino4_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode, act))
         if use_wino4:
             use_wino = False
@@ -447,7 +452,7 @@ class Plan:
                 raise _lib.IdhError("a conv input whose channel count is not a multiple of 16 must be a whole zero-padded buffer")
             if use_split:  # one blob: [3x3 panels][1x1 panels of the second source][scales]
                 w = split_packed_weight(conv, self.math, conv2)
-            elif use_wino4:
+            elif use_wino4 and i == 0:
                 w = packed_wino4_weight(cv)
             elif use_wino and i == 0:
                 w = packed_wino_weight(cv)
@@ -819,7 +824,7 @@ def build_flags() -> tuple:
     """Module-level switches that shape a plan at build time (part of every plan-cache key: toggling one takes effect on the
     next call instead of silently replaying a plan built under the old setting)."""
     return (WINO_GROUP, FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
-            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINO4_MIN_TILES, WINO4_MIN_FILL, DEFAULT_MATH)
+            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINOGRAD4_PROJ, WINO4_MIN_TILES, WINO4_MIN_FILL, DEFAULT_MATH)
 
 
 def _plan_cache(module: nn.Module) -> PlanCache:

@@ -99,17 +99,89 @@ def test_wino4_conv_channel_strided_views(wino4_everywhere):
     assert (wide_out[..., :64] == 7.0).all() and (wide_out[..., 128:] == 7.0).all(), "neighbouring channel slices must stay untouched"
 
 
-def test_wino4_not_taken_for_fused_projection_or_elu(wino4_everywhere):
-    """blocks with a 1x1 projection keep the F(2x2) kernel (its P steps), ELU layers, <= 16 input channels and Cout % 64 != 0 the other kernels"""
+def test_wino4_not_taken_for_elu_narrow_or_thin_layers(wino4_everywhere):
+    """ELU layers, <= 16 input channels, Cout % 64 != 0, a residual beside a projection: the other kernels"""
     nhwc = wino4_everywhere
     conv, proj = nn.Conv2d(64, 64, 3, 1, 1).cuda(), nn.Conv2d(32, 64, 1).cuda()
     x, x2 = torch.randn(1, 32, 64, 64, device="cuda"), torch.randn(1, 32, 64, 32, device="cuda")
     p = nhwc.Plan(x.device)
-    p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=1, x2=nhwc.View(x2, 0, 32), conv2=proj)
     p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=2)
     p.conv(nhwc.View(x, 0, 16), nn.Conv2d(16, 64, 3, 1, 1).cuda(), p.buffer(1, 32, 64, 64), act=1)
     p.conv(nhwc.View(x, 0, 64), nn.Conv2d(64, 32, 3, 1, 1).cuda(), p.buffer(1, 32, 64, 32), act=1)  # not a multiple of 64 output channels
+    p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=1, x2=nhwc.View(x2, 0, 32), conv2=proj, res=nhwc.View(x, 0, 64))
     assert all(op.tile_m != nhwc.TILE_WINO4 for op in p.ops)
+    old, nhwc.WINOGRAD4_PROJ = nhwc.WINOGRAD4_PROJ, False
+    try:
+        p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=1, x2=nhwc.View(x2, 0, 32), conv2=proj)
+    finally:
+        nhwc.WINOGRAD4_PROJ = old
+    assert p.ops[-1].tile_m != nhwc.TILE_WINO4, "WINOGRAD4_PROJ = False leaves the fused projection to the other kernels"
+
+
+# conv2(h) + downsample(x) of a BasicBlock whose channel count changes (reference layers.py:86-92): 3x3 on the F(4x4) kernel, the 1x1 projection
+# of the second tensor accumulated in the pixel domain inside the same launch (conv3x3_wino4_k<true>).  (B, cin, cout, H, W, projected channels, act):
+# the bench's shapes in small, ragged maps, a projection narrower than one 16-channel chunk's padding (24 -> 32), wide outputs, many tiles per workgroup
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 128, 192, 1), (1, 64, 64, 37, 45, 24, 1), (3, 128, 128, 9, 33, 384, 0), (2, 256, 256, 24, 32, 512, 1),
+                                   (1, 32, 64, 8, 32, 16, 1), (1, 64, 64, 5, 17, 48, 1), (40, 64, 64, 48, 128, 128, 1), (24, 64, 128, 40, 72, 112, 1)])
+def test_wino4_conv_with_fused_projection_vs_fp64_and_direct(shape, wino4_everywhere):
+    nhwc = wino4_everywhere
+    B, cin, cout, H, W, c2, act = shape
+    conv, proj = nn.Conv2d(cin, cout, 3, 1, 1).cuda(), nn.Conv2d(c2, cout, 1).cuda()
+    syn.fill_state_dict(conv, seed=cin + cout + H)
+    syn.fill_state_dict(proj, seed=c2 + W)
+    g = torch.Generator(device="cuda").manual_seed(H * W + c2)
+    xb = torch.randn(B, H, W, cin, device="cuda", generator=g)
+    x2b = torch.zeros(B, H, W, nhwc.ceil16(c2), device="cuda")
+    x2b[..., :c2] = torch.randn(B, H, W, c2, device="cuda", generator=g)
+    nb = min(B, 3)
+    ref = F.conv2d(xb[-nb:].permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1)
+    ref = ref + F.conv2d(x2b[-nb:, ..., :c2].permute(0, 3, 1, 2).double(), proj.weight.double(), proj.bias.double())
+    ref = (F.leaky_relu(ref, 0.2) if act == 1 else ref).permute(0, 2, 3, 1)
+    outs = {}
+    for wino4 in (True, False):
+        old = (nhwc.WINOGRAD4, nhwc.WINOGRAD)
+        nhwc.WINOGRAD4, nhwc.WINOGRAD = wino4, False
+        try:
+            p = nhwc.Plan(xb.device)
+            out = p.buffer(B, H, W, cout)
+            p.conv(nhwc.View(xb, 0, cin), conv, out, act=act, slope=0.2, x2=nhwc.View(x2b, 0, c2), conv2=proj)
+        finally:
+            nhwc.WINOGRAD4, nhwc.WINOGRAD = old
+        assert (p.ops[0].tile_m == nhwc.TILE_WINO4) == wino4
+        p.run()
+        p.run()  # persistent kernel state (LDS planes / V buffers shared with the P phase) must not leak between launches
+        torch.cuda.synchronize()
+        outs[wino4] = out.dense().clone()
+    assert torch.isfinite(outs[True]).all()
+    assert rel_err(outs[True][-nb:].cpu(), ref.cpu()) < 2e-5, "F(4x4) + projection vs fp64"
+    assert rel_err(outs[True].cpu(), outs[False].cpu()) < 2e-5, "F(4x4) + projection vs the direct kernel"
+
+
+def test_wino4_projection_reads_a_channel_slice_of_a_wider_buffer(wino4_everywhere):
+    """the projected tensor is the block input, itself a slice of a concat buffer (torch.cat elimination): channel stride != channel count"""
+    nhwc = wino4_everywhere
+    B, H, W = 2, 24, 80
+    conv, proj = nn.Conv2d(64, 64, 3, 1, 1).cuda(), nn.Conv2d(96, 64, 1).cuda()
+    syn.fill_state_dict(conv, seed=5)
+    syn.fill_state_dict(proj, seed=6)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    hbuf = torch.randn(B, H, W, 64, device="cuda", generator=g)
+    wide = torch.randn(B, H, W, 160, device="cuda", generator=g)
+    wide_out = torch.full((B, H, W, 128), 7.0, device="cuda")
+    old = nhwc.WINOGRAD
+    nhwc.WINOGRAD = False
+    try:
+        p = nhwc.Plan(hbuf.device)
+        p.conv(nhwc.View(hbuf, 0, 64), conv, nhwc.View(wide_out, 64, 64), act=1, slope=0.2, x2=nhwc.View(wide, 32, 96), conv2=proj)
+    finally:
+        nhwc.WINOGRAD = old
+    assert p.ops[0].tile_m == nhwc.TILE_WINO4
+    p.run()
+    torch.cuda.synchronize()
+    ref = F.conv2d(hbuf.permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1)
+    ref = F.leaky_relu(ref + F.conv2d(wide[..., 32:128].permute(0, 3, 1, 2).double(), proj.weight.double(), proj.bias.double()), 0.2).permute(0, 2, 3, 1)
+    assert rel_err(wide_out[..., 64:].cpu(), ref.cpu()) < 2e-5
+    assert (wide_out[..., :64] == 7.0).all()
 
 
 def test_networks_with_wino4_forced_match_goldens(wino4_everywhere):

@@ -162,12 +162,12 @@ def test_networks_with_wino_forced_match_goldens(wino_everywhere):
 
 def test_default_plan_uses_wino_at_bench_batch():
     """the default heuristics put the big plain 3x3 stride-1 layers of a batch on a Winograd kernel - F(4x4) where its 32 x 8 x 64-channel
-    tiles fill the chip (>= WINO4_MIN_TILES), F(2x2) for the layers F(4x4) does not take (here: a fused 1x1 projection) - and none at one
+    tiles fill the chip (>= WINO4_MIN_TILES; with or without a fused 1x1 projection), F(2x2) below that - and none at one
     small frame (fewer tiles than resident workgroups)"""
     from implicit_depth_amd import nhwc
 
     conv, proj = nn.Conv2d(64, 64, 3, 1, 1).cuda(), nn.Conv2d(32, 64, 1).cuda()
-    for B, H, W, want, want_proj in ((8, 96, 128, nhwc.TILE_WINO4, nhwc.TILE_WINO), (2, 96, 128, nhwc.TILE_WINO, nhwc.TILE_WINO), (1, 24, 32, None, None)):
+    for B, H, W, want, want_proj in ((8, 96, 128, nhwc.TILE_WINO4, nhwc.TILE_WINO4), (2, 96, 128, nhwc.TILE_WINO, nhwc.TILE_WINO), (1, 24, 32, None, None)):
         x, x2 = torch.randn(B, H, W, 64, device="cuda"), torch.randn(B, H, W, 32, device="cuda")
         p = nhwc.Plan(x.device)
         p.conv(nhwc.View(x, 0, 64), conv, p.buffer(B, H, W, 64))

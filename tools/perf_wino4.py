@@ -13,9 +13,10 @@ from implicit_depth_amd import nhwc
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-# (cin, cout, H, W, residual): residual 0 none, 1 identity residual
+# (cin, cout, H, W, residual): residual 0 none, 1 identity residual, c >= 16: fused 1x1 projection of a c-channel tensor (BasicBlock conv2 + downsample)
 LAYERS = [(64, 64, 192, 256, 0), (64, 64, 192, 256, 1), (192, 64, 192, 256, 0), (64, 64, 96, 128, 1), (192, 64, 96, 128, 0), (128, 128, 48, 64, 1),
-          (384, 128, 48, 64, 0), (256, 256, 24, 32, 1)]
+          (384, 128, 48, 64, 0), (256, 256, 24, 32, 1), (64, 64, 192, 256, 192), (64, 64, 192, 256, 128), (64, 64, 192, 256, 24), (64, 64, 96, 128, 192),
+          (128, 128, 48, 64, 384), (256, 256, 24, 32, 512)]
 sel = os.environ.get("LAYERS")
 if sel:
     LAYERS = [LAYERS[int(i)] for i in sel.split(",")]
@@ -24,14 +25,15 @@ if os.environ.get("VARIANTS"):
     VARIANTS = [v for v in VARIANTS if v[0] in os.environ["VARIANTS"].split(",")]
 
 
-def build(conv, x, res, tm):
+def build(conv, x, res, tm, proj=None, x2=None):
     p = nhwc.Plan(x.device)
     Bn, H, W, cin = x.shape
     out = p.buffer(Bn, H, W, conv.out_channels)
     old = (nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL)
     nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = tm == nhwc.TILE_WINO, tm == nhwc.TILE_WINO4, 1, 1, 0.0
     try:
-        p.conv(nhwc.View(x, 0, cin), conv, out, act=1, slope=0.2, res=None if res is None else nhwc.View(res, 0, conv.out_channels))
+        p.conv(nhwc.View(x, 0, cin), conv, out, act=1, slope=0.2, res=None if res is None else nhwc.View(res, 0, conv.out_channels),
+               x2=None if proj is None else nhwc.View(x2, 0, proj.in_channels), conv2=proj)
     finally:
         nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINO_MIN_TILES, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = old
     op = p.ops[0]
@@ -59,11 +61,19 @@ for (cin, cout, H, W, use_res) in LAYERS:
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.randn(B, H, W, cin, device="cuda", generator=g)
     res = torch.randn(B, H, W, cout, device="cuda", generator=g) if use_res == 1 else None
-    plans = [(name,) + build(conv, x, res, tm) for name, tm in VARIANTS]
+    proj = x2 = None
+    if use_res >= 16:
+        proj = nn.Conv2d(use_res, cout, 1).cuda()
+        syn.fill_state_dict(proj, 2)
+        x2 = torch.zeros(B, H, W, nhwc.ceil16(use_res), device="cuda")
+        x2[..., :use_res] = torch.randn(B, H, W, use_res, device="cuda", generator=g)
+    plans = [(name,) + build(conv, x, res, tm, proj, x2) for name, tm in VARIANTS]
     nb = min(B, 2)
     ref = F.conv2d(x[:nb].permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1)
     if use_res == 1:
         ref = ref + res[:nb].permute(0, 3, 1, 2).double()
+    if proj is not None:
+        ref = ref + F.conv2d(x2[:nb, ..., :use_res].permute(0, 3, 1, 2).double(), proj.weight.double(), proj.bias.double())
     ref = F.leaky_relu(ref, 0.2).permute(0, 2, 3, 1)
     errs = {}
     for name, p, out in plans:
@@ -76,7 +86,7 @@ for (cin, cout, H, W, use_res) in LAYERS:
             for _ in range(3):
                 p.run()
             best[name] = min(best[name], time_plan(p, 10))
-    fl = 2.0 * B * H * W * cout * cin * 9
+    fl = 2.0 * B * H * W * cout * (cin * 9 + (use_res if use_res >= 16 else 0))
     base = best[plans[0][0]]
     print(f"{cin:3d}->{cout:3d} @{H}x{W} B={B} res={use_res}: " + "  ".join(
         f"{name} {best[name] * 1e3:7.1f} us {fl / best[name] / 1e9:6.1f} TF-equiv x{base / best[name]:.2f} err {errs[name]:.1e}" for name, _, _ in plans), flush=True)
