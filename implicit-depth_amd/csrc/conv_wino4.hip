@@ -2,7 +2,8 @@
 //
 // Replaces the same nn.Conv2d calls as conv3x3_wino_k / conv3x3_lds_k (BasicBlock convs, reference modules/layers.py:59-95,
 // the 3x3 stride-1 layers of CVEncoder / BDDecoderPP / DepthDecoderPP, modules/networks.py:20-215) wherever the layer is a plain
-// conv (+ bias, residual, LeakyReLU) with a multiple of 64 output channels and enough tiles to fill the chip.  F(4x4,3x3) needs
+// conv (+ bias, LeakyReLU, and either a residual or BasicBlock's fused 1x1 projection of a second tensor, layers.py:86-92) with a multiple of
+// 64 output channels and enough tiles to fill the chip.  F(4x4,3x3) needs
 // 36 multiplies per 4x4 output tile and channel pair instead of 64 for four F(2x2) tiles (144 direct): 1.78x fewer
 // v_mfma_f32_16x16x4_f32 than conv3x3_wino_k, fp32 operands and fp32 accumulation throughout.
 //
@@ -75,8 +76,10 @@ __device__ __forceinline__ void at6(f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f32x
 //   after a halo copy cannot be used before that copy is back.  So the first copies of a pair are issued at the END of the odd stage's MFMA
 //   loop (rows 0.. of the next stage use A rows issued before that point).
 // * Epilogue: output transform (120 vector ops per channel quad) in registers, + bias + residual, LeakyReLU / identity, 16-byte NHWC stores
-//   (a lane holds 4 consecutive channels of the 4x4 pixels of its tile).
-// Measured (B = 32, profiles/r04/perf_wino4_final.txt): 1.17-1.43x over conv3x3_wino_k on the network's eligible layers.
+//   (a lane holds 4 consecutive channels of the 4x4 pixels of its tile).  conv3x3_wino4_k<true>: between the output transform and the stores the 1x1
+//   projection of a second tensor is accumulated by pixel-domain MFMAs (the "P phase", described where it is written).
+// Measured (B = 32, profiles/r04/perf_wino4_final.txt): 1.11-1.39x over conv3x3_wino_k on the network's plain layers, 1.07-1.25x on the blocks with a
+// fused projection.
 constexpr int kPlane = 432 * 32 + 128;            // 16 (row, column) phases x 3 x 9 texel slots x 32 B (+ 128: consecutive planes land on the other half of the banks)
 constexpr int kVBytes = 2 * 64 * 36 * 4;          // V of one stage: 2 k-steps x 64 lanes x 36 positions
 constexpr int kV0 = 3 * kPlane, kV1 = 3 * kPlane + kVBytes;

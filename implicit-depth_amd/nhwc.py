@@ -221,8 +221,8 @@ def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> b
 # 1.11-1.39x at B = 32 on every eligible layer of the network.  Layer by layer it wins or ties down to ~192 tiles and loses below
 # (96 tiles: 0.6-0.8x), but inside a whole step the threshold that never loses is 384 (bench.py --batch 1 / 4 / 8 / 16 with 192:
 # -5 / -4 / 0 / +1 %; with 384: 0 / +2 / +6 / +7 %; profiles/r04/experiments.md): below it the F(2x2) convs of a UNet++ level share ONE
-# grouped launch, which a half-filled grid of F(4x4) tiles does not beat.  Layers with a fused 1x1 projection, ELU or a normalised source
-# stay on F(2x2).
+# grouped launch, which a half-filled grid of F(4x4) tiles does not beat.  A fused 1x1 projection rides in the same kernel (conv3x3_wino4_k<true>:
+# 1.07-1.25x over F(2x2)'s); layers with ELU or a normalised source stay where they were.
 WINOGRAD4 = True
 WINOGRAD4_PROJ = True  # ... also for the blocks with a fused 1x1 projection (conv3x3_wino4_k<true>)
 WINO4_MIN_TILES = 384
