@@ -239,6 +239,8 @@ def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act
             return False
     if act not in (ACT_NONE, ACT_LRELU) or c0.in_channels <= 16:  # (<= 16: the copy pipeline runs a pair of 8-channel stages ahead)
         return False
+    if getattr(v0, "H", 0) * getattr(v0, "W", 0) * getattr(v0, "cs", 0) * 4 >= 1 << 30:  # (csrc: the halo's 32-bit offsets run a few rows past an image)
+        return False
     ty, tx = -(-Ho // 8), -(-Wo // 32)
     if Ho * Wo < WINO4_MIN_FILL * (ty * 8) * (tx * 32):
         return False

@@ -168,6 +168,13 @@ def test_winograd_kernel_selection_rules():
     assert not nhwc.wino4_eligible([(V(), c64)], 64, 32, 192, 256, nhwc.PAD_ZEROS + 1, L), "replicate padding"
     # tile fill: a 12x16 map covers 12 * 16 of 16 * 32 tile pixels
     assert not nhwc.wino4_eligible([(V(), nn.Conv2d(384, 384, 3, 1, 1))], 384, 64, 12, 16, Z, L)
+    # a 1080p x 192-channel image exceeds the kernel's 1 GiB-per-image bound (32-bit halo offsets): the plan must not pick it
+    big = V()
+    big.H, big.W, big.cs = 1088, 1920, 192
+    assert not nhwc.wino4_eligible([(big, c192)], 64, 4, 1088, 1920, Z, L)
+    ok = V()
+    ok.H, ok.W, ok.cs = 192, 256, 192
+    assert nhwc.wino4_eligible([(ok, c192)], 64, 32, 192, 256, Z, L)
     # what F(4x4) leaves goes to F(2x2) where that one's own rules hold
     assert nhwc.wino_eligible([(V(), c64), (V(), proj)], 64, 32, 192, 256, Z)
     assert nhwc.wino_eligible([(V(), c64)], 64, 4, 96, 128, Z) and not nhwc.wino_eligible([(V(), c64)], 64, 1, 24, 32, Z)
