@@ -223,6 +223,9 @@ def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> b
 # -5 / -4 / 0 / +1 %; with 384: 0 / +2 / +6 / +7 %; profiles/r04/experiments.md): below it the F(2x2) convs of a UNet++ level share ONE
 # grouped launch, which a half-filled grid of F(4x4) tiles does not beat.  A fused 1x1 projection rides in the same kernel (conv3x3_wino4_k<true>:
 # 1.07-1.25x over F(2x2)'s); layers with ELU or a normalised source stay where they were.
+# activation-buffer liveness reuse (Plan.release): BasicBlock intermediates of >= REUSE_MIN_BYTES are recycled by later blocks of the same shape
+BUFFER_REUSE = True
+REUSE_MIN_BYTES = 64 << 20
 WINOGRAD4 = True
 WINOGRAD4_PROJ = True  # ... also for the blocks with a fused 1x1 projection (conv3x3_wino4_k<true>)
 WINO4_MIN_TILES = 384
@@ -408,6 +411,7 @@ class Plan:
         self.ops: List[Op] = []
         self.meta: List[dict] = []  # per op: regions read / written, for the level scheduler
         self.keep: List[torch.Tensor] = []  # buffers / packed weights referenced by raw pointer
+        self._free: Dict[tuple, List[torch.Tensor]] = {}  # released buffers by shape (``release``)
         self._arr = None
         self._pos: Optional[List[int]] = None  # op index at build time -> index after schedule()
         self.flops = 0  # 2*MAC of the conv ops (algorithmic, no padding)
@@ -417,10 +421,24 @@ class Plan:
         """Dense NHWC buffer.  The conv kernel reads whole 16-channel blocks, so channel counts
         that are not a multiple of 16 get zero-filled padding channels (written by nobody)."""
         cs = ceil16(Cch)
+        pool = self._free.get((N, H, W, cs)) if cs == Cch else None
+        if pool:
+            return View(pool.pop(), 0, Cch)
         alloc = torch.zeros if cs != Cch else torch.empty
         t = alloc(N, H, W, cs, device=self.device, dtype=torch.float32)
         self.keep.append(t)
         return View(t, 0, Cch)
+
+    def release(self, v: View):
+        """Liveness reuse of activation memory: the caller will record no further op that touches ``v`` (a whole buffer of this plan), so a
+        later ``buffer()`` of the same shape may alias it.  Safe under the level scheduler by construction — the op regions are keyed by
+        the tensor, so the new writer gets a write-after-read dependency on the last reader — but that dependency also serialises blocks
+        that used to share a dependency level, which small grids need for their grouped launches: only buffers of at least
+        ``REUSE_MIN_BYTES`` (ops that fill the chip on their own) are pooled."""
+        t = v.buf
+        if (BUFFER_REUSE and v.c0 == 0 and v.C == t.shape[-1] and t.dim() == 4 and t.numel() * 4 >= REUSE_MIN_BYTES
+                and any(t is k for k in self.keep)):
+            self._free.setdefault(tuple(t.shape), []).append(t)
 
     # ops -----------------------------------------------------------------------------
     def conv(self, x: View, conv: nn.Conv2d, out: View, act=ACT_NONE, slope=0.2, res: Optional[View] = None,
@@ -666,6 +684,7 @@ class Plan:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=proj)
         else:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, x2=x, conv2=blk.downsample[0])
+        self.release(h)  # the block's intermediate dies with conv2
         return out
 
     # scheduling ----------------------------------------------------------------------
@@ -826,7 +845,7 @@ def build_flags() -> tuple:
     """Module-level switches that shape a plan at build time (part of every plan-cache key: toggling one takes effect on the
     next call instead of silently replaying a plan built under the old setting)."""
     return (WINO_GROUP, FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
-            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINOGRAD4_PROJ, WINO4_MIN_TILES, WINO4_MIN_FILL, DEFAULT_MATH)
+            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINOGRAD4_PROJ, WINO4_MIN_TILES, WINO4_MIN_FILL, BUFFER_REUSE, REUSE_MIN_BYTES, DEFAULT_MATH)
 
 
 def _plan_cache(module: nn.Module) -> PlanCache:
@@ -959,11 +978,16 @@ def build_decoder(p: Plan, dec, feats: List[View]):
                 if (lo.H * 2, lo.W * 2) != (xi.H, xi.W):
                     raise _lib.IdhError("decoder pyramid levels must differ by exactly x2")
                 p.upsample2(lo, cat.slice(cout, cout))
+                p.release(lo)  # (liveness reuse: these temporaries have no reader after this point)
                 if has_up:
                     lo2 = p.basic_block(outputs[-1], dec.convs[f"up_conv_{i + 1}{j}"])
                     p.upsample2(lo2, cat.slice(2 * cout, cout))
-            y = p.basic_block(cat, seq[0])
-            y = p.basic_block(y, seq.conv_0)
+                    p.release(lo2)
+            y0 = p.basic_block(cat, seq[0])
+            if isinstance(cat, View):
+                p.release(cat)
+            y = p.basic_block(y0, seq.conv_0)
+            p.release(y0)
             outputs.append(y)
             if j == 4 - i:  # the only (i,j) whose output_i result survives in the dict
                 head = dec.convs[f"output_{i}"]
@@ -1089,6 +1113,7 @@ def _conv_block(p: Plan, x: View, blk, out: Optional[View] = None) -> View:
     if out is None:
         out = p.buffer(x.N, x.H, x.W, blk.conv2.out_channels)
     p.conv(h, blk.conv2, out, act=act, slope=slope)
+    p.release(h)
     return out
 
 

@@ -178,3 +178,38 @@ def test_winograd_kernel_selection_rules():
     # what F(4x4) leaves goes to F(2x2) where that one's own rules hold
     assert nhwc.wino_eligible([(V(), c64), (V(), proj)], 64, 32, 192, 256, Z)
     assert nhwc.wino_eligible([(V(), c64)], 64, 4, 96, 128, Z) and not nhwc.wino_eligible([(V(), c64)], 64, 1, 24, 32, Z)
+
+
+def test_plan_buffer_liveness_reuse_rules():
+    """Plan.release / Plan.buffer (host logic): a released whole buffer of >= REUSE_MIN_BYTES is handed out again for the same shape, once;
+    small buffers (whose ops need their dependency level for grouped launches), channel-padded buffers (zero padding written by nobody),
+    slices and foreign tensors are not pooled.  The scheduler orders the new writer after the old readers through the shared tensor id."""
+    import torch
+
+    from implicit_depth_amd import nhwc
+
+    p = nhwc.Plan(torch.device("cpu"))
+    old = nhwc.REUSE_MIN_BYTES
+    nhwc.REUSE_MIN_BYTES = 1 << 16
+    try:
+        big = p.buffer(2, 32, 32, 16)  # 128 KiB
+        p.release(big)
+        again = p.buffer(2, 32, 32, 16)
+        assert again.buf is big.buf, "same shape: recycled"
+        assert p.buffer(2, 32, 32, 16).buf is not big.buf, "... once"
+        small = p.buffer(1, 8, 8, 16)  # 4 KiB
+        p.release(small)
+        assert p.buffer(1, 8, 8, 16).buf is not small.buf
+        padded = p.buffer(2, 32, 32, 24)  # 24 -> 32 channels with zero padding
+        p.release(padded)
+        assert p.buffer(2, 32, 32, 24).buf is not padded.buf
+        whole = p.buffer(2, 32, 32, 32)
+        p.release(whole.slice(0, 16))
+        assert p.buffer(2, 32, 32, 32).buf is not whole.buf, "a slice does not release its buffer"
+        foreign = nhwc.View(torch.empty(2, 32, 32, 16), 0, 16)
+        p.release(foreign)
+        assert p.buffer(2, 32, 32, 16).buf is not foreign.buf
+        # regions are keyed by the tensor: a recycled buffer carries its readers' dependencies to the next writer
+        assert nhwc._overlap([nhwc._region(big)], [nhwc._region(again)])
+    finally:
+        nhwc.REUSE_MIN_BYTES = old
