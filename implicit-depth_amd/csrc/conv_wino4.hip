@@ -75,7 +75,7 @@ __device__ __forceinline__ void at6(f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f32x
 // * Vector loads complete in order, and the halo comes from HBM (~3k cycles under load) while the A rows come from L2: an A row issued
 //   after a halo copy cannot be used before that copy is back.  So the first copies of a pair are issued at the END of the odd stage's MFMA
 //   loop (rows 0.. of the next stage use A rows issued before that point).
-// * Epilogue: output transform (120 vector ops per channel quad) in registers, + bias + residual, LeakyReLU / identity, 16-byte NHWC stores
+// * Epilogue: output transform (120 vector ops per channel quad) in registers, + bias + residual, LeakyReLU / ELU / identity, 16-byte NHWC stores
 //   (a lane holds 4 consecutive channels of the 4x4 pixels of its tile).  conv3x3_wino4_k<true>: between the output transform and the stores the 1x1
 //   projection of a second tensor is accumulated by pixel-domain MFMAs (the "P phase", described where it is written).
 // Measured (B = 32, profiles/r04/perf_wino4_final.txt): 1.11-1.39x over conv3x3_wino_k on the network's plain layers, 1.07-1.25x on the blocks with a
@@ -458,6 +458,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
             const int oy0 = cur.y0 + 4 * ty, ox0 = cur.x0 + 4 * tx;
             const bool has_res = a.res != nullptr;
             const float slope_eff = a.act == IDH_ACT_LRELU ? a.slope : 1.f;
+            // nn.ELU(alpha = 1) as torch's kernel forms it, exp(x) - 1, with the exponential through v_exp_f32 (as csrc/mlp.hip: |err| ~1e-7 absolute)
+            const bool elu = a.act == IDH_ACT_ELU;
             const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 4 * h) * 4, 0, 0));
             // M[xi][nu] = acc[p'(xi, nu)]
             auto M = [&](int xi, int nu) -> f32x4 & { return acc[9 * (2 * (xi / 3) + nu / 3) + 3 * (xi % 3) + nu % 3]; };
@@ -486,6 +488,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
                         f32x4 o = y[i] + b4 + r[i];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        if (elu) {  // (wave-uniform; the LeakyReLU / identity path above costs ELU layers 8 idle operations, the others nothing)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? __expf(o[e]) - 1.0f : o[e];
+                        }
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
                     }
                 }
@@ -558,6 +564,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
                         f32x4 o = Y[4 * i + j] + b4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        if (elu) {  // (wave-uniform; the LeakyReLU / identity path above costs ELU layers 8 idle operations, the others nothing)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? __expf(o[e]) - 1.0f : o[e];
+                        }
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix >= 0 ? (pix * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
                     }
                 }
@@ -594,7 +604,7 @@ bool wino4_supported(const ConvArgs &a) {
     // second source: a 1x1 stride-1 projection of a tensor of the output's size (weights in idh_pack_conv_weight's layout), no residual beside it
     const bool src2_ok = !s1.in || (s1.ks == 1 && s1.stride == 1 && !s1.up_in[0] && !s1.norm && s1.H == a.Ho && s1.W == a.Wo && !a.res &&
                                     (long long)s1.H * s1.W * s1.cs * 4 < (1ll << 31) && (long long)s1.cblocks * a.Cout_pad * 64 < (1ll << 31));
-    return src2_ok && (a.act == IDH_ACT_NONE || a.act == IDH_ACT_LRELU) && s.cblocks >= 2 && s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && a.S == 1 && (a.Cout % 64) == 0 &&
+    return src2_ok && (a.act == IDH_ACT_NONE || a.act == IDH_ACT_LRELU || a.act == IDH_ACT_ELU) && s.cblocks >= 2 && s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && a.S == 1 && (a.Cout % 64) == 0 &&
            (long long)s.H * s.W * s.cs * 4 < (1ll << 30) && (long long)a.Ho * a.Wo * a.out_cs * 4 < (1ll << 31) &&  // (input: the halo offsets advance by up to 8 rows past an out-of-range marker)
            (!a.res || (long long)a.Ho * a.Wo * a.res_cs * 4 < (1ll << 31)) && (long long)s.cblocks * a.Cout_pad * 36 * 16 * 4 < (1ll << 31);
 }

@@ -222,7 +222,7 @@ def wino_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> b
 # (96 tiles: 0.6-0.8x), but inside a whole step the threshold that never loses is 384 (bench.py --batch 1 / 4 / 8 / 16 with 192:
 # -5 / -4 / 0 / +1 %; with 384: 0 / +2 / +6 / +7 %; profiles/r04/experiments.md): below it the F(2x2) convs of a UNet++ level share ONE
 # grouped launch, which a half-filled grid of F(4x4) tiles does not beat.  A fused 1x1 projection rides in the same kernel (conv3x3_wino4_k<true>:
-# 1.07-1.25x over F(2x2)'s); layers with ELU or a normalised source stay where they were.
+# 1.07-1.25x over F(2x2)'s); layers with a normalised source stay where they were.
 # activation-buffer liveness reuse (Plan.release): BasicBlock intermediates of >= REUSE_MIN_BYTES are recycled by later blocks of the same shape
 BUFFER_REUSE = True
 REUSE_MIN_BYTES = 64 << 20
@@ -240,7 +240,7 @@ def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act
         (v1, c1) = srcs[1]
         if not WINOGRAD4_PROJ or len(srcs) > 2 or c1.kernel_size[0] != 1 or c1.stride[0] != 1 or isinstance(v1, CatView):
             return False
-    if act not in (ACT_NONE, ACT_LRELU) or c0.in_channels <= 16:  # (<= 16: the copy pipeline runs a pair of 8-channel stages ahead)
+    if act not in (ACT_NONE, ACT_LRELU, ACT_ELU) or c0.in_channels <= 16:  # (<= 16: the copy pipeline runs a pair of 8-channel stages ahead)
         return False
     if getattr(v0, "H", 0) * getattr(v0, "W", 0) * getattr(v0, "cs", 0) * 4 >= 1 << 30:  # (csrc: the halo's 32-bit offsets run a few rows past an image)
         return False

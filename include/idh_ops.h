@@ -134,7 +134,7 @@ int idh_pack_conv_weight_wino(const float *w_oihw, float *dst, int Cout, int Cin
  * tile_m = IDH_TILE_WINO4; src[0].w = the output of idh_pack_conv_weight_wino4 (U = G g G^T per (co, ci) in MFMA A-fragment order:
  * [Cin_pad/8][Cout_pad/16][k-step 2][position group 9][lane 64][4], positions quadrant-major, ci = 8 stage + 2 (lane >> 4) + k-step);
  * 32 x 8 pixel x 64 channel tiles, the input transform shared through LDS by the four 16-channel waves of a tile, two persistent
- * workgroups per CU.  Shape family: 3x3, stride 1, zero padding, Cin > 16, Cout % 64 == 0, split_k == 1, act NONE / LRELU; src[1] may be
+ * workgroups per CU.  Shape family: 3x3, stride 1, zero padding, Cin > 16, Cout % 64 == 0, split_k == 1, act NONE / LRELU / ELU; src[1] may be
  * a 1x1 stride-1 projection of a tensor of the output's size (weights packed by idh_pack_conv_weight as usual; then res must be NULL);
  * anything else: IDH_EUNSUPPORTED.  Error against fp64 ~2-7e-6 of
  * the output scale (direct kernel ~1e-6, F(2x2) ~4e-7).  (ABI 101 had a register-transform kernel under this code with another

@@ -72,6 +72,20 @@ def test_wino4_conv_vs_fp64_and_direct(shape, wino4_everywhere):
     assert rel_err(yw.cpu(), yd.cpu()) < 2e-5, "F(4x4) kernel vs direct kernel"
 
 
+def test_wino4_conv_elu_matches_torch(wino4_everywhere):
+    """ConvBlock's ELU (reference networks_fast.py:10-28) in the F(4x4) epilogue: exp(x) - 1 as torch's kernel forms it"""
+    nhwc = wino4_everywhere
+    B, cin, cout, H, W = 2, 64, 64, 24, 40
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).cuda()
+    syn.fill_state_dict(conv, seed=9)
+    xb = torch.randn(B, H, W, cin, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 2.0
+    ref = F.elu(F.conv2d(xb.permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double(), padding=1)).permute(0, 2, 3, 1)
+    yw = _run(nhwc, conv, xb, None, 2, 0.2, True)
+    yd = _run(nhwc, conv, xb, None, 2, 0.2, False)
+    assert (ref < 0).float().mean() > 0.2, "the test data must exercise the negative branch"
+    assert rel_err(yw.cpu(), ref.cpu()) < 2e-5 and rel_err(yw.cpu(), yd.cpu()) < 2e-5
+
+
 def test_wino4_conv_channel_strided_views(wino4_everywhere):
     """input = channel slice of a wider concat buffer, output = slice of another, residual strided too (torch.cat elimination)"""
     nhwc = wino4_everywhere
@@ -99,13 +113,12 @@ def test_wino4_conv_channel_strided_views(wino4_everywhere):
     assert (wide_out[..., :64] == 7.0).all() and (wide_out[..., 128:] == 7.0).all(), "neighbouring channel slices must stay untouched"
 
 
-def test_wino4_not_taken_for_elu_narrow_or_thin_layers(wino4_everywhere):
-    """ELU layers, <= 16 input channels, Cout % 64 != 0, a residual beside a projection: the other kernels"""
+def test_wino4_not_taken_for_narrow_or_thin_layers(wino4_everywhere):
+    """<= 16 input channels, Cout % 64 != 0, a residual beside a projection: the other kernels"""
     nhwc = wino4_everywhere
     conv, proj = nn.Conv2d(64, 64, 3, 1, 1).cuda(), nn.Conv2d(32, 64, 1).cuda()
     x, x2 = torch.randn(1, 32, 64, 64, device="cuda"), torch.randn(1, 32, 64, 32, device="cuda")
     p = nhwc.Plan(x.device)
-    p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=2)
     p.conv(nhwc.View(x, 0, 16), nn.Conv2d(16, 64, 3, 1, 1).cuda(), p.buffer(1, 32, 64, 64), act=1)
     p.conv(nhwc.View(x, 0, 64), nn.Conv2d(64, 32, 3, 1, 1).cuda(), p.buffer(1, 32, 64, 32), act=1)  # not a multiple of 64 output channels
     p.conv(nhwc.View(x, 0, 64), conv, p.buffer(1, 32, 64, 64), act=1, x2=nhwc.View(x2, 0, 32), conv2=proj, res=nhwc.View(x, 0, 64))

@@ -137,8 +137,8 @@ def test_state_dict_load_into_an_unwatched_child_invalidates_and_modules_pickle(
 
 def test_winograd_kernel_selection_rules():
     """nhwc.wino4_eligible / wino_eligible (host logic, no kernel runs): F(4x4) takes the plain 3x3 stride-1 zero-padded layers with
-    Cout % 64 == 0, > 16 input channels, LeakyReLU / no activation and >= WINO4_MIN_TILES tiles of 32 x 8 pixels x 64 channels that fill
-    the map, with or without a fused 1x1 projection; ELU layers, narrow outputs and small grids are left to F(2x2) / the direct kernels
+    Cout % 64 == 0, > 16 input channels, LeakyReLU / ELU / no activation and >= WINO4_MIN_TILES tiles of 32 x 8 pixels x 64 channels that fill
+    the map, with or without a fused 1x1 projection; narrow outputs and small grids are left to F(2x2) / the direct kernels
     (the thresholds are measured: profiles/r04/experiments.md 1b)."""
     from torch import nn
 
@@ -161,7 +161,8 @@ def test_winograd_kernel_selection_rules():
     # shape family
     assert nhwc.wino4_eligible([(V(), c64), (V(), proj)], 64, 32, 192, 256, Z, L), "fused 1x1 projection: conv3x3_wino4_k<true>"
     assert not nhwc.wino4_eligible([(V(), c64), (V(), s2)], 64, 32, 192, 256, Z, L), "a 3x3 second source"
-    assert not nhwc.wino4_eligible([(V(), c64)], 64, 32, 192, 256, Z, E), "ELU"
+    assert nhwc.wino4_eligible([(V(), c64)], 64, 32, 192, 256, Z, E), "ELU (ConvBlock) is in the epilogue"
+    assert not nhwc.wino4_eligible([(V(), c64)], 64, 32, 192, 256, Z, 7), "an unknown activation code"
     assert not nhwc.wino4_eligible([(V(), c16)], 64, 32, 192, 256, Z, L), "<= 16 input channels"
     assert not nhwc.wino4_eligible([(V(), c32)], 32, 32, 192, 256, Z, L), "Cout % 64"
     assert not nhwc.wino4_eligible([(V(), s2)], 64, 32, 96, 128, Z, L), "stride 2"
