@@ -454,16 +454,20 @@ class HotPathWorkload:
         executed = (vox // 16) * (32 * self.K + 120 + 256 + 64 / self.D) * 2048
         n_in = self.C * (self.K + 1) + 10 * self.K + 4
         algorithmic = 2 * vox * (n_in * 128 + 128 * 128 + 128)
-        busy = None
-        try:
-            rows = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_mfma_util_hot_path_mlp_b32.json")))
+        busy = busy_src = None
+        try:  # the newest round's committed PMC pass (profiles/rNN/pmc_mfma_util_hot_path_mlp_b32.json)
+            import glob
+
+            busy_src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_mfma_util_hot_path_mlp_b32.json")))[-1]
+            rows = json.load(open(busy_src))
             busy = next(r["mfma_util"] for r in rows if r["kernel"] == f"fv_mlp_k<{self.K}>") if (self.B, self.K, self.D) == (32, 7, 64) else None
+            busy_src = os.path.relpath(busy_src, ROOT)
         except Exception:
             pass
         return {"kernel": f"fv_mlp_k<{self.K}>", "ms": ms, "bound": "mfma", "achieved": executed / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": executed / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "executed_flops_per_launch": executed,
                 "algorithmic_flops_per_launch": algorithmic, "achieved_algorithmic": algorithmic / (ms * 1e-3) / 1e12,
-                "mfma_busy": busy, "mfma_busy_source": "profiles/r03/pmc_mfma_util_hot_path_mlp_b32.json (SQ_VALU_MFMA_BUSY_CYCLES pass)" if busy else None,
+                "mfma_busy": busy, "mfma_busy_source": f"{busy_src} (SQ_VALU_MFMA_BUSY_CYCLES pass)" if busy else None,
                 "frames_per_launch": self.B}
 
     def metrics(self):
@@ -737,12 +741,6 @@ def main():
                                          "achieved_algorithmic": all_fl / (all_ms * 1e-3) / 1e12, "launches_per_step": all_n, "ms_per_step": all_ms,
                                          "executed_flops_per_step": all_ex, "algorithmic_flops_per_step": all_fl},
                     "step_ms_hip_events": kernel_ms}
-            if wl.dominant_kernel == "conv3x3_wino4_k<false>":
-                # F(4x4) executes 36/64 of the multiplies F(2x2) needs for the same outputs: `frac` (matrix-pipe utilisation) is not comparable
-                # with earlier rounds' F(2x2) figure; this is the same time priced with the flops conv3x3_wino_k would execute for these launches
-                roof["f2x2_equivalent"] = {"achieved": achieved * 64 / 36, "frac": achieved * 64 / 36 / peak,
-                                           "note": "the dominant launches priced with Winograd F(2x2)'s executed flops (64 instead of 36 multiplies per 4x4 outputs "
-                                                   "and channel pair): comparable with rounds 2-3's roofline.frac of conv3x3_wino_k (0.674)"}
             if math != "fp32":
                 roof["peak_note"] = (f"fp32-equivalent flops; peak = {MFMA_16BIT_PEAK_TFLOPS:.0f} TFLOP/s dense 16-bit MFMA / "
                                      "3 products per MAC; the fp32-MFMA peak is 157.3")

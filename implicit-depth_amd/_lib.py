@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDH_LIB") or os.path.join(_HERE, "lib", "libidh.so")
 
 _lib = None
+MIN_ABI_VERSION = 103
 
 f32p = C.c_void_p  # device pointers travel as integers
 
@@ -118,6 +119,13 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
+        # the ABI this mirror was written against (include/idh.h): struct layouts, tile codes and packed-weight layouts changed at these versions
+        # (102: IDH_TILE_WINO4 names the shared-transform F(4x4) kernel and ITS packed layout - blobs packed by an older library are not portable)
+        ver = h.idh_version()
+        if ver < MIN_ABI_VERSION:
+            raise IdhError(f"{LIB_PATH} reports ABI version {ver}, this binding needs >= {MIN_ABI_VERSION}: rebuild with `python implicit-depth_amd/build.py --force`")
+        if h.idh_sizeof_volume_opts() != C.sizeof(VolumeOpts):
+            raise IdhError(f"{LIB_PATH}: sizeof(idh_volume_opts) = {h.idh_sizeof_volume_opts()} in the library, {C.sizeof(VolumeOpts)} in this binding")
         _lib = h
     return _lib
 

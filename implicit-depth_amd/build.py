@@ -18,10 +18,14 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "_obj")
 LIB = os.path.join(LIBDIR, "libidh.so")
 
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: only what include/*.h declares (under `#pragma GCC visibility push(default)`) is exported
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # per-source extras.  conv_wino4: the SLP vectoriser packs the scalar transform FMAs into v_pk_fma_f32 behind v_mov shuffles (98 moves
 # and 3 scratch reloads per two K stages; packed fp32 math is no faster than scalar beside fp32 MFMAs on gfx950)
-EXTRA_FLAGS = {"conv_wino4.hip": ["-fno-slp-vectorize"]}
+# -amdgpu-prealloc-sgpr-spill-vgprs: the lanes that take spilled scalars are reserved before vector allocation; without it the late reservation
+# fragments the file and the two staging quads held across the transform end up in scratch (tools/kernel_resources.py: 36 -> 8 B/lane, the 8 inside
+# the epilogue)
+EXTRA_FLAGS = {"conv_wino4.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-prealloc-sgpr-spill-vgprs"]}
 
 
 def _hipcc() -> str:

@@ -1,6 +1,7 @@
 #include "idh_common.h"
 
-extern "C" int idh_version(void) { return 102; }  // 101: idh_volume_opts.scratch / scratch_floats / struct_size; 102: Winograd F(4x4) conv (IDH_TILE_WINO4)
+extern "C" int idh_version(void) { return 103; }  // 101: idh_volume_opts.scratch / scratch_floats / struct_size; 102: Winograd F(4x4) conv (IDH_TILE_WINO4);
+                                                   // 103: struct_size accepted when >= the fields it guards, hidden visibility (the C ABI is the only export)
 extern "C" size_t idh_sizeof_volume_opts(void) { return sizeof(idh_volume_opts); }
 
 extern "C" const char *idh_error_string(int code) {

@@ -47,6 +47,14 @@ struct Wino4Args {
 __device__ __forceinline__ f32x4 fma4(float s, f32x4 x, f32x4 y) {
     return (f32x4){__builtin_fmaf(s, x[0], y[0]), __builtin_fmaf(s, x[1], y[1]), __builtin_fmaf(s, x[2], y[2]), __builtin_fmaf(s, x[3], y[3])};
 }
+// the lane id read afresh (two v_mbcnt): per-tile lane constants (halo offsets, the epilogue's pixel / channel offsets) are derived from THIS instead of
+// from values computed once at kernel entry, which hipcc keeps live across the stage loop - at 256 VGPRs that means scratch, and a scratch reload in
+// front of a batch of loads waits, through the in-order vmcnt, for every global load in flight (profiles/r04/experiments.md section 4)
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 // 1-D output transform A^T (6 -> 4): 12 vector operations
 __device__ __forceinline__ void at6(f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f32x4 m4, f32x4 m5, f32x4 &y0, f32x4 &y1, f32x4 &y2, f32x4 &y3) {
     const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
@@ -215,8 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
     const int row_pair = s.W * s.cs * 8;  // bytes of two image rows
     auto set_halo_cursor = [&](const Tile &t) {
         rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)t.img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));  // (re-derived per tile rather than spilled: see conv_wino.hip)
+        const int tid_o = 64 * wave + fresh_lane();  // (re-derived per tile rather than spilled: see fresh_lane)
         const int gr = tid_o & 3;
         {
             const int iy = t.y0 - 1 + (tid_o >> 7), ix = t.x0 - 1 + ((tid_o >> 2) & 31);
@@ -237,24 +244,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, voffH1, __builtin_amdgcn_readfirstlane(32 * ch), 0));
     };
     // LDS address of copy k of this thread in the plane pair (offA: granules 0, 1; offB: granules 2, 3)
-    int wdst0, wdst1;
+    int wdst0;
     {
         const int wq = tid & 1, rr = tid >> 7, col = (tid >> 2) & 31;
         wdst0 = 32 * (108 * rr + 27 * (col & 3) + (col >> 2)) + 16 * wq;
-        const int e = tid >> 2, r = e >> 1;
-        wdst1 = 32 * (((4 * (r & 3) + (e & 1)) * 3 + (r >> 2)) * 9 + 8) + 16 * (wq ^ ((r >> 2) & 1));
     }
     const bool wselB = (tid >> 1) & 1;
     auto st_halo = [&](int k, f32x4 v, int offA, int offB) {
         const int off = wselB ? offB : offA;
         if (k < 5) *(lds_f32x4 *)(lds + ((off + wdst0) ^ (((k >> 1) & 1) << 4)) + 32 * (216 * (k & 1) + 9 * (k >> 1))) = v;  // row 2k + rr: rm = 2 (k & 1) + rr, R = k >> 1
-        else if (tid < 80) *(lds_f32x4 *)(lds + off + wdst1) = v;
+        else if (wave < 2) {  // (threads 0..79; the address of the one copy per stage pair that needs it is derived on the spot: see fresh_lane)
+            const int t = 64 * wave + fresh_lane();
+            if (t < 80) {
+                const int e = t >> 2, r = e >> 1;
+                *(lds_f32x4 *)(lds + off + 32 * (((4 * (r & 3) + (e & 1)) * 3 + (r >> 2)) * 9 + 8) + 16 * ((t & 1) ^ ((r >> 2) & 1))) = v;
+            }
+        }
     };
 
     // ---- this lane's raw-patch read bases: element (i, c) of tile (ty, tx): texel p = ((4 (i & 3) + (c & 3)) * 3 + ty + (i >> 2)) * 9 + tx + (c >> 2); channels 2h, 2h+1
-    int rbase[2];  // [i >> 2]
-#pragma unroll
-    for (int di = 0; di < 2; ++di) rbase[di] = 32 * (9 * ty + tx) + 16 * ((h >> 1) ^ ((ty + di) & 1)) + 8 * (h & 1);
+    const int rbase = 32 * (9 * ty + tx) + 16 * ((h >> 1) ^ (ty & 1)) + 8 * (h & 1);  // rows i < 4; rows 4, 5 (R + 1): the granule bit flips (^ 16)
     const int vbase = lane * 144;  // V[ks][lane][36]: 144 B per lane (36-dword stride: conflict-free ds_read_b128)
     const int qa = wave >> 1, qb = wave & 1;  // this wave's quadrant of positions: xi = 3 qa .., nu = 3 qb ..
 
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
     auto transform = [&](auto hic, auto hjc, int hoff, int vbuf) {
         constexpr bool HI_I = decltype(hic)::value, HI_J = decltype(hjc)::value;
         constexpr int I0 = HI_I ? 1 : 0, J0 = HI_J ? 1 : 0;
-        const int rb[2] = {rbase[0] + hoff, rbase[1] + hoff};
+        const int rb[2] = {rbase + hoff, (rbase ^ 16) + hoff};
         auto rd = [&](int i, int c) -> f32x2 { return *(lds_cf32x2 *)(lds + rb[i >> 2] + 32 * (((4 * (i & 3) + (c & 3)) * 3 + (i >> 2)) * 9 + (c >> 2))); };
         f32x2 d[2][5];
 #pragma unroll
@@ -325,6 +334,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 #ifdef IDH_ABL_W4_NOA
         Af[slot] = (f32x4){1.f, 2.f, 3.f, 4.f};
         return;
+#endif
+#ifdef IDH_ABL_W4_HALFA  // (timing experiment: every second A row is not fetched - what would sharing each row between two waves be worth at most?)
+        if ((so >> 10) & 1) return;
 #endif
         Af[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffA, so, 0));
     };
@@ -451,13 +463,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
         for (int p = 0; p < 36; ++p) asm volatile("" ::"v"(acc[p]));
 #else
         {
+            const int lane_e = fresh_lane(), tid_e = 64 * wave + lane_e;
+            const int n = lane_e & 15, h = lane_e >> 4, ty = n >> 3, tx = n & 7;  // (shadow the kernel-entry values: see fresh_lane)
+            (void)tid_e;
             const int n0 = 16 * cbw;
             const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)cur.img * a.Ho * a.Wo * a.out_cs, 0, a.Ho * a.Wo * a.out_cs * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)cur.img * a.Ho * a.Wo * a.res_cs : a.out), 0,
                                                                                   a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
             const int oy0 = cur.y0 + 4 * ty, ox0 = cur.x0 + 4 * tx;
             const bool has_res = a.res != nullptr;
-            const float slope_eff = a.act == IDH_ACT_LRELU ? a.slope : 1.f;
+            const float slope_eff = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(a.act == IDH_ACT_LRELU ? __builtin_bit_cast(int, a.slope) : 0x3f800000));  // (scalar register)
             // nn.ELU(alpha = 1) as torch's kernel forms it, exp(x) - 1, with the exponential through v_exp_f32 (as csrc/mlp.hip: |err| ~1e-7 absolute)
             const bool elu = a.act == IDH_ACT_ELU;
             const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 4 * h) * 4, 0, 0));
@@ -480,7 +495,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
                     if (has_res) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
+#ifdef IDH_ABL_W4_EPILIN  // (timing experiment: residual loads / stores of a wave cover 8 FULL cache lines per instruction instead of 16 half lines: bound for an LDS-transposed epilogue)
+                            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, ((cur.y0 / 8 * wa.tiles_x + cur.x0 / 32) * 64 + (4 * i + j) * 4 + wave) * 1024 + lane_e * 16, 0, 0));
+#else
                             r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pix[i] >= 0 ? (pix[i] * a.res_cs + n0 + 4 * h) * 4 : kOob, 0, 0));
+#endif
                     }
                     at6(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], y[0], y[1], y[2], y[3]);
 #pragma unroll
@@ -492,7 +511,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? __expf(o[e]) - 1.0f : o[e];
                         }
+#ifdef IDH_ABL_W4_EPILIN
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, ((cur.y0 / 8 * wa.tiles_x + cur.x0 / 32) * 64 + (4 * i + j) * 4 + wave) * 1024 + lane_e * 16, 0, 0);
+#else
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
+#endif
                     }
                 }
             } else {
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
                 // copies: thread t, round r: pixel (row 2 r + (t >> 7), column (t >> 2) & 31) of the 32 x 8 tile group, channel quad t & 3 (64 contiguous bytes per
                 // pixel); its tile is 8 (r >> 1) + (column >> 2), its pixel of the tile 4 (2 (r & 1) + (t >> 7)) + (column & 3)
                 int voffX[4];
-                const int hq = tid & 3, xx = (tid >> 2) & 31, t7 = tid >> 7;
+                const int hq = tid_e & 3, xx = (tid_e >> 2) & 31, t7 = tid_e >> 7;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int iy = cur.y0 + 2 * r + t7, ix = cur.x0 + xx;

@@ -19,6 +19,7 @@
 // cost volume is written exactly once.  (cv_dot_k below keeps this one-lane-per-tap form; the launcher
 // prefers cv_dot_quad_k, the quad-coalesced form further down, whenever 32-bit tap offsets suffice.)  The per-(b,k) 3x4 homographies are built once per
 // workgroup into LDS and read back as same-address (broadcast) LDS reads.
+#include <cstddef>
 #include <stdlib.h>
 
 #include "idh_common.h"
@@ -1094,7 +1095,7 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
         a.tiles_x = idh_cdiv(W, kTileW); a.tiles_y = idh_cdiv(H, kTileH);
         cv_win_split(B, K, H, W, D, &a.psplit, &a.units_per_split);
         // optional scratch for the arg-max over split planes (idh_volume_opts.scratch: >= idh_cost_volume_dot_scratch_floats)
-        a.partial = (opts && opts->struct_size == (int64_t)sizeof(idh_volume_opts) && opts->scratch && lowest_bhw && a.psplit > 1 &&
+        a.partial = (opts && opts->struct_size >= (int64_t)(offsetof(idh_volume_opts, struct_size) + sizeof(int64_t)) && opts->scratch && lowest_bhw && a.psplit > 1 &&
                      opts->scratch_floats >= 2ll * a.psplit * B * H * W) ? opts->scratch : nullptr;
         a.list_bytes = ((a.units_per_split + 3) / 4) * K * kRunsPerPair * (int)sizeof(RunEntry);
         a.planes_bytes = ((D + 3) & ~3) * (int)sizeof(float);

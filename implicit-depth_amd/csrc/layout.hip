@@ -3,6 +3,8 @@
 // 16-byte-vector read.  Converted once at the module boundary.
 #include "idh_common.h"
 
+namespace {
+
 // One thread = (pixel, group of 4 channels): reads 4 strided floats (coalesced across the
 // 16 lanes that share a channel group), writes one float4 (fully coalesced across the wave).
 __global__ __launch_bounds__(256) void nchw_to_nhwc_k(const float *__restrict__ src,
@@ -50,6 +52,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_k(const float *__restrict__ 
         if (p0 + p < HW && c0 + c < C) d[(long long)(c0 + c) * HW + p0 + p] = tile[c][p];
     }
 }
+
+}  // namespace
 
 extern "C" int idh_nchw_to_nhwc_f32(const float *src, float *dst, int n_img, int C, int HW, void *stream) {
     if (!src || !dst || n_img < 0 || C <= 0 || HW <= 0) return IDH_EINVAL;

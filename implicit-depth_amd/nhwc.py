@@ -232,7 +232,10 @@ WINO4_MIN_TILES = 384
 WINO4_MIN_FILL = 0.85
 
 
-def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act: int) -> bool:
+def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act: int, out=None, res=None) -> bool:
+    """Mirror of ``idh_conv::wino4_supported`` (csrc/conv_wino4.hip) plus the fill / tile-count rules.  ``out`` / ``res``: the views the op
+    writes / adds - their per-image byte sizes (with the channel stride of a wider concat buffer) are 32-bit buffer ranges in the kernel, so a
+    layer that exceeds them is planned onto F(2x2) / the direct kernels here instead of failing at run time with IDH_EUNSUPPORTED."""
     (v0, c0) = srcs[0]
     if c0.kernel_size[0] != 3 or c0.stride[0] != 1 or pad_mode != PAD_ZEROS or cout % 64 or isinstance(v0, CatView):
         return False
@@ -243,6 +246,15 @@ def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act
     if act not in (ACT_NONE, ACT_LRELU, ACT_ELU) or c0.in_channels <= 16:  # (<= 16: the copy pipeline runs a pair of 8-channel stages ahead)
         return False
     if getattr(v0, "H", 0) * getattr(v0, "W", 0) * getattr(v0, "cs", 0) * 4 >= 1 << 30:  # (csrc: the halo's 32-bit offsets run a few rows past an image)
+        return False
+    for v in (out, res):  # output / residual image: 32-bit byte offsets
+        if v is not None and Ho * Wo * getattr(v, "cs", 0) * 4 >= 1 << 31:
+            return False
+    if len(srcs) > 1:
+        (v1, c1) = srcs[1]
+        if getattr(v1, "H", 0) * getattr(v1, "W", 0) * getattr(v1, "cs", 0) * 4 >= 1 << 31 or ((c1.in_channels + 15) // 16) * 4 * (((cout + 15) // 16) * 16) * 64 >= 1 << 31:
+            return False
+    if ((c0.in_channels + 15) // 16) * 4 * (((cout + 15) // 16) * 16) * 36 * 16 * 4 >= 1 << 31:  # packed weights
         return False
     ty, tx = -(-Ho // 8), -(-Wo // 32)
     if Ho * Wo < WINO4_MIN_FILL * (ty * 8) * (tx * 32):
@@ -412,6 +424,8 @@ class Plan:
         self.meta: List[dict] = []  # per op: regions read / written, for the level scheduler
         self.keep: List[torch.Tensor] = []  # buffers / packed weights referenced by raw pointer
         self._free: Dict[tuple, List[torch.Tensor]] = {}  # released buffers by shape (``release``)
+        self.recycled_candidates = 0  # buffers handed to the pool by ``release``
+        self.recycled = 0  # ... and how many of them a later ``buffer()`` took over (tests assert that aliasing really happened)
         self._arr = None
         self._pos: Optional[List[int]] = None  # op index at build time -> index after schedule()
         self.flops = 0  # 2*MAC of the conv ops (algorithmic, no padding)
@@ -423,6 +437,7 @@ class Plan:
         cs = ceil16(Cch)
         pool = self._free.get((N, H, W, cs)) if cs == Cch else None
         if pool:
+            self.recycled += 1
             return View(pool.pop(), 0, Cch)
         alloc = torch.zeros if cs != Cch else torch.empty
         t = alloc(N, H, W, cs, device=self.device, dtype=torch.float32)
@@ -438,7 +453,11 @@ class Plan:
         t = v.buf
         if (BUFFER_REUSE and v.c0 == 0 and v.C == t.shape[-1] and t.dim() == 4 and t.numel() * 4 >= REUSE_MIN_BYTES
                 and any(t is k for k in self.keep)):
-            self._free.setdefault(tuple(t.shape), []).append(t)
+            pool = self._free.setdefault(tuple(t.shape), [])
+            if any(t is f for f in pool):  # a second release of a buffer that is still in the pool would hand it to TWO later allocations
+                raise _lib.IdhError("Plan.release: buffer released twice")
+            pool.append(t)
+            self.recycled_candidates += 1
 
     # ops -----------------------------------------------------------------------------
     def conv(self, x: View, conv: nn.Conv2d, out: View, act=ACT_NONE, slope=0.2, res: Optional[View] = None,
@@ -454,7 +473,7 @@ class Plan:
         use_wino = (WINOGRAD and self.math == "fp32" and norm is None and
                     wino_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode))
         use_wino4 = (WINOGRAD4 and self.math == "fp32" and norm is None and (x2 is None or res is None) and
-                     wino4_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode, act))
+                     wino4_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode, act, out, res))
         if use_wino4:
             use_wino = False
         for i, (v, cv) in enumerate(srcs):
@@ -796,6 +815,9 @@ PLAN_CACHE_ENTRIES = 4
 
 class ParamKey(tuple):
     """The part of a plan-cache key that names parameter versions / build-time switches (as opposed to input shapes)."""
+
+    def __add__(self, other):  # (tuple.__add__ would hand back a plain tuple, which PlanCache.put's stale-twin eviction does not recognise)
+        return ParamKey(tuple.__add__(self, other))
 
 
 class PlanCache:

@@ -26,6 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations of this header are its whole dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define IDH_OK 0
 #define IDH_EINVAL (-1)      /* bad shape / null pointer / unsupported parameter */
@@ -76,10 +80,13 @@ typedef struct idh_volume_opts {
                        pixel here and the arg-max pass combines those instead of re-reading the whole volume (same result:
                        first maximum wins).  NULL: no scratch, the pass reads the volume. */
     int64_t scratch_floats;
-    int64_t struct_size; /* = sizeof(idh_volume_opts) of the header the caller was built against (idh_sizeof_volume_opts() tells what the
-                            library was built with).  The fields from `scratch` on were added in ABI version 101: the library honours them
-                            only when struct_size covers them, so a caller built against the version-100 header (a shorter struct) is never
-                            read past its end into a garbage scratch pointer. */
+    int64_t struct_size; /* = sizeof(idh_volume_opts) of the header the caller was built against.  The fields from `scratch` on exist since ABI
+                            version 101; the library honours them only when struct_size >= offsetof(struct_size) + 8, i.e. when the caller says
+                            its struct reaches at least this far (a LARGER value - a later header with more fields appended - is accepted).
+                            This is a consistency check between a caller and the header it was built with, NOT protection for a caller built
+                            against the shorter version-100 struct: for such a caller the field itself lies past the end of its struct.  A
+                            binding must therefore compare idh_sizeof_volume_opts() / idh_version() with its own mirror when it loads the
+                            library (implicit-depth_amd/_lib.py does, and refuses to bind on a mismatch). */
 } idh_volume_opts;
 
 /* sizeof(idh_volume_opts) as compiled into the library (bindings assert their mirror matches; idh_version() >= 101). */
@@ -257,6 +264,9 @@ int idh_plane_iou_fwd(const float *query_depth_bdn, const float *gt_depth_b1n, c
 int idh_depth_metrics_fwd(const float *gt_bn, const float *pred_bn, const unsigned char *valid_bn, int B, int N,
                           int mult_a, float *out_b12, void *workspace, size_t workspace_bytes, void *stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

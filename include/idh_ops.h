@@ -18,6 +18,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations of this header are its whole dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 enum {
     IDH_OP_CONV = 1,        /* implicit-GEMM conv on fp32 MFMA (layers.py:59-75 convs)       */
@@ -153,6 +157,9 @@ int idh_run_ops(const idh_op *ops_host, int n, void *stream);
  * is launched; usable without a GPU), or a negative IDH_E* code. */
 int idh_count_launches(const idh_op *ops_host, int n);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

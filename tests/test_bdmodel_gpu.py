@@ -86,12 +86,35 @@ def test_hot_path_reproduces_reference_depthmodel_forward():
     assert (out["overall_mask_bhw"].cpu() != torch.as_tensor(g["overall_mask_bhw"])).float().mean().item() < 2e-3
 
 
-@pytest.mark.parametrize("volume", ["mlp", "dot"])
-def test_full_size_bdmodel_forward_golden(volume):
+@pytest.fixture
+def conv_plan(request):
+    """"default": the kernel selection a one-frame plan gets by itself (no layer reaches the F(4x4) tile threshold).  "wino4": the thresholds
+    of nhwc.wino4_eligible lowered so that EVERY eligible layer runs conv3x3_wino4_k - the kernel selection of the B = 32 bench plan, compared
+    with the reference's full-size goldens directly instead of through a batch-invariance hop."""
+    from implicit_depth_amd import nhwc
+
+    old = (nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL)
+    if request.param == "wino4":
+        nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = True, 1, 0.0
+    yield request.param
+    nhwc.WINOGRAD4, nhwc.WINO4_MIN_TILES, nhwc.WINO4_MIN_FILL = old
+
+
+def _assert_plan_kernels(hot, conv_plan, min_wino4):
+    from implicit_depth_amd import nhwc
+
+    ops = [op for ent in hot._plans.values() for op in ent["plan"].ops if op.kind == nhwc.OP_CONV]
+    n4 = sum(op.tile_m == nhwc.TILE_WINO4 for op in ops)
+    print(f"conv plan {conv_plan}: {n4} of {len(ops)} convs on conv3x3_wino4_k")
+    assert (n4 >= min_wino4) if conv_plan == "wino4" else (n4 == 0)
+
+
+@pytest.mark.parametrize("volume,conv_plan", [("mlp", "default"), ("dot", "default"), ("mlp", "wino4")], indirect=["conv_plan"])
+def test_full_size_bdmodel_forward_golden(volume, conv_plan):
     """BASELINE.json's size: the reference's BDModel.forward on a 512x384 tuple — mlp_feature_volume K=7
     (reference-native) and simple_cost_volume K=8 (BASELINE's literal "8 views") — D=64, 8 query planes;
     goldens g5_full_*: checksums + strided slices, backbone features regenerated from the seeds the reference
-    run used."""
+    run used.  conv_plan "wino4": the same comparison with every eligible conv on the F(4x4) kernel."""
     from implicit_depth_amd import cost_volume as cv
     from implicit_depth_amd import networks as net
     from implicit_depth_amd.dropin import hot_path_of
@@ -117,6 +140,7 @@ def test_full_size_bdmodel_forward_golden(volume):
     out = hot(mc, ms, pyr, src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1),
               cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"], src["K_s1_b44"], cur["invK_s1_b44"],
               rendered_depth=cur["rendered_depth"], return_mask=True)
+    _assert_plan_kernels(hot, conv_plan, 80)
     pred, low = out["pred_0"].cpu(), out["lowest_cost_bhw"].cpu()
     assert rel_err(pred[:, :, ::6, ::8], g["pred_slice"]) < TOL
     if volume == "mlp":
@@ -178,8 +202,10 @@ def test_full_size_temporal_prior_golden():
     assert ((out["lowest_cost_bhw"].cpu()[:, ::3, ::4] - torch.as_tensor(g["lowest_slice"])).abs() > 1e-5).float().mean().item() < 5e-3
 
 
-def test_full_size_depthmodel_forward_golden():
-    """The reference's DepthModel.forward at 512x384 (mlp_feature_volume K=7, D=64, DepthDecoderPP heads + exp)."""
+@pytest.mark.parametrize("conv_plan", ["default", "wino4"], indirect=True)
+def test_full_size_depthmodel_forward_golden(conv_plan):
+    """The reference's DepthModel.forward at 512x384 (mlp_feature_volume K=7, D=64, DepthDecoderPP heads + exp); conv_plan "wino4": every
+    eligible conv on the F(4x4) kernel."""
     import numpy as np
 
     from implicit_depth_amd import cost_volume as cv
@@ -204,6 +230,7 @@ def test_full_size_depthmodel_forward_golden():
     hot = hot_path_of(h)
     out = hot(mc, ms, pyr, src["cam_T_world_b44"] @ cur["world_T_cam_b44"].unsqueeze(1),
               cur["cam_T_world_b44"].unsqueeze(1) @ src["world_T_cam_b44"], src["K_s1_b44"], cur["invK_s1_b44"], return_mask=True)
+    _assert_plan_kernels(hot, conv_plan, 80)
     for i in range(4):
         sl = (slice(None), slice(None), slice(None, None, 3), slice(None, None, 4)) if i >= 2 else (slice(None), slice(None), slice(None, None, 6), slice(None, None, 8))
         for nm, tol in ((f"log_depth_pred_s{i}_b1hw", TOL), (f"depth_pred_s{i}_b1hw", 5 * TOL)):  # exp() amplifies

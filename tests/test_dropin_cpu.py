@@ -212,5 +212,19 @@ def test_plan_buffer_liveness_reuse_rules():
         assert p.buffer(2, 32, 32, 16).buf is not foreign.buf
         # regions are keyed by the tensor: a recycled buffer carries its readers' dependencies to the next writer
         assert nhwc._overlap([nhwc._region(big)], [nhwc._region(again)])
+        # a buffer still waiting in the pool cannot be released again (it would be handed to two later allocations); once it has been taken
+        # over, its new owner may release it
+        import pytest
+
+        from implicit_depth_amd import _lib
+
+        twice = p.buffer(2, 16, 16, 64)
+        p.release(twice)
+        with pytest.raises(_lib.IdhError):
+            p.release(twice)
+        taken = p.buffer(2, 16, 16, 64)
+        assert taken.buf is twice.buf
+        p.release(taken)
+        assert (p.recycled, p.recycled_candidates) == (2, 3)
     finally:
         nhwc.REUSE_MIN_BYTES = old

@@ -187,6 +187,43 @@ def test_plan_cache_replays_alternating_batch_sizes():
         nhwc.MERGE_LEVELS = old
 
 
+@pytest.mark.parametrize("depth_model", [False, True])
+def test_buffer_reuse_aliasing_is_bit_identical(depth_model):
+    """Plan.release (nhwc.BUFFER_REUSE) lets later allocations ALIAS the big activation temporaries; the level scheduler must order every new
+    writer after the old readers.  The default threshold (64 MiB) pools nothing at test sizes, so this runs the whole HotPath (matching-free:
+    CVEncoder + UNet++ decoder + occlusion MLP / depth heads, through schedule_segments) with the threshold at 0 - every released buffer is
+    recycled - and demands bit-identical outputs to the plan with private buffers; also with two frames, and replayed (aliased buffers hold
+    garbage from the previous run)."""
+    from implicit_depth_amd import nhwc
+
+    B, K, H, W, D, P = 2, 2, 24, 32, 16, 2
+    old = (nhwc.BUFFER_REUSE, nhwc.REUSE_MIN_BYTES)
+    results, recycled = {}, {}
+    try:
+        for reuse in (False, True):
+            nhwc.BUFFER_REUSE, nhwc.REUSE_MIN_BYTES = reuse, 0
+            model, inp, pyr, rd = _build(B, K, H, W, D, P, depth_model=depth_model)
+            model.cuda()
+            d = {k: v.cuda() for k, v in inp.items()}
+            outs = []
+            for _ in range(2):
+                out = model(d["cur_feats"], d["src_feats"], [t.cuda() for t in pyr], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
+                            rendered_depth=None if depth_model else rd.cuda())
+                outs.append({k: v.clone() for k, v in out.items() if torch.is_tensor(v)})
+            plan = next(iter(model._plans.values()))["plan"]
+            recycled[reuse] = (plan.recycled, plan.recycled_candidates)
+            results[reuse] = outs
+    finally:
+        nhwc.BUFFER_REUSE, nhwc.REUSE_MIN_BYTES = old
+    print("recycled buffers (taken over, released):", recycled)
+    assert recycled[False] == (0, 0) and recycled[True][0] >= 8, recycled
+    keys = sorted(results[False][0])
+    assert keys and keys == sorted(results[True][0])
+    for k in keys:
+        for run in range(2):
+            assert torch.equal(results[True][run][k], results[False][0][k]), (k, run)
+
+
 def test_bench_n2_branch_on_one_gpu_over_gloo(tmp_path):
     """bench.py's N > 1 branch (shard, barrier, MAX all-reduce, ragged metric all-gather, rank-0 JSON) under a real launcher with
     real kernels: two ranks share the single GPU of the box over gloo (RCCL refuses duplicate devices; the RCCL leg itself is the
