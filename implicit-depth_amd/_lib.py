@@ -122,7 +122,7 @@ def lib():
         # the ABI this mirror was written against (include/idh.h): struct layouts, tile codes and packed-weight layouts changed at these versions
         # (102: IDH_TILE_WINO4 names the shared-transform F(4x4) kernel and ITS packed layout - blobs packed by an older library are not portable)
         ver = h.idh_version()
-        if ver < MIN_ABI_VERSION:
+        if ver < MIN_ABI_VERSION and not os.environ.get("IDH_LIB_ANY_ABI"):  # (IDH_LIB_ANY_ABI: A/B timing against a library built from an older tree)
             raise IdhError(f"{LIB_PATH} reports ABI version {ver}, this binding needs >= {MIN_ABI_VERSION}: rebuild with `python implicit-depth_amd/build.py --force`")
         if h.idh_sizeof_volume_opts() != C.sizeof(VolumeOpts):
             raise IdhError(f"{LIB_PATH}: sizeof(idh_volume_opts) = {h.idh_sizeof_volume_opts()} in the library, {C.sizeof(VolumeOpts)} in this binding")

@@ -55,13 +55,18 @@ __device__ __forceinline__ int fresh_lane() {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
-// 1-D output transform A^T (6 -> 4): 12 vector operations
+// 1-D output transform A^T (6 -> 4): 12 operations per component, written component by component: vector-typed arithmetic becomes v_pk_*_f32 on 64-bit
+// register pairs, whose alignment constraints fragment the register file at the epilogue's peak (scratch) and which cost ~3x a scalar operation
+// beside the other wave's fp32 MFMAs (profiles/r04/experiments.md section 4)
 __device__ __forceinline__ void at6(f32x4 m0, f32x4 m1, f32x4 m2, f32x4 m3, f32x4 m4, f32x4 m5, f32x4 &y0, f32x4 &y1, f32x4 &y2, f32x4 &y3) {
-    const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-    y0 = (m0 + s1) + s2;
-    y1 = fma4(0.5f, d1, d2 * 2.f);
-    y2 = fma4(0.25f, s1, s2 * 4.f);
-    y3 = fma4(0.125f, d1, fma4(8.f, d2, m5));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float s1 = m1[e] + m2[e], d1 = m1[e] - m2[e], s2 = m3[e] + m4[e], d2 = m3[e] - m4[e];
+        y0[e] = (m0[e] + s1) + s2;
+        y1[e] = __builtin_fmaf(0.5f, d1, d2 * 2.f);
+        y2[e] = __builtin_fmaf(0.25f, s1, s2 * 4.f);
+        y3[e] = __builtin_fmaf(0.125f, d1, __builtin_fmaf(8.f, d2, m5[e]));
+    }
 }
 
 // Design (two workgroups per CU, two waves per SIMD):
@@ -164,8 +169,8 @@ __device__ __forceinline__ void bt3_finish(float s0, float s1, float s2, float &
 }
 
 // SRC2: BasicBlock's 1x1 projection of a second tensor (layers.py:86-92), accumulated in the PIXEL domain after the output transform (the epilogue's
-// "P phase" below)
-template <bool SRC2>
+// "P phase" below).  RES: a residual tensor is added in the epilogue (BasicBlock's identity shortcut; never together with SRC2).
+template <bool SRC2, bool RES>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
     __shared__ __attribute__((aligned(16))) char lds_raw[kLdsBytes];
     lds_char *lds = (lds_char *)lds_raw;
@@ -218,53 +223,65 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
     // are masked per lane.  Granules 0, 1 (the even stage's 8 channels) go to one plane, 2, 3 to the next; within a plane a texel has 32 B and its
     // channel quad q sits in granule q ^ (R & 1): the 16 tiles of a wave read, for a given patch element, a 2 x 8 block of (R, cq) whose 16-byte
     // granules fall into 16 different bank groups (conflict-free ds_read_b64).
+    // The cursor (image descriptor + tile origin) lives in scalar registers; the per-lane source offsets are derived from the lane id read afresh
+    // at every batch of copies (halo_src0 / halo_src1, ~10 integer operations) instead of being held in vector registers from tile to tile: whatever
+    // lane-invariant value is live across the epilogue's register peak hipcc parks in scratch, and its reload then sits in the stage loop right
+    // behind the copies it addresses - where the in-order vmcnt makes it wait for them (see fresh_lane).
     __amdgpu_buffer_rsrc_t rsH;
-    int voffH0, voffH1;
+    int cy0 = 0, cx0 = 0;
     const int row_pair = s.W * s.cs * 8;  // bytes of two image rows
     auto set_halo_cursor = [&](const Tile &t) {
         rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.in + (size_t)t.img * s.H * s.W * s.cs), 0, s.H * s.W * s.cs * 4, 0x00020000);
-        const int tid_o = 64 * wave + fresh_lane();  // (re-derived per tile rather than spilled: see fresh_lane)
-        const int gr = tid_o & 3;
-        {
-            const int iy = t.y0 - 1 + (tid_o >> 7), ix = t.x0 - 1 + ((tid_o >> 2) & 31);
-            voffH0 = (unsigned)ix < (unsigned)s.W ? (iy * s.W + ix) * s.cs * 4 + 16 * gr : kOob;
-        }
-        {
-            const int e = tid_o >> 2;
-            const int iy = t.y0 - 1 + (e >> 1), ix = t.x0 + 31 + (e & 1);
-            voffH1 = ((e < 20) & (ix < s.W) & ((unsigned)iy < (unsigned)s.H)) ? (iy * s.W + ix) * s.cs * 4 + 16 * gr : kOob;
-        }
+        cy0 = t.y0; cx0 = t.x0;
     };
-    auto ld_halo = [&](int k, int ch) -> f32x4 {  // ch: the pair's first stage
+    auto halo_src0 = [&]() -> int {  // copies 0..4: texel (row 2 k + (t >> 7), column (t >> 2) & 31), granule t & 3
+        const int t = 64 * wave + fresh_lane();
+        const int iy = cy0 - 1 + (t >> 7), ix = cx0 - 1 + ((t >> 2) & 31);
+        return (unsigned)ix < (unsigned)s.W ? (iy * s.W + ix) * s.cs * 4 + 16 * (t & 3) : kOob;
+    };
+    auto halo_src1 = [&]() -> int {  // copy 5: columns 32, 33 of the ten rows (threads 0..79)
+        const int t = 64 * wave + fresh_lane();
+        const int e = t >> 2;
+        const int iy = cy0 - 1 + (e >> 1), ix = cx0 + 31 + (e & 1);
+        return ((e < 20) & (ix < s.W) & ((unsigned)iy < (unsigned)s.H)) ? (iy * s.W + ix) * s.cs * 4 + 16 * (t & 3) : kOob;
+    };
+    auto ld_halo = [&](int k, int ch, int src0) -> f32x4 {  // ch: the pair's first stage; src0 = halo_src0() of this batch
 #ifdef IDH_ABL_W4_NOHALO
         return (f32x4){0.f, 0.f, 0.f, 0.f};
 #endif
         if (k < 5)  // (the row advance goes into the VECTOR offset: the scalar offset takes no part in the buffer range check)
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, (int)((unsigned)voffH0 + (unsigned)(k * row_pair)), __builtin_amdgcn_readfirstlane(32 * ch), 0));
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, voffH1, __builtin_amdgcn_readfirstlane(32 * ch), 0));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, (int)((unsigned)src0 + (unsigned)(k * row_pair)), __builtin_amdgcn_readfirstlane(32 * ch), 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, halo_src1(), __builtin_amdgcn_readfirstlane(32 * ch), 0));
     };
     // LDS address of copy k of this thread in the plane pair (offA: granules 0, 1; offB: granules 2, 3)
-    int wdst0;
-    {
-        const int wq = tid & 1, rr = tid >> 7, col = (tid >> 2) & 31;
-        wdst0 = 32 * (108 * rr + 27 * (col & 3) + (col >> 2)) + 16 * wq;
-    }
-    const bool wselB = (tid >> 1) & 1;
-    auto st_halo = [&](int k, f32x4 v, int offA, int offB) {
-        const int off = wselB ? offB : offA;
-        if (k < 5) *(lds_f32x4 *)(lds + ((off + wdst0) ^ (((k >> 1) & 1) << 4)) + 32 * (216 * (k & 1) + 9 * (k >> 1))) = v;  // row 2k + rr: rm = 2 (k & 1) + rr, R = k >> 1
-        else if (wave < 2) {  // (threads 0..79; the address of the one copy per stage pair that needs it is derived on the spot: see fresh_lane)
+    // Per-lane constants of the stage loop.  They are (re)derived at the start of EVERY tile from the lane id read afresh (derive_lane_constants, ~25
+    // integer operations per tile): nothing lane-invariant is then live across the epilogue, whose register peak would otherwise push them into
+    // scratch - with the reload inside the stage loop, in front of the halo loads (see fresh_lane).
+    int vbase, voffA;
+    auto derive_lane_constants = [&]() {
+        const int ln = fresh_lane();
+        vbase = ln * 144;  // V[ks][lane][36]: 144 B per lane (36-dword stride: conflict-free ds_read_b128)
+        voffA = ln * 16;
+    };
+    derive_lane_constants();
+    // LDS address of this thread's copies in the plane pair (offA: granules 0, 1; offB: granules 2, 3), derived per batch of stores like the sources
+    auto halo_dst = [&](int offA, int offB) -> int {
+        const int t = 64 * wave + fresh_lane();
+        const int wq = t & 1, rr = t >> 7, col = (t >> 2) & 31;
+        return ((t >> 1) & 1 ? offB : offA) + 32 * (108 * rr + 27 * (col & 3) + (col >> 2)) + 16 * wq;
+    };
+    auto st_halo = [&](int k, f32x4 v, int dst0, int offA, int offB) {
+        if (k < 5) *(lds_f32x4 *)(lds + (dst0 ^ (((k >> 1) & 1) << 4)) + 32 * (216 * (k & 1) + 9 * (k >> 1))) = v;  // row 2k + rr: rm = 2 (k & 1) + rr, R = k >> 1
+        else if (wave < 2) {  // (threads 0..79)
             const int t = 64 * wave + fresh_lane();
             if (t < 80) {
                 const int e = t >> 2, r = e >> 1;
-                *(lds_f32x4 *)(lds + off + 32 * (((4 * (r & 3) + (e & 1)) * 3 + (r >> 2)) * 9 + 8) + 16 * ((t & 1) ^ ((r >> 2) & 1))) = v;
+                *(lds_f32x4 *)(lds + ((t >> 1) & 1 ? offB : offA) + 32 * (((4 * (r & 3) + (e & 1)) * 3 + (r >> 2)) * 9 + 8) + 16 * ((t & 1) ^ ((r >> 2) & 1))) = v;
             }
         }
     };
 
     // ---- this lane's raw-patch read bases: element (i, c) of tile (ty, tx): texel p = ((4 (i & 3) + (c & 3)) * 3 + ty + (i >> 2)) * 9 + tx + (c >> 2); channels 2h, 2h+1
-    const int rbase = 32 * (9 * ty + tx) + 16 * ((h >> 1) ^ (ty & 1)) + 8 * (h & 1);  // rows i < 4; rows 4, 5 (R + 1): the granule bit flips (^ 16)
-    const int vbase = lane * 144;  // V[ks][lane][36]: 144 B per lane (36-dword stride: conflict-free ds_read_b128)
     const int qa = wave >> 1, qb = wave & 1;  // this wave's quadrant of positions: xi = 3 qa .., nu = 3 qb ..
 
     // transform of the stage whose halo is in the plane at `hoff` -> this wave's quadrant of V in `vbuf`.  The quadrant needs a 5 x 5 part of the
@@ -272,6 +289,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
     auto transform = [&](auto hic, auto hjc, int hoff, int vbuf) {
         constexpr bool HI_I = decltype(hic)::value, HI_J = decltype(hjc)::value;
         constexpr int I0 = HI_I ? 1 : 0, J0 = HI_J ? 1 : 0;
+        // (patch read base derived on the spot, once per stage: one vector register less held through the MFMA loop)
+        const int ln = fresh_lane(), n_ = ln & 15, h_ = ln >> 4, ty_ = n_ >> 3, tx_ = n_ & 7;
+        const int rbase = 32 * (9 * ty_ + tx_) + 16 * ((h_ >> 1) ^ (ty_ & 1)) + 8 * (h_ & 1);  // rows i < 4; rows 4, 5 (R + 1): the granule bit flips (^ 16)
         const int rb[2] = {rbase + hoff, (rbase ^ 16) + hoff};
         auto rd = [&](int i, int c) -> f32x2 { return *(lds_cf32x2 *)(lds + rb[i >> 2] + 32 * (((4 * (i & 3) + (c & 3)) * 3 + (i >> 2)) * 9 + (c >> 2))); };
         f32x2 d[2][5];
@@ -322,7 +342,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.w), 0, nS * nCB * kPanelFloats * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.bias ? a.bias : a.out), 0, a.bias ? a.Cout * 4 : 0, 0x00020000);
-    const int voffA = lane * 16;
     // A fragments: a ring of kRing rows that runs across stage and tile boundaries: row j of a stage is consumed from Af[j % kRing] and the
     // register reloaded at once with the row kRing further on (12 MFMAs of lookahead)
 #ifndef IDH_W4_RING
@@ -347,10 +366,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         f32x4 t0[3];
+        const int hs = halo_src0(), hd = halo_dst(0, kPlane);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) t0[k] = ld_halo(3 * b + k, 0);
+        for (int k = 0; k < 3; ++k) t0[k] = ld_halo(3 * b + k, 0, hs);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) st_halo(3 * b + k, t0[k], 0, kPlane);
+        for (int k = 0; k < 3; ++k) st_halo(3 * b + k, t0[k], hd, 0, kPlane);
     }
     {
 #ifdef IDH_ABL_W4_SAMEA  // (timing experiment: every wave reads channel block 0's fragments: what would sharing the A rows in L1 be worth?)
@@ -367,8 +387,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
     // even stage S: halo(S + 2) -> plane pl2, halo(S + 3) -> plane pl0 (halo(S) left it one barrier ago), in a batch of 2 and one of 4 copies; at its entry
     // stg[] holds the first batch in flight
     f32x4 stg[4];
+    {
+        const int hs = halo_src0();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) stg[k] = ld_halo(k, 2);
+        for (int k = 0; k < 2; ++k) stg[k] = ld_halo(k, 2, hs);
+    }
     __syncthreads();
     int pl0 = 0, pl1 = kPlane, pl2 = 2 * kPlane;  // LDS offsets of the planes of halo(S), halo(S + 1), halo(S + 2) (rotated every stage)
 
@@ -420,10 +443,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
                 for (int e = 0; e < 4; ++e) acc[4 * (j % 9) + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[j % kRing][e], Bf[j][e], acc[4 * (j % 9) + e], 0, 0, 0);
                 ldA(j % kRing, j + kRing < 18 ? aso + 1024 * (j + kRing) : aso_n + 1024 * (j + kRing - 18));
                 if (PAR == 0 && j == 8) {
+                    const int hd = halo_dst(pl2, pl0), hs = halo_src0();
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) st_halo(k, stg[k], pl2, pl0);
+                    for (int k = 0; k < 2; ++k) st_halo(k, stg[k], hd, pl2, pl0);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) stg[k] = ld_halo(2 + k, ch);
+                    for (int k = 0; k < 4; ++k) stg[k] = ld_halo(2 + k, ch, hs);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #ifdef IDH_ABL_W4_TRACE
@@ -431,16 +455,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 #endif
             }
             if (PAR == 0) {
+                const int hd = halo_dst(pl2, pl0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) st_halo(2 + k, stg[k], pl2, pl0);
+                for (int k = 0; k < 4; ++k) st_halo(2 + k, stg[k], hd, pl2, pl0);
             } else {
                 // first half of the next even stage's copies (halo(E + 2), halo(E + 3), E = c + 1 or stage 0 of the next tile), issued HERE: loads complete in
                 // order, so an A row issued after a copy cannot be used before the copy is back from HBM (~3k cycles); rows 0..5 of a stage use A rows
                 // issued before this point
                 if (c + 3 == nS) set_halo_cursor(nxt);
                 const int chn = c + 3 >= nS ? c + 3 - nS : c + 3;
+                const int hs = halo_src0();
 #pragma unroll
-                for (int k = 0; k < 2; ++k) stg[k] = ld_halo(k, chn);
+                for (int k = 0; k < 2; ++k) stg[k] = ld_halo(k, chn, hs);
             }
             W4T(tr0 + 5);
             // transform(S + 1): halo(S + 1) -> V(S + 1)
@@ -471,42 +497,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
             const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.res ? a.res + (size_t)cur.img * a.Ho * a.Wo * a.res_cs : a.out), 0,
                                                                                   a.res ? a.Ho * a.Wo * a.res_cs * 4 : 0, 0x00020000);
             const int oy0 = cur.y0 + 4 * ty, ox0 = cur.x0 + 4 * tx;
-            const bool has_res = a.res != nullptr;
             const float slope_eff = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(a.act == IDH_ACT_LRELU ? __builtin_bit_cast(int, a.slope) : 0x3f800000));  // (scalar register)
             // nn.ELU(alpha = 1) as torch's kernel forms it, exp(x) - 1, with the exponential through v_exp_f32 (as csrc/mlp.hip: |err| ~1e-7 absolute)
             const bool elu = a.act == IDH_ACT_ELU;
             const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 4 * h) * 4, 0, 0));
             // M[xi][nu] = acc[p'(xi, nu)]
             auto M = [&](int xi, int nu) -> f32x4 & { return acc[9 * (2 * (xi / 3) + nu / 3) + 3 * (xi % 3) + nu % 3]; };
+            // pixel (i, j) of this lane's tile: element offset of its channel-0 value in an image of channel stride 1, or -1 outside the map
+            auto pixel = [&](int i, int j) -> int { return ((oy0 + i < a.Ho) & (ox0 + j < a.Wo)) ? (oy0 + i) * a.Wo + ox0 + j : -1; };
+            // residual loads run ahead of their use: column 0's are issued before the row pass (while the 144 accumulators are still live there is room
+            // for one column), columns 1, 2's right after it and column 3's after column 0's pass (a ring of three) (issued one column at a time just before use, every column exposed a full memory round
+            // trip: the NOEPI ablation put 27-33 % of a 64-channel tile with residual into the epilogue)
+            f32x4 r[3][4];  // (ring: column j in slot j % 3)
+            auto ld_res = [&](int j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#ifdef IDH_ABL_W4_EPILIN  // (timing experiment: residual loads / stores of a wave cover 8 FULL cache lines per instruction instead of 16 half lines: bound for an LDS-transposed epilogue)
+                    r[j % 3][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, ((cur.y0 / 8 * wa.tiles_x + cur.x0 / 32) * 64 + (4 * i + j) * 4 + wave) * 1024 + lane_e * 16, 0, 0));
+#else
+                    const int px = pixel(i, j);
+                    r[j % 3][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, px >= 0 ? (px * a.res_cs + n0 + 4 * h) * 4 : kOob, 0, 0));
+#endif
+                }
+            };
+            if constexpr (RES) ld_res(0);
             f32x4 u[6][4];
 #pragma unroll
-            for (int xi = 0; xi < 6; ++xi) at6(M(xi, 0), M(xi, 1), M(xi, 2), M(xi, 3), M(xi, 4), M(xi, 5), u[xi][0], u[xi][1], u[xi][2], u[xi][3]);
+            for (int xi = 0; xi < 6; ++xi) {
+                at6(M(xi, 0), M(xi, 1), M(xi, 2), M(xi, 3), M(xi, 4), M(xi, 5), u[xi][0], u[xi][1], u[xi][2], u[xi][3]);
+                // the row's 16 results are pinned HERE: left alone, LLVM sinks the outputs 1..3 of every row into the column passes that use them and keeps the
+                // rows' sums / differences (20 values per row instead of 12) alive across the whole pass - the epilogue's register peak, i.e. scratch
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = u[xi][j][e];
+                        asm volatile("" : "+v"(t));
+                        u[xi][j][e] = t;
+                    }
+            }
             if constexpr (!SRC2) {
+                if constexpr (RES) {
+                    __builtin_amdgcn_sched_barrier(0);  // (the loads stay BELOW the row pass: hoisted above it their 48 registers do not fit beside the accumulators)
+                    ld_res(1); ld_res(2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    f32x4 r[4], y[4];
-                    int pix[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
-                        pix[i] = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
-                        r[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-                    if (has_res) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#ifdef IDH_ABL_W4_EPILIN  // (timing experiment: residual loads / stores of a wave cover 8 FULL cache lines per instruction instead of 16 half lines: bound for an LDS-transposed epilogue)
-                            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, ((cur.y0 / 8 * wa.tiles_x + cur.x0 / 32) * 64 + (4 * i + j) * 4 + wave) * 1024 + lane_e * 16, 0, 0));
-#else
-                            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pix[i] >= 0 ? (pix[i] * a.res_cs + n0 + 4 * h) * 4 : kOob, 0, 0));
-#endif
-                    }
+                    f32x4 y[4];
                     at6(u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j], y[0], y[1], y[2], y[3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        f32x4 o = y[i] + b4 + r[i];
+                        f32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = y[i][e] + b4[e];
+                            if constexpr (RES) o[e] += r[j % 3][i][e];
+                            o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        }
                         if (elu) {  // (wave-uniform; the LeakyReLU / identity path above costs ELU layers 8 idle operations, the others nothing)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? __expf(o[e]) - 1.0f : o[e];
@@ -514,8 +562,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 #ifdef IDH_ABL_W4_EPILIN
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, ((cur.y0 / 8 * wa.tiles_x + cur.x0 / 32) * 64 + (4 * i + j) * 4 + wave) * 1024 + lane_e * 16, 0, 0);
 #else
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, pix[i] >= 0 ? (pix[i] * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
+                        const int px = pixel(i, j);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rsO, px >= 0 ? (px * a.out_cs + n0 + 4 * h) * 4 : kOob, 0, 0);
 #endif
+                    }
+                    if constexpr (RES) {
+                        if (j == 0) {  // column 3 into the slot column 0 just left
+                            __builtin_amdgcn_sched_barrier(0);
+                            ld_res(3);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             } else {
@@ -584,9 +640,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
                     for (int i = 0; i < 4; ++i) {
                         const bool ok = (oy0 + i < a.Ho) & (ox0 + j < a.Wo);
                         const int pix = ok ? (oy0 + i) * a.Wo + ox0 + j : -1;
-                        f32x4 o = Y[4 * i + j] + b4;
+                        f32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        for (int e = 0; e < 4; ++e) {
+                            o[e] = Y[4 * i + j][e] + b4[e];
+                            o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        }
                         if (elu) {  // (wave-uniform; the LeakyReLU / identity path above costs ELU layers 8 idle operations, the others nothing)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? __expf(o[e]) - 1.0f : o[e];
@@ -601,6 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
         if (!has_next) break;
         t_cur = t_next;
         cur = nxt;
+        derive_lane_constants();
 #ifdef IDH_ABL_W4_TRACE
         ++tile_i;
 #endif
@@ -642,8 +702,9 @@ int launch_conv_wino4(const ConvArgs &a, int N, hipStream_t st) {
     wa.tiles = (int)tiles;
     long long grid = 2ll * wino4_cus();
     if (grid > wa.tiles) grid = wa.tiles >= 8 ? wa.tiles / 8 * 8 : wa.tiles;
-    if (a.s[1].in) hipLaunchKernelGGL(conv3x3_wino4_k<true>, dim3((unsigned)grid), dim3(256), 0, st, wa);
-    else hipLaunchKernelGGL(conv3x3_wino4_k<false>, dim3((unsigned)grid), dim3(256), 0, st, wa);
+    if (a.s[1].in) hipLaunchKernelGGL((conv3x3_wino4_k<true, false>), dim3((unsigned)grid), dim3(256), 0, st, wa);
+    else if (a.res) hipLaunchKernelGGL((conv3x3_wino4_k<false, true>), dim3((unsigned)grid), dim3(256), 0, st, wa);
+    else hipLaunchKernelGGL((conv3x3_wino4_k<false, false>), dim3((unsigned)grid), dim3(256), 0, st, wa);
     IDH_CHECK_LAUNCH();
     return IDH_OK;
 }

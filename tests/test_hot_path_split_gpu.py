@@ -26,7 +26,7 @@ def test_bdmodel_golden_with_split_convs(volume, split_default):
 
 @pytest.mark.parametrize("volume", ["mlp", "dot"])
 def test_full_size_bdmodel_golden_with_split_kernels(volume, split_everything):
-    base.test_full_size_bdmodel_forward_golden(volume)
+    base.test_full_size_bdmodel_forward_golden(volume, "default")
 
 
 def test_full_size_temporal_golden_with_split_kernels(split_everything):
@@ -34,7 +34,7 @@ def test_full_size_temporal_golden_with_split_kernels(split_everything):
 
 
 def test_full_size_depthmodel_golden_with_split_kernels(split_everything):
-    base.test_full_size_depthmodel_forward_golden()
+    base.test_full_size_depthmodel_forward_golden("default")
 
 
 def test_depthmodel_golden_with_split_convs(split_default):
