@@ -451,7 +451,9 @@ class HotPathWorkload:
             times.append(e0.elapsed_time(e1) / iters)
         ms = sorted(times)[1]
         vox = self.B * self.H * self.W * self.D
-        executed = (vox // 16) * (32 * self.K + 120 + 256 + 64 / self.D) * 2048
+        # MFMAs issued per 16-voxel tile and plane: 32 per source view, 96 for the per-voxel metadata (12 slots per lane quarter; 104 at K = 8, where the
+        # plane depth needs a fourth block), 256 for layer 2, + 64 per pixel tile for the plane-independent part (csrc/feature_volume.hip)
+        executed = (vox // 16) * (32 * self.K + (96 if self.K < 8 else 104) + 256 + 64 / self.D) * 2048
         n_in = self.C * (self.K + 1) + 10 * self.K + 4
         algorithmic = 2 * vox * (n_in * 128 + 128 * 128 + 128)
         busy = busy_src = None

@@ -179,10 +179,15 @@ class CostVolumeManager(nn.Module):
         return m.to(ref_module.linear_ramp_1d11.device)
 
 
-def feature_mlp_column_maps(K: int, C: int = 16):
+def feature_mlp_column_maps(K: int, C: int = 16, fold_mask: bool = False):
     """Column index maps that re-order the reference MLP's first Linear (input layout of
     modules/cost_volume.py:681-695) into the K order csrc/feature_volume.hip builds its MFMA
-    operands in.  -1 = structurally zero column.  Returns (voxel_cols, pixel_cols, pose_cols)."""
+    operands in.  -1 = structurally zero column.  Returns (voxel_cols, pixel_cols, pose_cols).
+
+    ``fold_mask`` (fv_mlp_k: fp32, K <= 8, C = 16): the per-view "valid" inputs are identically 1 (the reference clamps z to 1e-5 before it
+    tests z > 0, geometry_utils.py:86 / cost_volume.py:216), so their weight columns belong to the bias (``feature_mlp_mask_columns``) and a
+    lane quarter carries SIX values per view - [z, dot, ray angle, ray xyz] at 6j..6j+5 - in three 16-column blocks; the plane depth sits in
+    quarter 3's first slot of the absent view 7 when K < 8, else alone in a fourth block (quarter 0, k-step 0)."""
     base = C * (K + 1)
     col_mask = lambda k: base + k
     col_z = lambda k: base + K + k
@@ -196,6 +201,25 @@ def feature_mlp_column_maps(K: int, C: int = 16):
     # metadata blocks: lane quarter q carries, for each of its J views v = q + 4j, [mask, z, dot, ray angle, ray xyz] at
     # 7j..7j+6, and (quarter 0) the plane depth at 7J.  J = 2 for K <= 8 (fv_mlp_k's fixed layout), else ceil(K/4)
     # (fv_mlp_gen_k); ceil((7J+1)/4) blocks of 16 columns
+    if fold_mask:
+        if K > 8:
+            raise ValueError("fold_mask is the layout of fv_mlp_k (K <= 8)")
+        for cblk in range(4):  # (the packed blob keeps K + 4 blocks; block 3 is empty for K < 8)
+            for q in range(4):
+                for kk in range(4):
+                    idx = 4 * cblk + kk
+                    v = q + 4 * (idx // 6)
+                    col = -1
+                    if idx < 12 and v < K:
+                        col = [col_z(v), col_dot(v), col_ang(v), col_ray(v, 0), col_ray(v, 1), col_ray(v, 2)][idx % 6]
+                    elif (K < 8 and idx == 6 and q == 3) or (K == 8 and idx == 12 and q == 0):
+                        col = col_plane
+                    voxel.append(col)
+        pixel = [C * K + i for i in range(C)]
+        for q in range(4):
+            for kk in range(4):
+                pixel.append(base_r + kk if (q == 0 and kk < 3) else -1)
+        return voxel, pixel, list(range(base_p, base_p + 3 * K))
     J = 2 if K <= 8 else -(-K // 4)
     for cblk in range(-(-(7 * J + 1) // 4)):
         for q in range(4):
@@ -214,6 +238,11 @@ def feature_mlp_column_maps(K: int, C: int = 16):
             pixel.append(base_r + kk if (q == 0 and kk < 3) else -1)
     pose = list(range(base_p, base_p + 3 * K))
     return voxel, pixel, pose
+
+
+def feature_mlp_mask_columns(K: int, C: int = 16):
+    """Columns of the first Linear that multiply the per-view "valid" inputs (identically 1: summed into the bias under ``fold_mask``)."""
+    return [C * (K + 1) + k for k in range(K)]
 
 
 # Arithmetic of the MLP kernels (feature volume, BinaryMLP): "fp32" = v_mfma_f32_16x16x4_f32 (default),
@@ -258,7 +287,8 @@ class FeatureVolumeManager(CostVolumeManager):
             raise _lib.IdhError("feature-volume kernels cover matching_dim_size 16 / 32, up to 16 source views and MLP widths [*,128,128,1]")
         if math == "f16x3" and (C != 16 or K > 8):
             raise _lib.IdhError("the split-precision feature volume covers matching_dim_size 16 and up to 8 source views")
-        vox, pix, pose = feature_mlp_column_maps(K, C)
+        fold = math == "fp32" and C == 16 and K <= 8  # fv_mlp_k's layout (csrc/feature_volume.hip); the f16x3 / generic kernels keep the mask columns
+        vox, pix, pose = feature_mlp_column_maps(K, C, fold_mask=fold)
         dev = w1.device
         w1e = torch.cat([w1, torch.zeros(128, 1, device=dev)], 1)
         pick = lambda cols: w1e[:, torch.tensor([c if c >= 0 else w1.shape[1] for c in cols], device=dev)].contiguous()
@@ -282,7 +312,10 @@ class FeatureVolumeManager(CostVolumeManager):
 
         vecs = torch.zeros(3, 128, device=dev)
         vecs[0], vecs[1], vecs[2, 0] = lins[1].bias.detach(), w3[0], lins[2].bias.detach()[0]
-        out = {"w1v": fragv(pick(vox)), "w1p": frag(pick(pix)), "pose": pick(pose), "b1": lins[0].bias.detach().contiguous(),
+        b1 = lins[0].bias.detach()
+        if fold:  # sum in fp64, as one rounding of the folded constant
+            b1 = (b1.double() + w1[:, torch.tensor(feature_mlp_mask_columns(K, C), device=dev)].double().sum(1)).float()
+        out = {"w1v": fragv(pick(vox)), "w1p": frag(pick(pix)), "pose": pick(pose), "b1": b1.contiguous(),
                "w2": fragv(w2.contiguous()), "vecs": vecs.contiguous(), "math": math}
         self.__dict__["_idh_fv"] = (key, out)
         return out

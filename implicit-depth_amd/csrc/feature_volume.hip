@@ -42,7 +42,15 @@ constexpr int kWsHom = 0, kWsT = 192, kWsInvK = 256, kWsBias = 272;
 static_assert(kWsT == 12 * IDH_MAX_SOURCE_VIEWS && kWsInvK == kWsT + 4 * IDH_MAX_SOURCE_VIEWS && kWsBias + kHid <= 400, "workspace layout");
 constexpr int kWsStrideReal = 400;
 
-__device__ __forceinline__ float lrelu01(float x) { return x >= 0.f ? x : x * 0.01f; }
+// LeakyReLU(0.01) as max(x, 0.01 x): two vector instructions instead of the three of the compare / select form, same value for every input
+// (x >= 0: x >= 0.01 x; x < 0: 0.01 x > x; NaN stays NaN) - 64 fewer instructions per plane and wave beside the MFMAs
+// (v_max_f32 through inline asm: fmaxf() in IEEE mode first canonicalises its operand with a second v_max - three instructions again)
+__device__ __forceinline__ float lrelu01(float x) {
+    float r;
+    const float y = x * 0.01f;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 
 __device__ __forceinline__ float fv_depth_plane(int i, int D, float dmin, float dmax) {
     float ramp = 0.f;
@@ -208,8 +216,11 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             f32x4 acc1[kNS];
 #pragma unroll
             for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
-            // metadata registers of this lane: [0..6] view q, [7..13] view q+4, [14] plane depth
-            const float m0 = q < K ? 1.f : 0.f, m7 = q + 4 < K ? 1.f : 0.f;  // "valid" masks: see maskv below
+            // metadata registers of this lane: six per view - z, dot, ray angle, ray xyz - [1..6] view q, [8..13] view q+4, and the plane depth.  The
+            // per-view "valid" input of the reference is identically 1 (z is clamped to 1e-5 BEFORE the z > 0 test, geometry_utils.py:86,
+            // cost_volume.py:216; NaN depths included): its weight columns are folded into the layer-1 bias on the host
+            // (implicit-depth_amd/cost_volume.py), which leaves 12 slots per lane quarter = three 16-column blocks, plus the plane depth: in the
+            // (unused) first slot of view 7 in quarter 3 when K < 8, else as the only column of a fourth block.
             float m1 = 0.f, m2 = 0.f, m8 = 0.f, m9 = 0.f;
             // Software-pipelined view loop: the projection + 4 tap loads of view k+1 are issued
             // before the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work.
@@ -254,9 +265,6 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             for (int k = 0; k < K; ++k) {
                 const Tap nxt = issue(min(k + 1, K - 1));  // unconditional: counted vmcnt waits
                 const float z = cur.z;
-                // the per-view "valid" input: (z > 0) AFTER z was clamped to 1e-5 (geometry_utils.py:86, cost_volume.py:216) — identically
-                // 1, NaN depths included (fmaxf(NaN, 1e-5) = 1e-5): a constant of the lane's two views, not per-view work
-                constexpr float maskv = 1.f;
                 f32x4 wv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -336,16 +344,23 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 if (v1 < K) ray(v1, m10, m11, m12, m13);
 #endif
             }
-            const f32x4 mb[4] = {(f32x4){m0, m1, m2, m3}, (f32x4){m4, m5, m6, m7}, (f32x4){m8, m9, m10, m11},
-                                 (f32x4){m12, m13, depth, 0.f}};
+            const bool depth_in_q3 = K < 8;
+            if (depth_in_q3 && q == 3) m8 = depth;
+            const f32x4 mb[4] = {(f32x4){m1, m2, m3, m4}, (f32x4){m5, m6, m8, m9}, (f32x4){m10, m11, m12, m13}, (f32x4){depth, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 3; ++c) {
 #pragma unroll
                 for (int i = 0; i < kNS; ++i) {
                     const f32x4 A = sW1[((K + c) * kNS + i) * 64 + lane];
-                    // the last metadata slot of every quarter (block 3, k-step 3) is structurally zero in operand and weights
 #pragma unroll
-                    for (int kk = 0; kk < (c == 3 ? 3 : 4); ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], mb[c][kk], acc1[i], 0, 0, 0);
+                    for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], mb[c][kk], acc1[i], 0, 0, 0);
+                }
+            }
+            if (!depth_in_q3) {  // K = 8: the plane depth is the only column of block 3 (quarter 0, k-step 0)
+#pragma unroll
+                for (int i = 0; i < kNS; ++i) {
+                    const float A0 = reinterpret_cast<const float *>(&sW1[((K + 3) * kNS + i) * 64 + lane])[0];
+                    acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, mb[3][0], acc1[i], 0, 0, 0);
                 }
             }
             // ---- LeakyReLU(0.01) -> layer 2 (weights from LDS) -> LeakyReLU -> layer 3 ----------

@@ -53,6 +53,17 @@ def test_feature_mlp_column_maps_are_a_permutation_of_the_reference_layout():
         n_in = 16 * (K + 1) + 10 * K + 4
         assert sorted(used) == list(range(n_in)), "every reference MLP input column appears exactly once"
         assert len(vox) == 16 * (K + 4) and len(pix) == 32 and len(pose) == 3 * K
+    # fv_mlp_k's layout: the per-view "valid" columns (identically-1 inputs) go to the bias, everything else appears exactly once
+    for K in (1, 2, 7, 8):
+        vox, pix, pose = cv.feature_mlp_column_maps(K, fold_mask=True)
+        used = [c for c in vox + pix + pose + cv.feature_mlp_mask_columns(K) if c >= 0]
+        assert sorted(used) == list(range(16 * (K + 1) + 10 * K + 4))
+        assert len(vox) == 16 * (K + 4) and len(pix) == 32 and len(pose) == 3 * K
+        plane = 16 * (K + 1) + 2 * K
+        blk, rem = divmod(vox[16 * K:].index(plane), 16)
+        assert (blk, rem // 4, rem % 4) == ((1, 3, 2) if K < 8 else (3, 0, 0)), "plane depth: quarter 3's first view-7 slot, or alone in block 3"
+        if K < 8:
+            assert all(c < 0 for c in vox[16 * (K + 3):]), "block 3 is empty below 8 views"
 
 
 def test_inference_mode_parameters_invalidate_weight_caches_on_load_state_dict():
