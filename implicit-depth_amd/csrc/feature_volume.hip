@@ -207,6 +207,24 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             }
         }
 
+        // ---- the projection of a source view is computed ONCE per voxel, by the lane quarter that owns the view's metadata (quarter q: views q and
+        // q + 4), and handed to the other three quarters through ds_bpermute_b32: packed tap address + 4 bilinear weights = 5 values per view
+        // instead of ~65 vector instructions repeated by all four lanes of the voxel (the fp32 MFMAs and the vector ALU share the SIMD: every
+        // instruction removed is matrix time).  Plane-independent parts of the own two views' homographies stay in registers.
+        const int ov[2] = {min(q, K - 1), min(q + 4, K - 1)};  // (absent views: a valid stand-in whose results nobody reads)
+        float oq[2][3], oh[2][3];
+#pragma unroll
+        for (int jv = 0; jv < 2; ++jv) {
+            const float *hm = pb + kWsHom + 12 * ov[jv];
+            oq[jv][0] = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
+            oq[jv][1] = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
+            oq[jv][2] = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
+            oh[jv][0] = hm[9]; oh[jv][1] = hm[10]; oh[jv][2] = hm[11];
+        }
+        // taps through a buffer descriptor of this frame's K source maps: 32-bit offsets (view k: scalar offset k * N * 64 bytes)
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src + (size_t)b * a.src_bs), 0, K * N * kC * 4, 0x00020000);
+        const int bp0 = 4 * ln;  // ds_bpermute address of this voxel's lane in quarter 0 (+ 64 per quarter)
+
         f32x4 ob = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bool vec_ok = ((d0 & 3) == 0) && ((a.vol_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.vol) & 15) == 0);
 #pragma unroll 1
@@ -222,24 +240,17 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             // (implicit-depth_amd/cost_volume.py), which leaves 12 slots per lane quarter = three 16-column blocks, plus the plane depth: in the
             // (unused) first slot of view 7 in quarter 3 when K < 8, else as the only column of a fourth block.
             float m1 = 0.f, m2 = 0.f, m8 = 0.f, m9 = 0.f;
-            // Software-pipelined view loop: the projection + 4 tap loads of view k+1 are issued
-            // before the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work.
-            struct Tap {
-                f32x4 t00, t01, t10, t11;
-                float w00, w01, w10, w11, z;
-            };
-            auto issue = [&](int k) {
-                Tap t;
-                const float *hm = pb + kWsHom + 12 * k;
-                const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
-                const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
-                const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
-                const float cx = fmaf(depth, qx, hm[9]);
-                const float cy = fmaf(depth, qy, hm[10]);
-                const float cz = fmaf(depth, qz, hm[11]);
-                t.z = fmaxf(cz, 1e-5f);
-                float r = __builtin_amdgcn_rcpf(t.z);
-                r = r * fmaf(-t.z, r, 2.0f);
+            // own views: projection, bilinear weights and the packed tap address (pixel index of tap 00 | x step << 30 | y step << 31)
+            struct Own { int pk; float w00, w01, w10, w11, z; };
+            Own own[2];
+#pragma unroll
+            for (int jv = 0; jv < 2; ++jv) {
+                const float cx = fmaf(depth, oq[jv][0], oh[jv][0]);
+                const float cy = fmaf(depth, oq[jv][1], oh[jv][1]);
+                const float cz = fmaf(depth, oq[jv][2], oh[jv][2]);
+                const float z = fmaxf(cz, 1e-5f);
+                float r = __builtin_amdgcn_rcpf(z);
+                r = r * fmaf(-z, r, 2.0f);
                 const float su = cx * r, sv = cy * r;
                 const float sx = fminf(fmaxf(su - 0.5f, -1.0f), Wf);
                 const float sy = fminf(fmaxf(sv - 0.5f, -1.0f), Hf);
@@ -252,31 +263,61 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
                 const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
                 const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
-                const float *sb = a.src + (size_t)b * a.src_bs + (size_t)k * N * kC + 4 * q;
-                t.t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kC);
-                t.t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kC);
-                t.t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kC);
-                t.t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kC);
-                t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
+                own[jv].pk = (ya0 * a.W + xa0) | ((xa1 - xa0) << 30) | ((ya1 - ya0) << 31);
+                own[jv].w00 = wx0 * wy0; own[jv].w01 = wx1 * wy0; own[jv].w10 = wx0 * wy1; own[jv].w11 = wx1 * wy1;
+                own[jv].z = z;
+            }
+            m1 = q < K ? own[0].z : 0.f;
+            m8 = q + 4 < K ? own[1].z : 0.f;
+            // Software-pipelined view loop: the tap address of view k+1 is fetched from its owner quarter and its 4 tap loads are issued before
+            // the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work; the weights follow one view behind the address.
+            struct Tap { f32x4 t00, t01, t10, t11; };
+            struct Wts { float w00, w01, w10, w11; };
+            auto bperm = [&](int k, float v) -> float {
+                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp0 + 64 * (k & 3), __builtin_bit_cast(int, v)));
+            };
+            auto issue = [&](int k) {  // k: compile-time after unrolling (selects own[k >> 2] and the source quarter k & 3)
+                const Own &o = own[k >> 2];
+                const int pk = __builtin_amdgcn_ds_bpermute(bp0 + 64 * (k & 3), o.pk);
+                const int o00 = ((pk & 0x3fffffff) << 6) + 16 * q;
+                const int o01 = o00 + (((pk >> 30) & 1) << 6);
+                const int ystep = (int)((unsigned)pk >> 31) * (a.W * 64);
+                Tap t;
+                const int so = __builtin_amdgcn_readfirstlane(k * N * (kC * 4));
+                t.t00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o00, so, 0));
+                t.t01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o01, so, 0));
+                t.t10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o00 + ystep, so, 0));
+                t.t11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o01 + ystep, so, 0));
                 return t;
             };
+            auto weights = [&](int k) {
+                const Own &o = own[k >> 2];
+                Wts w;
+                w.w00 = bperm(k, o.w00); w.w01 = bperm(k, o.w01); w.w10 = bperm(k, o.w10); w.w11 = bperm(k, o.w11);
+                return w;
+            };
+            constexpr int KU = KT > 0 ? KT : kMaxK;
             Tap cur = issue(0);
-#pragma clang loop unroll_count(KT > 0 ? KT : 1)
-            for (int k = 0; k < K; ++k) {
-                const Tap nxt = issue(min(k + 1, K - 1));  // unconditional: counted vmcnt waits
-                const float z = cur.z;
+            Wts wc = weights(0);
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                if (KT == 0 && k >= K) break;
+                const int kn = (KT > 0) ? (k + 1 < KT ? k + 1 : k) : k + 1;  // (KT = 0: the stand-in of an absent view k + 1 < 8 is fetched, never used)
+                Tap nxt = cur;
+                Wts wn = wc;
+                if (kn != k && kn < KU) { nxt = issue(kn); wn = weights(kn); }
                 f32x4 wv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    wv[e] = fmaf(cur.w11, cur.t11[e], fmaf(cur.w10, cur.t10[e], fmaf(cur.w01, cur.t01[e], cur.w00 * cur.t00[e])));
+                    wv[e] = fmaf(wc.w11, cur.t11[e], fmaf(wc.w10, cur.t10[e], fmaf(wc.w01, cur.t01[e], wc.w00 * cur.t00[e])));
                 float part = wv[0] * cur4[0];
                 part = fmaf(wv[1], cur4[1], part); part = fmaf(wv[2], cur4[2], part); part = fmaf(wv[3], cur4[3], part);
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
                 const float dotv = part;  // * mask (== 1)
                 const bool s0 = (k == q), s1 = (k == q + 4);
-                m1 = s0 ? z : m1; m2 = s0 ? dotv : m2;
-                m8 = s1 ? z : m8; m9 = s1 ? dotv : m9;
+                m2 = s0 ? dotv : m2;
+                m9 = s1 ? dotv : m9;
                 // layer-1 block k: warped features of view k
 #pragma unroll
                 for (int i = 0; i < kNS; ++i) {
@@ -285,13 +326,8 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                     for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
                 }
                 if constexpr (KT > 0) {
-                    // Scheduling hint (unrolled view loop = one scheduling region): ask for small alternating groups of MFMAs and
-                    // vector instructions instead of a ~90-instruction vector block followed by 32 back-to-back matrix ops.
-                    // fp32 MFMA and VALU do not overlap on a SIMD, so this only trims dependency stalls — and the
-                    // best pattern follows the vector-instruction count of a view: "1 MFMA, 2 VALU" x 32 was best with the
-                    // mask tracked in this loop (17.81 -> 17.33 ms per 32 frames, K=7, D=64); with the mask moved out of the
-                    // loop that pattern costs 17.58, no hint 17.33, a plain sched_barrier per view 17.21 and "2 MFMA, 3 VALU"
-                    // x 16: 17.19.  Hand-made pipelines across views were all slower (profiles/r02/experiments.md).
+                    // Scheduling hint (unrolled view loop = one scheduling region): small alternating groups of MFMAs and vector instructions
+                    // instead of a vector block followed by 32 back-to-back matrix ops (history of the pattern: profiles/r02/experiments.md)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -302,6 +338,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                     }
                 }
                 cur = nxt;
+                wc = wn;
             }
             // rays / ray angles of this lane's two views (cost_volume.py:630-659)
             float m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m10 = 0.f, m11 = 0.f, m12 = 0.f, m13 = 0.f;
