@@ -42,14 +42,15 @@ constexpr int kWsHom = 0, kWsT = 192, kWsInvK = 256, kWsBias = 272;
 static_assert(kWsT == 12 * IDH_MAX_SOURCE_VIEWS && kWsInvK == kWsT + 4 * IDH_MAX_SOURCE_VIEWS && kWsBias + kHid <= 400, "workspace layout");
 constexpr int kWsStrideReal = 400;
 
-// LeakyReLU(0.01) as max(x, 0.01 x): two vector instructions instead of the three of the compare / select form, same value for every input
-// (x >= 0: x >= 0.01 x; x < 0: 0.01 x > x; NaN stays NaN) - 64 fewer instructions per plane and wave beside the MFMAs
-// (v_max_f32 through inline asm: fmaxf() in IEEE mode first canonicalises its operand with a second v_max - three instructions again)
+// LeakyReLU(0.01), three vector instructions (multiply, compare, select).  max(x, 0.01 x) would be two - but fmaxf() in IEEE mode canonicalises its
+// operand with an extra v_max (three again), and a bare v_max_f32 through inline asm is NOT safe here: hipcc does not track the MFMA -> VALU
+// wait states for inline asm operands, and fv_mlp_k<8> with its layer-2 chunks scheduled freely produced wrong values with it (measured,
+// profiles/r05/experiments.md; the ~0.1 ms it saved is not worth a hazard the compiler cannot see).
 __device__ __forceinline__ float lrelu01(float x) {
-    float r;
-    const float y = x * 0.01f;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
+#ifdef IDH_ABL_FV2_NOACT
+    return x;
+#endif
+    return x >= 0.f ? x : x * 0.01f;
 }
 
 __device__ __forceinline__ float fv_depth_plane(int i, int D, float dmin, float dmax) {
@@ -227,24 +228,30 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 
         f32x4 ob = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bool vec_ok = ((d0 & 3) == 0) && ((a.vol_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.vol) & 15) == 0);
-#pragma unroll 1
-        for (int d = d0; d < d1; ++d) {
-            const float depth = fv_plane(a, b, p, d);
-            const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
-            f32x4 acc1[kNS];
+        // ---- per-plane prologue of a voxel: the own two views' projection (bilinear weights, packed tap address: pixel index of tap 00 | x step << 30 |
+        // y step << 31) and their viewing rays / ray angles (cost_volume.py:630-659).  It runs ONE PLANE AHEAD, inside the previous plane's layer 2
+        // (256 MFMAs to hide under), together with the first view's tap loads: computed at the top of its own plane, the dependent chain
+        // projection -> ds_bpermute -> address -> tap loads (L2 latency) -> blend stood in front of every plane's first MFMA.
+        struct Own { int pk; float w00, w01, w10, w11, z; };
+        struct Pro { Own own[2]; float depth, m3, m4, m5, m6, m10, m11, m12, m13; };
+        struct Tap { f32x4 t00, t01, t10, t11; };
+        struct Wts { float w00, w01, w10, w11; };
+        float oc[2][3];  // source camera centres of the own views (cost_volume.py:630-633)
 #pragma unroll
-            for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
-            // metadata registers of this lane: six per view - z, dot, ray angle, ray xyz - [1..6] view q, [8..13] view q+4, and the plane depth.  The
-            // per-view "valid" input of the reference is identically 1 (z is clamped to 1e-5 BEFORE the z > 0 test, geometry_utils.py:86,
-            // cost_volume.py:216; NaN depths included): its weight columns are folded into the layer-1 bias on the host
-            // (implicit-depth_amd/cost_volume.py), which leaves 12 slots per lane quarter = three 16-column blocks, plus the plane depth: in the
-            // (unused) first slot of view 7 in quarter 3 when K < 8, else as the only column of a fourth block.
-            float m1 = 0.f, m2 = 0.f, m8 = 0.f, m9 = 0.f;
-            // own views: projection, bilinear weights and the packed tap address (pixel index of tap 00 | x step << 30 | y step << 31)
-            struct Own { int pk; float w00, w01, w10, w11, z; };
-            Own own[2];
+        for (int jv = 0; jv < 2; ++jv) {
+            const float *t = pb + kWsT + 4 * ov[jv];
+            oc[jv][0] = t[0]; oc[jv][1] = t[1]; oc[jv][2] = t[2];
+        }
+        auto prologue = [&](int d) {
+            Pro P;
+            const float depth = fv_plane(a, b, p, d);
+            P.depth = depth;
 #pragma unroll
             for (int jv = 0; jv < 2; ++jv) {
+#ifdef IDH_ABL_FV2_NOPRO
+                P.own[jv].pk = p; P.own[jv].w00 = P.own[jv].w01 = P.own[jv].w10 = P.own[jv].w11 = depth; P.own[jv].z = depth;
+                continue;
+#endif
                 const float cx = fmaf(depth, oq[jv][0], oh[jv][0]);
                 const float cy = fmaf(depth, oq[jv][1], oh[jv][1]);
                 const float cz = fmaf(depth, oq[jv][2], oh[jv][2]);
@@ -263,50 +270,86 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
                 const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
                 const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
-                own[jv].pk = (ya0 * a.W + xa0) | ((xa1 - xa0) << 30) | ((ya1 - ya0) << 31);
-                own[jv].w00 = wx0 * wy0; own[jv].w01 = wx1 * wy0; own[jv].w10 = wx0 * wy1; own[jv].w11 = wx1 * wy1;
-                own[jv].z = z;
+                P.own[jv].pk = (ya0 * a.W + xa0) | ((xa1 - xa0) << 30) | ((ya1 - ya0) << 31);
+                P.own[jv].w00 = wx0 * wy0; P.own[jv].w01 = wx1 * wy0; P.own[jv].w10 = wx0 * wy1; P.own[jv].w11 = wx1 * wy1;
+                P.own[jv].z = z;
             }
-            m1 = q < K ? own[0].z : 0.f;
-            m8 = q + 4 < K ? own[1].z : 0.f;
+            // unit ray e = (X - c) / |X - c| through v_rsq_f32 + one Newton step (<= 1 ulp), and the ray angle as the plain dot product cr . e: the
+            // reference divides it by max(|cr|, 1e-5) max(|e|, 1e-5) (cosine_similarity), both 1 up to rounding for unit vectors - a 1e-7 relative
+            // difference, three orders below the 1e-4 bar.  (Absent views: computed on the stand-in view, multiplied by zero weight columns.)
+            const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
+            auto ray = [&](int jv, float &ang, float &e0, float &e1, float &e2) {
+                const float ax = Xx - oc[jv][0], ay = Xy - oc[jv][1], az = Xz - oc[jv][2];
+                const float n2 = fmaf(az, az, fmaf(ay, ay, ax * ax));
+                float in = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));
+                in = in * fmaf(-0.5f * n2 * in, in, 1.5f);
+                e0 = ax * in; e1 = ay * in; e2 = az * in;
+                ang = fmaf(crz, e2, fmaf(cry, e1, crx * e0));
+            };
+#ifdef IDH_ABL_FV2_NORAY
+            P.m3 = P.m4 = P.m5 = P.m6 = P.m10 = P.m11 = P.m12 = P.m13 = depth;
+            return P;
+#endif
+            ray(0, P.m3, P.m4, P.m5, P.m6);
+            ray(1, P.m10, P.m11, P.m12, P.m13);
+            return P;
+        };
+        auto issue = [&](const Pro &P, int k) {  // k: compile-time after unrolling (selects own[k >> 2] and the source quarter k & 3)
+            const int pk = __builtin_amdgcn_ds_bpermute(bp0 + 64 * (k & 3), P.own[k >> 2].pk);
+            const int o00 = ((pk & 0x3fffffff) << 6) + 16 * q;
+            const int o01 = o00 + (((pk >> 30) & 1) << 6);
+            const int ystep = (int)((unsigned)pk >> 31) * (a.W * 64);
+            Tap t;
+#ifdef IDH_ABL_FV2_NOTAPS  // (timing experiments, tools/abl_fv32.sh: results are meaningless)
+            t.t00 = t.t01 = t.t10 = t.t11 = (f32x4){1.f + (float)o00, 2.f + (float)o01, 3.f + (float)ystep, 4.f};
+            return t;
+#endif
+            const int so = __builtin_amdgcn_readfirstlane(k * N * (kC * 4));
+            t.t00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o00, so, 0));
+            t.t01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o01, so, 0));
+            t.t10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o00 + ystep, so, 0));
+            t.t11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o01 + ystep, so, 0));
+            return t;
+        };
+        auto weights = [&](const Pro &P, int k) {
+            const Own &o = P.own[k >> 2];
+            auto bperm = [&](float v) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp0 + 64 * (k & 3), __builtin_bit_cast(int, v))); };
+            Wts w;
+            w.w00 = bperm(o.w00); w.w01 = bperm(o.w01); w.w10 = bperm(o.w10); w.w11 = bperm(o.w11);
+            return w;
+        };
+        Pro P = prologue(d0);
+        Tap cur = issue(P, 0);
+        Wts wc = weights(P, 0);
+#pragma unroll 1
+        for (int d = d0; d < d1; ++d) {
+            const float depth = P.depth;
+            f32x4 acc1[kNS];
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
+            // metadata registers of this lane: six per view - z, dot, ray angle, ray xyz - [1..6] view q, [8..13] view q+4, and the plane depth.  The
+            // per-view "valid" input of the reference is identically 1 (z is clamped to 1e-5 BEFORE the z > 0 test, geometry_utils.py:86,
+            // cost_volume.py:216; NaN depths included): its weight columns are folded into the layer-1 bias on the host
+            // (implicit-depth_amd/cost_volume.py), which leaves 12 slots per lane quarter = three 16-column blocks, plus the plane depth: in the
+            // (unused) first slot of view 7 in quarter 3 when K < 8, else as the only column of a fourth block.
+            float m2 = 0.f, m9 = 0.f;
+            const float m1 = q < K ? P.own[0].z : 0.f;
+            float m8 = q + 4 < K ? P.own[1].z : 0.f;
             // Software-pipelined view loop: the tap address of view k+1 is fetched from its owner quarter and its 4 tap loads are issued before
-            // the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work; the weights follow one view behind the address.
-            struct Tap { f32x4 t00, t01, t10, t11; };
-            struct Wts { float w00, w01, w10, w11; };
-            auto bperm = [&](int k, float v) -> float {
-                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp0 + 64 * (k & 3), __builtin_bit_cast(int, v)));
-            };
-            auto issue = [&](int k) {  // k: compile-time after unrolling (selects own[k >> 2] and the source quarter k & 3)
-                const Own &o = own[k >> 2];
-                const int pk = __builtin_amdgcn_ds_bpermute(bp0 + 64 * (k & 3), o.pk);
-                const int o00 = ((pk & 0x3fffffff) << 6) + 16 * q;
-                const int o01 = o00 + (((pk >> 30) & 1) << 6);
-                const int ystep = (int)((unsigned)pk >> 31) * (a.W * 64);
-                Tap t;
-                const int so = __builtin_amdgcn_readfirstlane(k * N * (kC * 4));
-                t.t00 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o00, so, 0));
-                t.t01 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o01, so, 0));
-                t.t10 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o00 + ystep, so, 0));
-                t.t11 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o01 + ystep, so, 0));
-                return t;
-            };
-            auto weights = [&](int k) {
-                const Own &o = own[k >> 2];
-                Wts w;
-                w.w00 = bperm(k, o.w00); w.w01 = bperm(k, o.w01); w.w10 = bperm(k, o.w10); w.w11 = bperm(k, o.w11);
-                return w;
-            };
+            // the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work; the weights follow with the address.
             constexpr int KU = KT > 0 ? KT : kMaxK;
-            Tap cur = issue(0);
-            Wts wc = weights(0);
 #pragma unroll
             for (int k = 0; k < KU; ++k) {
                 if (KT == 0 && k >= K) break;
                 const int kn = (KT > 0) ? (k + 1 < KT ? k + 1 : k) : k + 1;  // (KT = 0: the stand-in of an absent view k + 1 < 8 is fetched, never used)
                 Tap nxt = cur;
                 Wts wn = wc;
-                if (kn != k && kn < KU) { nxt = issue(kn); wn = weights(kn); }
+                if (kn != k && kn < KU) { nxt = issue(P, kn); wn = weights(P, kn); }
                 f32x4 wv;
+#ifdef IDH_ABL_FV2_NOBLEND
+                wv = cur.t00 + cur.t11;
+                float part = wc.w00 + wc.w11 + cur.t01[0] + cur.t10[0];
+#else
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     wv[e] = fmaf(wc.w11, cur.t11[e], fmaf(wc.w10, cur.t10[e], fmaf(wc.w01, cur.t01[e], wc.w00 * cur.t00[e])));
@@ -314,6 +357,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 part = fmaf(wv[1], cur4[1], part); part = fmaf(wv[2], cur4[2], part); part = fmaf(wv[3], cur4[3], part);
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
+#endif
                 const float dotv = part;  // * mask (== 1)
                 const bool s0 = (k == q), s1 = (k == q + 4);
                 m2 = s0 ? dotv : m2;
@@ -321,7 +365,11 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 // layer-1 block k: warped features of view k
 #pragma unroll
                 for (int i = 0; i < kNS; ++i) {
+#ifdef IDH_ABL_FV2_NOLDSA
+                    const f32x4 A = (f32x4){1.f, 2.f, 3.f, 4.f} * (float)(i + 1);
+#else
                     const f32x4 A = sW1[(k * kNS + i) * 64 + lane];
+#endif
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
                 }
@@ -340,47 +388,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 cur = nxt;
                 wc = wn;
             }
-            // rays / ray angles of this lane's two views (cost_volume.py:630-659)
-            float m3 = 0.f, m4 = 0.f, m5 = 0.f, m6 = 0.f, m10 = 0.f, m11 = 0.f, m12 = 0.f, m13 = 0.f;
-            {
-                const int v0 = q, v1 = q + 4;
-#ifdef IDH_ABL_FV_OLDRAY
-                if (v0 < K) {
-                    const float *t = pb + kWsT + 4 * v0;
-                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
-                    const float in = 1.0f / fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
-                    m4 = ax * in; m5 = ay * in; m6 = az * in;
-                    const float n1 = fmaxf(sqrtf(crx * crx + cry * cry + crz * crz), 1e-5f);
-                    const float n2 = fmaxf(sqrtf(m4 * m4 + m5 * m5 + m6 * m6), 1e-5f);
-                    m3 = (crx * m4 + cry * m5 + crz * m6) / (n1 * n2);
-                }
-                if (v1 < K) {
-                    const float *t = pb + kWsT + 4 * v1;
-                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
-                    const float in = 1.0f / fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
-                    m11 = ax * in; m12 = ay * in; m13 = az * in;
-                    const float n1 = fmaxf(sqrtf(crx * crx + cry * cry + crz * crz), 1e-5f);
-                    const float n2 = fmaxf(sqrtf(m11 * m11 + m12 * m12 + m13 * m13), 1e-5f);
-                    m10 = (crx * m11 + cry * m12 + crz * m13) / (n1 * n2);
-                }
-#else
-                // unit ray e = (X - c) / |X - c| through v_rsq_f32 + one Newton step (<= 1 ulp), and the ray angle as the plain dot
-                // product cr . e: the reference divides it by max(|cr|, 1e-5) max(|e|, 1e-5) (cosine_similarity), both 1 up to
-                // rounding for unit vectors — a 1e-7 relative difference, three orders below the 1e-4 bar, for ~25 fewer vector
-                // instructions per view pair and plane (fp32 MFMA and VALU share the SIMD: every one is paid in matrix time)
-                auto ray = [&](int v, float &ang, float &e0, float &e1, float &e2) {
-                    const float *t = pb + kWsT + 4 * v;
-                    const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
-                    const float n2 = fmaf(az, az, fmaf(ay, ay, ax * ax));
-                    float in = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));
-                    in = in * fmaf(-0.5f * n2 * in, in, 1.5f);
-                    e0 = ax * in; e1 = ay * in; e2 = az * in;
-                    ang = fmaf(crz, e2, fmaf(cry, e1, crx * e0));
-                };
-                if (v0 < K) ray(v0, m3, m4, m5, m6);
-                if (v1 < K) ray(v1, m10, m11, m12, m13);
-#endif
-            }
+            const float m3 = P.m3, m4 = P.m4, m5 = P.m5, m6 = P.m6, m10 = P.m10, m11 = P.m11, m12 = P.m12, m13 = P.m13;
             const bool depth_in_q3 = K < 8;
             if (depth_in_q3 && q == 3) m8 = depth;
             const f32x4 mb[4] = {(f32x4){m1, m2, m3, m4}, (f32x4){m5, m6, m8, m9}, (f32x4){m10, m11, m12, m13}, (f32x4){depth, 0.f, 0.f, 0.f}};
@@ -402,6 +410,9 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             }
             // ---- LeakyReLU(0.01) -> layer 2 (weights from LDS) -> LeakyReLU -> layer 3 ----------
             f32x4 acc2[kNS];
+            Pro Pn;
+            Tap curn;
+            Wts wcn;
 #pragma unroll
             for (int i = 0; i < kNS; ++i) {
 #pragma unroll
@@ -412,13 +423,31 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             for (int c = 0; c < kNS; ++c) {
 #pragma unroll
                 for (int i = 0; i < kNS; ++i) {
+#ifdef IDH_ABL_FV2_NOLDSA
+                    const f32x4 A = (f32x4){1.f, 2.f, 3.f, 4.f} * (float)(i + 1);
+#else
                     const f32x4 A = sW2[(c * kNS + i) * 64 + lane];
+#endif
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], acc1[c][kk], acc2[i], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                // The NEXT plane's prologue and first taps ride on layer 2 (the last plane of a task repeats its own: harmless).  Measured placements,
+                // 32 frames (profiles/r05/experiments.md): prologue at the top of its own plane 15.45 ms; here with a sched_barrier per chunk 15.48 (no
+                // gain: the scheduler then runs the chunk's 32 MFMAs first and the whole dependent chain after them); without the per-chunk barriers,
+                // in chunk 0 / 1 / 4: 14.9 / 15.1 / 15.3; before the activation 15.5; before the metadata MFMAs 15.4.
+                // (Run-time view count, KT = 0: chunk 1 and a barrier per chunk - without them that variant spills 400 B per lane.)
+                if (c == (KT > 0 ? 0 : 1)) {
+                    Pn = prologue(min(d + 1, d1 - 1));
+                    curn = issue(Pn, 0);
+                    wcn = weights(Pn, 0);
+                }
+                if constexpr (KT == 0) __builtin_amdgcn_sched_barrier(0);
             }
             float s = 0.f;
+#ifdef IDH_ABL_FV2_NOL3
+#pragma unroll
+            for (int i = 0; i < kNS; ++i) s += acc2[i][0];
+#else
 #pragma unroll
             for (int i = 0; i < kNS; ++i) {
                 const f32x4 w3 = *reinterpret_cast<const f32x4 *>(s_w3 + 16 * i + 4 * q);
@@ -427,6 +456,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             }
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
+#endif
             const float val = s + b3;
             if (a.vol_cs > 0) {
                 // NHWC output: collect 4 consecutive planes and write one 16-byte vector (a 4-byte store
@@ -463,6 +493,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 }
                 if (q == 0 && live) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
             }
+            P = Pn; cur = curn; wc = wcn;
         }
     }
 }
@@ -1154,6 +1185,8 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_gen_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k<7>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(fv_mlp_f16_k<7>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1178,6 +1211,7 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     } else {
         const size_t lds = ((size_t)(K + 4) * kNS * 64 + kNS * kNS * 64) * sizeof(f32x4);
         if (K == 7) hipLaunchKernelGGL(fv_mlp_k<7>, dim3(grid), dim3(512), lds, st, a);
+        else if (K == 8) hipLaunchKernelGGL(fv_mlp_k<8>, dim3(grid), dim3(512), lds, st, a);  // (BASELINE.json's literal 8 source views)
         else hipLaunchKernelGGL(fv_mlp_k<0>, dim3(grid), dim3(512), lds, st, a);
     }
     IDH_CHECK_LAUNCH();
