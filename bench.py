@@ -367,7 +367,8 @@ class HotPathWorkload:
         from implicit_depth_amd import nhwc
 
         if op.tile_m == nhwc.TILE_WINO4:
-            return f"conv3x3_wino4_k<{'true' if op.src[1].in_ else 'false'}>"
+            # conv3x3_wino4_k<SRC2, RES>: fused 1x1 projection of a second tensor / residual added in the epilogue (never both)
+            return f"conv3x3_wino4_k<{'true' if op.src[1].in_ else 'false'}, {'true' if (op.res and not op.src[1].in_) else 'false'}>"
         if op.tile_m == nhwc.TILE_WINO:
             return f"conv3x3_wino_{'group_' if grouped else ''}k<4, 2, 8, {'true' if op.src[1].in_ else 'false'}>"
         if op.tile_m in (10, 11):

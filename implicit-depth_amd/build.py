@@ -25,7 +25,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # -amdgpu-prealloc-sgpr-spill-vgprs: the lanes that take spilled scalars are reserved before vector allocation; without it the late reservation
 # fragments the file and the two staging quads held across the transform end up in scratch (tools/kernel_resources.py: 36 -> 8 B/lane, the 8 inside
 # the epilogue)
-EXTRA_FLAGS = {"conv_wino4.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-prealloc-sgpr-spill-vgprs"]}
+EXTRA_FLAGS = {"conv_wino4.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-prealloc-sgpr-spill-vgprs"],
+               "conv_wino4p.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-prealloc-sgpr-spill-vgprs"]}
 
 
 def _hipcc() -> str:

@@ -73,5 +73,6 @@ int launch_conv_wino_group(const ConvArgs *const *as, const int *Ns, int n, hipS
 // conv_wino4.hip: Winograd F(4x4,3x3) on the fp32 matrix cores (3x3 stride 1, zero padding, ONE source, Cout % 64 == 0, Cin > 16)
 bool wino4_supported(const ConvArgs &a);
 int launch_conv_wino4(const ConvArgs &a, int N, hipStream_t st);
+bool wino4_split_enabled();  // developer switch IDH_W4_SPLIT (conv_wino4.hip)
 
 }  // namespace idh_conv

@@ -21,6 +21,7 @@
 // (The round's first design kept the transformed input in registers - one wave per SIMD with 288 accumulators, every wave transforming its
 // own tiles for two 16-channel blocks - and reached 1.03-1.19x over F(2x2); its timelines and ablations are in profiles/r04/experiments.md.
 // This kernel superseded it on every layer and that code is gone.)
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_args.h"
@@ -693,14 +694,36 @@ bool wino4_supported(const ConvArgs &a) {
 }
 
 // 32 x 8 pixel x 64 channel tiles, two persistent workgroups per CU
+int launch_conv_wino4p(const ConvArgs &a, int N, hipStream_t st);                                // conv_wino4p.hip
+void launch_pack_wino4p(const float *w, float *dst, int Cout, int Cin, hipStream_t st);
+
+// Developer switch IDH_W4_SPLIT=1 (read once per process): the layers without a fused 1x1 projection run on the position-split kernel
+// conv3x3_wino4p_k (conv_wino4p.hip: 8 waves per workgroup, 18 positions per wave, four waves per SIMD) and the packed blob then holds BOTH
+// fragment orders, conv3x3_wino4_k's first.  Measured 6-8 % SLOWER than this kernel on the big layers (profiles/r05/experiments.md), so it is
+// off by default; kept buildable and parity-tested (tests/test_conv_wino4_gpu.py) as the record of that experiment.
+static bool wino4_use_split() {
+    static const bool on = getenv("IDH_W4_SPLIT") && atoi(getenv("IDH_W4_SPLIT")) != 0;
+    return on;
+}
+
+bool wino4_split_enabled() { return wino4_use_split(); }
+
 int launch_conv_wino4(const ConvArgs &a, int N, hipStream_t st) {
     if (!wino4_supported(a)) return IDH_EUNSUPPORTED;
+    if (!a.s[1].in && wino4_use_split()) {
+        ConvArgs b = a;
+        b.s[0].w = a.s[0].w + (size_t)a.s[0].cblocks * 16 * a.Cout_pad * 36;
+        return launch_conv_wino4p(b, N, st);
+    }
     Wino4Args wa{a, (a.Wo + 31) / 32, (a.Ho + 7) / 8, 0};
     wa.c.NT = a.Cout / 64;
     const long long tiles = (long long)N * wa.tiles_x * wa.tiles_y * wa.c.NT;
     if (tiles >= (1ll << 31)) return IDH_EUNSUPPORTED;
     wa.tiles = (int)tiles;
     long long grid = 2ll * wino4_cus();
+#ifdef IDH_ABL_W4_GRIDENV  // (experiment: IDH_W4_GRID = persistent workgroups)
+    if (getenv("IDH_W4_GRID")) grid = atoi(getenv("IDH_W4_GRID"));
+#endif
     if (grid > wa.tiles) grid = wa.tiles >= 8 ? wa.tiles / 8 * 8 : wa.tiles;
     if (a.s[1].in) hipLaunchKernelGGL((conv3x3_wino4_k<true, false>), dim3((unsigned)grid), dim3(256), 0, st, wa);
     else if (a.res) hipLaunchKernelGGL((conv3x3_wino4_k<false, true>), dim3((unsigned)grid), dim3(256), 0, st, wa);
@@ -713,7 +736,7 @@ int launch_conv_wino4(const ConvArgs &a, int N, hipStream_t st) {
 
 extern "C" size_t idh_packed_wino4_weight_floats(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
-    return (size_t)((Cin + 15) & ~15) * ((Cout + 15) & ~15) * 36;
+    return (idh_conv::wino4_split_enabled() ? 2 : 1) * (size_t)((Cin + 15) & ~15) * ((Cout + 15) & ~15) * 36;  // (both fragment orders: launch_conv_wino4)
 }
 
 extern "C" int idh_pack_conv_weight_wino4(const float *w, float *dst, int Cout, int Cin, void *stream) {
@@ -724,5 +747,9 @@ extern "C" int idh_pack_conv_weight_wino4(const float *w, float *dst, int Cout, 
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(pack_wino4_weight_k, dim3(grid), dim3(256), 0, idh_stream(stream), w, dst, Cout, Cin, nS, nCB);
     IDH_CHECK_LAUNCH();
+    if (idh_conv::wino4_split_enabled()) {
+        idh_conv::launch_pack_wino4p(w, dst + (size_t)((Cin + 15) & ~15) * ((Cout + 15) & ~15) * 36, Cout, Cin, idh_stream(stream));
+        IDH_CHECK_LAUNCH();
+    }
     return IDH_OK;
 }

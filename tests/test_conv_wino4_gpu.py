@@ -226,3 +226,18 @@ def test_networks_with_wino4_forced_match_goldens(wino4_everywhere):
     print("F(4x4) everywhere, BDDecoderPP vs reference golden:", errs)
     for e in errs:
         assert e < TOL
+
+
+def test_position_split_variant_in_subprocess():
+    """conv3x3_wino4p_k (csrc/conv_wino4p.hip: the 36 positions of a channel block split between two waves, four waves per SIMD) - measured
+    slower than conv3x3_wino4_k and off by default (developer switch IDH_W4_SPLIT=1, read once per process): the fp64 / direct-kernel parity
+    cases of this file, re-run in a process with the switch on, keep the experiment reproducible."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, IDH_W4_SPLIT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "vs_fp64_and_direct or elu_matches", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout

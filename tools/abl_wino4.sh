@@ -7,8 +7,9 @@ VARS="${VARS:-NOXFORM NOEPI NOA NOB NOHALO NOA,NOB,NOXFORM,NOHALO}"
 if [ "$1" = build ]; then
   for v in $VARS; do
     name=${v//,/_}; defs=""; for d in ${v//,/ }; do defs="$defs -DIDH_ABL_W4_$d"; done
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $defs -fno-slp-vectorize -mllvm -amdgpu-prealloc-sgpr-spill-vgprs -c implicit-depth_amd/csrc/conv_wino4.hip -o /tmp/w4_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls implicit-depth_amd/_obj/*.o | grep -v conv_wino4.o) /tmp/w4_$name.o -o implicit-depth_amd/_obj/abl/libidh_ablw4_$name.so && echo built $name
+    F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function $defs -fno-slp-vectorize -mllvm -amdgpu-prealloc-sgpr-spill-vgprs"
+    /opt/rocm/bin/hipcc $F -c implicit-depth_amd/csrc/conv_wino4.hip -o /tmp/w4_$name.o && /opt/rocm/bin/hipcc $F -c implicit-depth_amd/csrc/conv_wino4p.hip -o /tmp/w4p_$name.o &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls implicit-depth_amd/_obj/*.o | grep -v "conv_wino4.o\|conv_wino4p.o") /tmp/w4_$name.o /tmp/w4p_$name.o -o implicit-depth_amd/_obj/abl/libidh_ablw4_$name.so && echo built $name
   done
 elif [ "$1" = trace ]; then
   shift
