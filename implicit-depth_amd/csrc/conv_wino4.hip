@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
                         for (int e = 0; e < 4; ++e) {
                             o[e] = y[i][e] + b4[e];
                             if constexpr (RES) o[e] += r[j % 3][i][e];
-                            o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                            o[e] = fmaxf(o[e], o[e] * slope_eff);  // LeakyReLU / identity (slope_eff in [0, 1], wino4_supported): the sum above is canonical, so this is mul + v_max
                         }
                         if (elu) {  // (wave-uniform; the LeakyReLU / identity path above costs ELU layers 8 idle operations, the others nothing)
 #pragma unroll
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             o[e] = Y[4 * i + j][e] + b4[e];
-                            o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                            o[e] = fmaxf(o[e], o[e] * slope_eff);  // LeakyReLU / identity (slope_eff in [0, 1], wino4_supported): the sum above is canonical, so this is mul + v_max
                         }
                         if (elu) {  // (wave-uniform; the LeakyReLU / identity path above costs ELU layers 8 idle operations, the others nothing)
 #pragma unroll
@@ -688,7 +688,8 @@ bool wino4_supported(const ConvArgs &a) {
     // second source: a 1x1 stride-1 projection of a tensor of the output's size (weights in idh_pack_conv_weight's layout), no residual beside it
     const bool src2_ok = !s1.in || (s1.ks == 1 && s1.stride == 1 && !s1.up_in[0] && !s1.norm && s1.H == a.Ho && s1.W == a.Wo && !a.res &&
                                     (long long)s1.H * s1.W * s1.cs * 4 < (1ll << 31) && (long long)s1.cblocks * a.Cout_pad * 64 < (1ll << 31));
-    return src2_ok && (a.act == IDH_ACT_NONE || a.act == IDH_ACT_LRELU || a.act == IDH_ACT_ELU) && s.cblocks >= 2 && s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && a.S == 1 && (a.Cout % 64) == 0 &&
+    // (LeakyReLU is evaluated as max(x, slope x): slopes in [0, 1] - every activation of the reference's conv stacks, ReLU = 0 included)
+    return src2_ok && (a.act == IDH_ACT_NONE || (a.act == IDH_ACT_LRELU && a.slope >= 0.f && a.slope <= 1.f) || a.act == IDH_ACT_ELU) && s.cblocks >= 2 && s.ks == 3 && s.stride == 1 && s.pad_mode == IDH_PAD_ZEROS && !s.up_in[0] && !s.norm && a.S == 1 && (a.Cout % 64) == 0 &&
            (long long)s.H * s.W * s.cs * 4 < (1ll << 30) && (long long)a.Ho * a.Wo * a.out_cs * 4 < (1ll << 31) &&  // (input: the halo offsets advance by up to 8 rows past an out-of-range marker)
            (!a.res || (long long)a.Ho * a.Wo * a.res_cs * 4 < (1ll << 31)) && (long long)s.cblocks * a.Cout_pad * 36 * 16 * 4 < (1ll << 31);
 }

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino4p_k(const Wino4pArgs wa) 
                     for (int e = 0; e < 4; ++e) {
                         o[e] = Y[i][j][e] + b4[e];
                         if constexpr (RES) o[e] += r[i][j][e];
-                        o[e] = o[e] < 0.f ? o[e] * slope_eff : o[e];
+                        o[e] = fmaxf(o[e], o[e] * slope_eff);  // LeakyReLU / identity (slope_eff in [0, 1], wino4_supported): the sum above is canonical, so this is mul + v_max
                     }
                     if (elu) {
 #pragma unroll

@@ -232,7 +232,7 @@ WINO4_MIN_TILES = 384
 WINO4_MIN_FILL = 0.85
 
 
-def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act: int, out=None, res=None) -> bool:
+def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act: int, out=None, res=None, slope: float = 0.2) -> bool:
     """Mirror of ``idh_conv::wino4_supported`` (csrc/conv_wino4.hip) plus the fill / tile-count rules.  ``out`` / ``res``: the views the op
     writes / adds - their per-image byte sizes (with the channel stride of a wider concat buffer) are 32-bit buffer ranges in the kernel, so a
     layer that exceeds them is planned onto F(2x2) / the direct kernels here instead of failing at run time with IDH_EUNSUPPORTED."""
@@ -243,7 +243,7 @@ def wino4_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int, act
         (v1, c1) = srcs[1]
         if not WINOGRAD4_PROJ or len(srcs) > 2 or c1.kernel_size[0] != 1 or c1.stride[0] != 1 or isinstance(v1, CatView):
             return False
-    if act not in (ACT_NONE, ACT_LRELU, ACT_ELU) or c0.in_channels <= 16:  # (<= 16: the copy pipeline runs a pair of 8-channel stages ahead)
+    if act not in (ACT_NONE, ACT_LRELU, ACT_ELU) or (act == ACT_LRELU and not 0.0 <= slope <= 1.0) or c0.in_channels <= 16:  # (<= 16: the copy pipeline runs a pair of 8-channel stages ahead)
         return False
     if getattr(v0, "H", 0) * getattr(v0, "W", 0) * getattr(v0, "cs", 0) * 4 >= 1 << 30:  # (csrc: the halo's 32-bit offsets run a few rows past an image)
         return False
@@ -473,7 +473,7 @@ class Plan:
         use_wino = (WINOGRAD and self.math == "fp32" and norm is None and
                     wino_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode))
         use_wino4 = (WINOGRAD4 and self.math == "fp32" and norm is None and (x2 is None or res is None) and
-                     wino4_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode, act, out, res))
+                     wino4_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode, act, out, res, slope))
         if use_wino4:
             use_wino = False
         for i, (v, cv) in enumerate(srcs):
