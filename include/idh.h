@@ -135,7 +135,13 @@ const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D);
  * with MLP = Linear -> LeakyReLU(.01) -> Linear -> LeakyReLU(.01) -> Linear (networks.py:218-233).
  * The first Linear's weight W1 (128 x 16(K+1)+10K+4) is passed in three pieces, in the K order
  * the kernel builds its operands in (implicit-depth_amd/cost_volume.py:pack_feature_mlp):
- *   w1_voxel_packed  per-voxel columns [warped K*16 | 4 metadata blocks], MFMA fragment order
+ *   w1_voxel_packed  per-voxel columns [warped K*16 | 4 metadata blocks], MFMA fragment order.  Metadata blocks of the fp32 kernel for
+ *                    K <= 8, C = 16 (fv_mlp_k, ABI >= 103): lane quarter q carries [z, dot, ray angle, ray xyz] of views q and q + 4 at slots
+ *                    0..5 / 6..11 of three 16-column blocks; the plane depth sits in quarter 3's slot 6 when K < 8, else alone in block 3
+ *                    (quarter 0, k-step 0).  The K per-view "valid" columns are NOT in the blob: those inputs are identically 1 (z is
+ *                    clamped to 1e-5 before the z > 0 test, geometry_utils.py:86), so the caller adds their weight columns to `b1`
+ *                    (implicit-depth_amd/cost_volume.py: feature_mlp_column_maps(fold_mask=True), feature_mlp_mask_columns).  The generic
+ *                    (K > 8 / C = 32) and f16x3 kernels keep the seven-slot layout with the mask column (fold_mask=False).
  *   w1_pixel_packed  per-pixel columns [cur feats 16 | cur ray 3 + pad], MFMA fragment order
  *   w1_pose_rowmajor (128, 3K) columns of the pose-distance / R / t measures (folded into a
  *                    per-batch-element bias on the device)
