@@ -128,3 +128,21 @@ def test_launch_grouping_decisions_without_a_gpu():
     bad = lds64(1, 0)
     bad.out = None
     assert count([bad]) == -1
+
+
+def test_hot_kernels_compile_without_scratch():
+    """The stage loops of the F(4x4) conv kernel and the plane loop of the tuned feature-volume kernel must stay spill-free: a scratch reload in front
+    of a batch of loads waits for every load in flight (profiles/r04-r05/experiments.md).  Compiles the two sources for gfx950 with
+    -Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py; no GPU needed) and reads the ScratchSize of each instance."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import kernel_resources as kr
+
+    csrc = os.path.join(root, "implicit-depth_amd", "csrc")
+    rows = {r["Name"]: int(r.get("ScratchSize [bytes/lane]", 0)) for src in ("conv_wino4.hip", "feature_volume.hip") for r in kr.resources(os.path.join(csrc, src))}
+    for name in ("conv3x3_wino4_k<true, false>", "conv3x3_wino4_k<false, true>", "conv3x3_wino4_k<false, false>", "fv_mlp_k<7>", "fv_mlp_k<0>"):
+        assert name in rows, (name, sorted(rows))
+        assert rows[name] == 0, (name, rows[name])
