@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--sequences", type=int, default=1, help="--workload temporal: independent sequences per GPU in one batch, each carrying its own prior")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="--workload temporal, one sequence: F consecutive frames share the volume / conv launches of a step; the occlusion MLP and its "
+                         "carried prior stay frame by frame (HotPath.forward(frame_chain=...)); same outputs as F single-frame steps")
     ap.add_argument("--no-head", action="store_true", help="start at finished matching features (round-1 workload) instead of the layer1 map")
     ap.add_argument("--conv-math", default="fp32", choices=["fp32", "f16x3"],
                     help="arithmetic of the 3x3 stride-1 convs: fp32 MFMA (default) or the fp32-equivalent split-precision kernels")
@@ -544,11 +547,14 @@ class TemporalWorkload(HotPathWorkload):
     def __init__(self, args, device, rank):
         a = copy.copy(args)
         self.S = max(1, int(getattr(args, "sequences", 1)))
-        a.batch = self.S  # S sequences per GPU, one frame of each per step
+        self.F = max(1, int(getattr(args, "frames_in_flight", 1)))  # consecutive frames of ONE sequence per step
+        if self.F > 1 and self.S > 1:
+            raise SystemExit("--frames-in-flight needs --sequences 1")
+        a.batch = self.S * self.F  # S sequences per GPU, one frame of each per step (or F consecutive frames of one sequence)
         super().__init__(a, device, rank)
         import implicit_depth_amd.synthetic as syn
 
-        S = self.S
+        S = self.S * self.F
         self.rd = torch.full((S, 1, self.Hi // 2, self.Wi // 2), 2.0, device=device)
         self.host_rd = self.rd.cpu()
         K0 = syn.intrinsics(self.Wi // 2, self.Hi // 2).float()
@@ -557,8 +563,8 @@ class TemporalWorkload(HotPathWorkload):
         # sequence-specific motion every frame
         self.poses = []
         for t in range(64):
-            T = torch.eye(4).repeat(S, 1, 1)
-            for q in range(S):
+            T = torch.eye(4).repeat(self.S, 1, 1)
+            for q in range(self.S):
                 T[q, 0, 3] = (0.05 + 0.005 * q) * t
                 T[q, 1, 3] = 0.001 * q * t
             self.poses.append((T.to(device), torch.linalg.inv(T).to(device)))  # world_T_cam, cam_T_world
@@ -567,11 +573,21 @@ class TemporalWorkload(HotPathWorkload):
 
     def metric(self):
         return (f"frames/sec (temporal BDModel.forward hot path, {self.Wi}x{self.Hi}, {self.D} planes, {self.K + 1}-frame tuple, "
-                f"prior carried frame to frame, {self.S} sequence(s) per GPU)")
+                f"prior carried frame to frame, {self.S} sequence(s) per GPU" + (f", {self.F} consecutive frames per step" if self.F > 1 else "") + ")")
 
     def step(self, ev=None):
         if ev is not None:
             ev[0].record()
+        if self.F > 1:  # F consecutive frames of the one sequence: everything up to the decoder in one batch, the MLP / prior chain frame by frame
+            ps = [self.poses[(self.t + f) % len(self.poses)] for f in range(self.F)]
+            chain = {"world_T_cam_b44": torch.cat([p[0] for p in ps]), "cam_T_world_b44": torch.cat([p[1] for p in ps]), "K_s0_b44": self.K0, "invK_s0_b44": self.invK0,
+                     "prior_prediction": self.prev[0] if self.prev is not None else None, "prior_cam_T_world": self.prev[1] if self.prev is not None else None}
+            self.out = self._forward(frame_chain=chain)
+            self.prev = (torch.sigmoid(self.out["pred_0"][-1:]), ps[-1][1])
+            self.t += self.F
+            if ev is not None:
+                ev[1].record()
+            return
         wTc, cTw = self.poses[self.t % len(self.poses)]
         prior_inputs = None
         if self.prev is not None:
@@ -793,9 +809,9 @@ def main():
                 out["warp_match"] = WarpMatchDot(a3, device, rank).kernel_roofline()
             torch.cuda.empty_cache()
             if world == 1:  # BASELINE.json configs[4]: the temporal loop, D=96, prior carried over 48 frames
-                def temporal_run(S):
+                def temporal_run(S, F=1):
                     a4 = copy.copy(args)
-                    a4.planes, a4.views, a4.volume, a4.sequences = 96, 7, "mlp", S
+                    a4.planes, a4.views, a4.volume, a4.sequences, a4.frames_in_flight = 96, 7, "mlp", S, F
                     tw = TemporalWorkload(a4, device, rank)
                     with torch.inference_mode():
                         for _ in range(8):
@@ -811,14 +827,20 @@ def main():
                     cfg = tw.config()["workload"]
                     del tw
                     torch.cuda.empty_cache()
-                    return {"value": S * len(evs) / el, "unit": "frames/s", "sequences": S, "frames": S * len(evs), "ms_per_step_median_hip_events": _median(ts)}, cfg
+                    return {"value": S * F * len(evs) / el, "unit": "frames/s", "sequences": S, "frames": S * F * len(evs), "ms_per_step_median_hip_events": _median(ts),
+                            **({"frames_per_step": F, "ms_per_frame": _median(ts) / F} if F > 1 else {})}, cfg
 
                 one, cfg = temporal_run(1)  # the reference's loop: one sequence, one frame at a time
                 out["temporal"] = {"value": one["value"], "unit": "frames/s", "frames": one["frames"],
                                    "ms_per_frame_median_hip_events": one["ms_per_step_median_hip_events"], "config": cfg,
                                    # S independent sequences per GPU in one batch, each carrying its own prior (how the path shards
                                    # "by sequence"): frames/s of all S sequences together
-                                   "sequences_per_gpu": {"1": one, "4": temporal_run(4)[0], "8": temporal_run(8)[0]}}
+                                   "sequences_per_gpu": {"1": one, "4": temporal_run(4)[0], "8": temporal_run(8)[0]},
+                                   # ONE sequence, F consecutive frames per step: head, volume, CVEncoder and decoder do not depend on the previous
+                                   # frame and run once for the F frames; the occlusion MLP with its carried prior stays frame by frame
+                                   # (HotPath.forward(frame_chain=...): same outputs as F single-frame steps, tests/test_temporal_gpu.py).  Throughput of a
+                                   # recorded scan (the reference's inference.py), at a latency of one step per frame
+                                   "frames_in_flight": {"2": temporal_run(1, 2)[0], "4": temporal_run(1, 4)[0]}}
             if args.volume == "mlp" and args.views != 8:
                 # BASELINE.json's literal "8 source views" through the whole path (the headline is the reference-native 8-frame
                 # tuple = 7 source views): same batch, D, head and query planes, K = 8

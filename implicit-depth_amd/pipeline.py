@@ -114,7 +114,8 @@ class HotPath(nn.Module):
                 rendered_depth: Optional[torch.Tensor] = None, prior: Optional[torch.Tensor] = None,
                 return_mask: bool = False, return_features: bool = False,
                 prior_inputs: Optional[Dict[str, torch.Tensor]] = None, infer_depth: bool = False,
-                matching_layer1: Optional[torch.Tensor] = None, return_matching_feats: bool = False) -> Dict[str, torch.Tensor]:
+                matching_layer1: Optional[torch.Tensor] = None, return_matching_feats: bool = False,
+                frame_chain: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """``matching_layer1`` (B, K+1, 64, H, W): output of the matching backbone (conv1..layer1 of the ResNet18,
         third-party, run by the caller) for frame b's current image followed by its K source images — the order
         reference bd_model.py:149-160 builds; contiguous or channels-last per image
@@ -123,7 +124,15 @@ class HotPath(nn.Module):
         ``prior``: an already-warped prior channel (B,P,H/2,W/2), or ``prior_inputs`` = the
         reference's temporal inputs {"prior_prediction", "prior_cam_T_world", "world_T_cam_b44",
         "K_s0_b44", "invK_s0_b44"} (bd_model.py:420-431) to warp it here; with neither, a
-        prior-enabled MLP sees the constant -1 (bd_model.py:433-434)."""
+        prior-enabled MLP sees the constant -1 (bd_model.py:433-434).
+        ``frame_chain``: the B batch entries are CONSECUTIVE FRAMES OF ONE SEQUENCE (the temporal loop of
+        inference/inference.py:139-157 over a recorded scan).  Everything up to the decoder does not depend on the previous
+        frame, so it runs once for all B frames; only the occlusion MLP is evaluated frame by frame, frame b taking
+        sigmoid(pred_0) of frame b-1 - warped by sample_prior with frame b-1's cam_T_world - as its prior, exactly as B
+        separate calls would.  Keys: "world_T_cam_b44", "cam_T_world_b44" (B,4,4: the frames' poses), "K_s0_b44",
+        "invK_s0_b44" (B,4,4), and the chain's start "prior_prediction" (1,1,H/2,W/2) + "prior_cam_T_world" (1,4,4) (or None
+        for the first frame of a sequence).  Returns the usual dictionary with pred_0 of all B frames (the last one's
+        sigmoid and pose are the next call's chain start)."""
         _lib.require_cuda_f32(matching_cur_feats, matching_src_feats, matching_layer1, src_cam_T_cur_cam, src_K, cur_invK, rendered_depth, prior, *cur_feats)
         head = None
         head_ch = 0
@@ -199,7 +208,27 @@ class HotPath(nn.Module):
         p.run(ent["n_head_ops"])
 
         # 3. occlusion MLP over every query plane (BDModel only)
-        if self.binary_mlp is not None and rendered_depth is not None:
+        if self.binary_mlp is not None and rendered_depth is not None and frame_chain is not None:
+            from .mlp import sample_prior
+
+            if infer_depth or prior is not None or prior_inputs is not None:
+                raise _lib.IdhError("frame_chain excludes prior / prior_inputs / infer_depth")
+            f0 = final[0]
+            prev_pred, prev_cTw = frame_chain.get("prior_prediction"), frame_chain.get("prior_cam_T_world")
+            pred = torch.empty(B, rendered_depth.shape[1], f0.H, f0.W, device=dev)
+            priors = []
+            for b in range(B):
+                pb = None
+                if prev_pred is not None:
+                    pb = sample_prior(rendered_depth[b:b + 1], prev_pred, frame_chain["world_T_cam_b44"][b:b + 1], prev_cTw,
+                                      frame_chain["K_s0_b44"][b:b + 1], frame_chain["invK_s0_b44"][b:b + 1])
+                priors.append(pb)
+                occlusion_logits(self.binary_mlp, f0.buf[b:b + 1], f0.c0, f0.C, rendered_depth[b:b + 1], pb, out=pred[b:b + 1])
+                prev_pred, prev_cTw = torch.sigmoid(pred[b:b + 1]), frame_chain["cam_T_world_b44"][b:b + 1]  # sigmoid_custom(x, 1.0), inference.py:154
+            out["pred_0"] = pred
+            if all(t is not None for t in priors):
+                out["prior_mask"] = torch.cat(priors, 0)
+        elif self.binary_mlp is not None and rendered_depth is not None:
             if prior is None and prior_inputs is not None and prior_inputs.get("prior_prediction") is not None:
                 from .mlp import sample_prior
 

@@ -57,3 +57,36 @@ def test_sequences_in_one_batch_are_independent_and_match_the_single_sequence_lo
         for t, o in enumerate(_frames(one, T)):
             r = ref[t][q:q + 1]
             assert float((o - r).abs().max() / r.abs().max()) < 5e-5, (q, t)
+
+
+def test_frames_in_flight_chain_matches_the_frame_by_frame_loop():
+    """HotPath.forward(frame_chain=...): F consecutive frames of ONE sequence share the head / volume / conv launches, the occlusion MLP and its
+    carried prior stay frame by frame.  Must equal the single-frame loop (same bar as the batched-sequences test: the two-frame plan takes other
+    tile shapes, i.e. another summation order) over several steps, including the prior handed from one step to the next."""
+    from bench import TemporalWorkload
+
+    F, T = 2, 4
+    dev = torch.device("cuda:0")
+    a = _args(1)
+    a.frames_in_flight = F
+    big = TemporalWorkload(a, dev, 0)
+    assert big.B == F
+    one = TemporalWorkload(_args(1), dev, 0)
+    one.model.load_state_dict(big.model.state_dict())
+    one.poses = big.poses
+    with torch.inference_mode():
+        for step in range(T):
+            big.step()
+            got = big.out["pred_0"].clone()
+            assert got.shape[0] == F
+            for f in range(F):  # the same frames one at a time: frame index 2 * step + f, inputs = batch entry f
+                one.d = {k: (v[f:f + 1].contiguous() if v.dim() > 0 and v.shape[0] == F else v) for k, v in big.d.items()}
+                one.pyr = [t[f:f + 1].contiguous() for t in big.pyr]
+                one.l1 = big.l1[f:f + 1].contiguous()
+                assert one.t == F * step + f
+                one.step()
+                r = one.out["pred_0"]
+                assert float((got[f:f + 1] - r).abs().max() / r.abs().max()) < 5e-5, (step, f)
+            if step > 0:
+                assert "prior_mask" in big.out and big.out["prior_mask"].shape[0] == F
+    torch.cuda.synchronize()
