@@ -106,8 +106,8 @@ def _check_all_kernels_vs_fp64(inp, H, W, D, tag):
 def test_every_kernel_vs_fp64_oracle_on_random_geometry(seed):
     """the same random geometries, each of the three kernels against the INDEPENDENT fp64 restatement (oracle/cost_volume.py: explicit
     homography, hand-rolled gather) — the window-vs-quad comparison above shares the projection code, so a common-mode error would pass it"""
-    rng = np.random.default_rng(1000 + seed)  # the seeds (and so the cases) of the HIP-vs-HIP test
-    for case in range(12):
+    rng = np.random.default_rng(1000 + seed)  # the seeds (and so the first cases) of the HIP-vs-HIP test
+    for case in range(8):  # (8 of its 12 geometries per seed: the fp64 oracle on the host is what this test costs - 48 geometries in ~100 s)
         B, K = int(rng.integers(1, 4)), int(rng.integers(1, 9))
         H, W, D = int(rng.integers(12, 70)), int(rng.integers(48, 150)), int(rng.integers(1, 70))
         g = torch.Generator().manual_seed(int(rng.integers(0, 1 << 30)))
