@@ -179,11 +179,14 @@ class CostVolumeManager(nn.Module):
         return m.to(ref_module.linear_ramp_1d11.device)
 
 
-def feature_mlp_column_maps(K: int, C: int = 16, fold_mask: bool = False):
+def feature_mlp_column_maps(K: int, C: int = 16, fold_mask: bool = False, layout: str = "packed7"):
     """Column index maps that re-order the reference MLP's first Linear (input layout of
     modules/cost_volume.py:681-695) into the K order csrc/feature_volume.hip builds its MFMA
     operands in.  -1 = structurally zero column.  Returns (voxel_cols, pixel_cols, pose_cols).
 
+    ``layout="gen8"`` (fv_mlp_gen_k: K > 8 or C = 32): lane quarter q carries EIGHT slots per view group j (views q + 4j) - [valid, z, dot, ray
+    angle | ray xyz, plane depth (group 0, quarter 0 only)] = two 16-column blocks per group, 2 ceil(K/4) blocks (2 x 2 for K <= 8) - so that a
+    group's metadata is consumed inside its own loop iteration of the kernel.
     ``fold_mask`` (fv_mlp_k: fp32, K <= 8, C = 16): the per-view "valid" inputs are identically 1 (the reference clamps z to 1e-5 before it
     tests z > 0, geometry_utils.py:86 / cost_volume.py:216), so their weight columns belong to the bias (``feature_mlp_mask_columns``) and a
     lane quarter carries SIX values per view - [z, dot, ray angle, ray xyz] at 6j..6j+5 - in three 16-column blocks; the plane depth sits in
@@ -221,6 +224,24 @@ def feature_mlp_column_maps(K: int, C: int = 16, fold_mask: bool = False):
                 pixel.append(base_r + kk if (q == 0 and kk < 3) else -1)
         return voxel, pixel, list(range(base_p, base_p + 3 * K))
     J = 2 if K <= 8 else -(-K // 4)
+    if layout == "gen8":
+        for cblk in range(2 * J):
+            for q in range(4):
+                for kk in range(4):
+                    v, slot = q + 4 * (cblk >> 1), 4 * (cblk & 1) + kk
+                    col = -1
+                    if slot < 7 and v < K:
+                        col = [col_mask(v), col_z(v), col_dot(v), col_ang(v), col_ray(v, 0), col_ray(v, 1), col_ray(v, 2)][slot]
+                    elif slot == 7 and cblk == 1 and q == 0:
+                        col = col_plane
+                    voxel.append(col)
+        pixel = [C * K + i for i in range(C)]
+        for q in range(4):
+            for kk in range(4):
+                pixel.append(base_r + kk if (q == 0 and kk < 3) else -1)
+        return voxel, pixel, list(range(base_p, base_p + 3 * K))
+    if layout != "packed7":
+        raise ValueError(layout)
     for cblk in range(-(-(7 * J + 1) // 4)):
         for q in range(4):
             for kk in range(4):
@@ -288,7 +309,8 @@ class FeatureVolumeManager(CostVolumeManager):
         if math == "f16x3" and (C != 16 or K > 8):
             raise _lib.IdhError("the split-precision feature volume covers matching_dim_size 16 and up to 8 source views")
         fold = math == "fp32" and C == 16 and K <= 8  # fv_mlp_k's layout (csrc/feature_volume.hip); the f16x3 / generic kernels keep the mask columns
-        vox, pix, pose = feature_mlp_column_maps(K, C, fold_mask=fold)
+        generic = math == "fp32" and (K > 8 or C != 16)  # fv_mlp_gen_k
+        vox, pix, pose = feature_mlp_column_maps(K, C, fold_mask=fold, layout="gen8" if generic else "packed7")
         dev = w1.device
         w1e = torch.cat([w1, torch.zeros(128, 1, device=dev)], 1)
         pick = lambda cols: w1e[:, torch.tensor([c if c >= 0 else w1.shape[1] for c in cols], device=dev)].contiguous()

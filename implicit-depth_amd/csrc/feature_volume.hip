@@ -123,7 +123,7 @@ struct FvArgs {
     int B, K, H, W, D;
     int tiles_per_img;     // ceil(N/16)
     int DP, G;             // planes per task, plane groups
-    int J, MB;             // generic kernel: source views per lane quarter (view q + 4j), metadata blocks = ceil((7J + 1) / 4)
+    int J, MB;             // generic kernel: source views per lane quarter (view q + 4j), metadata blocks = 2 J
     float dmin, dmax;
     // idh_volume_opts, resolved: batch strides (floats) and caller-supplied planes (null = log-spaced)
     long long cur_bs, src_bs;
@@ -501,13 +501,17 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
 // ------------------------------------------------------------------------------------------
 // Generic variant: any source-view count up to IDH_MAX_SOURCE_VIEWS (FeatureVolumeManager takes num_source_views from
 // model_num_views - 1, reference cost_volume.py:382-435 / depth_model.py:206-212) and matching_feature_dims = 16 * CB
-// (options.py:138).  Same arithmetic and operand order as fv_mlp_k; what changes is where things live:
-//   * W1's per-voxel blocks — K*CB feature blocks + MB metadata blocks, up to 40 x 8 KiB — no longer fit next to W2 in
+// (options.py:138).  Same arithmetic as fv_mlp_k; what changes is where things live:
+//   * W1's per-voxel blocks - K*CB feature blocks + 2J metadata blocks, up to 40 x 8 KiB - do not fit next to W2 in
 //     LDS and are read through L1 / L2 as MFMA fragments (every wave of the chip reads the same 8 KiB per block);
-//   * lane quarter q carries the metadata of views q, q+4, .. q+4(J-1) (J = ceil(K/4), or 2 for K <= 8 as in fv_mlp_k):
-//     7J values + the plane depth = MB = ceil((7J+1)/4) metadata blocks; the view loop is unrolled over (j, r) so that
-//     every metadata register index is a compile-time constant;
-//   * no software pipelining of the taps: this is the coverage path, fv_mlp_k<7> stays the measured one.
+//   * lane quarter q carries the metadata of views q, q+4, .. q+4(J-1), J = ceil(K/4) (2 for K <= 8), EIGHT slots per view
+//     group j = two 16-column blocks: [valid, z, dot, ray angle | ray xyz, plane depth (group 0, quarter 0) / 0]
+//     (implicit-depth_amd/cost_volume.py: feature_mlp_column_maps(layout="gen8")).  With eight slots a view group's
+//     metadata MFMAs are issued inside ITS iteration of a run-time loop over j, so no metadata array lives across
+//     iterations (round 4's seven-slot packing needed one indexed by the run-time group: 428-508 B of scratch per lane);
+//   * as in fv_mlp_k (round 5) the projection of a view is computed once per voxel, by its owner quarter, and handed to
+//     the other three through ds_bpermute_b32; the four views of a group are unrolled, the next view's tap loads are
+//     issued before the current view's blend.
 template <int CB>
 __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -521,15 +525,15 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
     const float *s_b2 = a.vecs, *s_w3 = a.vecs + kHid;
     const float b3 = a.vecs[2 * kHid];
     constexpr int kCc = kC * CB;
-    constexpr int kJmax = IDH_MAX_SOURCE_VIEWS / 4;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ln = lane & 15, q = lane >> 4;
     const int N = a.H * a.W;
-    const int K = a.K, J = a.J, MB = a.MB;
+    const int K = a.K, J = a.J;
     const float Wf = (float)a.W, Hf = (float)a.H;
     const long long ntasks = (long long)a.B * a.tiles_per_img * a.G;
+    const int bp0 = 4 * ln;  // ds_bpermute address of this voxel's lane in quarter 0 (+ 64 per quarter)
 
     for (long long task = (long long)idh_xcd_remap(blockIdx.x, gridDim.x) * 8 + wave; task < ntasks; task += (long long)gridDim.x * 8) {
         const int g = __builtin_amdgcn_readfirstlane((int)(task % a.G));
@@ -573,6 +577,8 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
                 for (int kk = 0; kk < 4; ++kk) pre[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[kk], rayB[kk], pre[i], 0, 0, 0);
             }
         }
+        // taps through a buffer descriptor of this frame's K source maps (32-bit offsets; view k: scalar offset k * N * kCc * 4)
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src + (size_t)b * a.src_bs), 0, K * N * kCc * 4, 0x00020000);
 
         f32x4 ob = (f32x4){0.f, 0.f, 0.f, 0.f};
         const bool vec_ok = ((d0 & 3) == 0) && ((a.vol_cs & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.vol) & 15) == 0);
@@ -583,16 +589,14 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
             f32x4 acc1[kNS];
 #pragma unroll
             for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
-            float m[8 * kJmax];  // this quarter's metadata: [7j .. 7j+6] = mask, z, dot, ray angle, ray xyz of view q + 4j; [7J] = plane depth
-#pragma unroll
-            for (int i = 0; i < 8 * kJmax; ++i) m[i] = 0.f;
-            bool any_inb = false, any_front = false;
-            // ONE view per iteration of a run-time loop (round 4: the 16-view unrolled form kept every view's temporaries and the 32
-            // metadata slots live at once: 1.4-2.5 KB of scratch per lane).  The metadata registers keep compile-time indices: view k
-            // belongs to lane quarter k & 3, slot group k >> 2, selected by predicate.
+            bool any_inb = false, any_front = false;  // (of this quarter's own views; OR-ed over the quarters at the last plane)
 #pragma unroll 1
-            for (int k = 0; k < K; ++k) {
-                const float *hm = pb + kWsHom + 12 * k;
+            for (int j = 0; j < J; ++j) {
+                // ---- this quarter's view of group j: projection, bilinear weights, packed tap address (pixel index | x step << 30 | y step << 31),
+                // viewing ray and ray angle (cost_volume.py:630-659).  An absent view (q + 4j >= K) computes on a stand-in nobody reads.
+                const int v = q + 4 * j, vs = min(v, K - 1);
+                const bool mine = v < K;
+                const float *hm = pb + kWsHom + 12 * vs;
                 const float qx = fmaf(hm[0], pxf, fmaf(hm[1], pyf, hm[2]));
                 const float qy = fmaf(hm[3], pxf, fmaf(hm[4], pyf, hm[5]));
                 const float qz = fmaf(hm[6], pxf, fmaf(hm[7], pyf, hm[8]));
@@ -603,8 +607,8 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
                 float rc = __builtin_amdgcn_rcpf(z);
                 rc = rc * fmaf(-z, rc, 2.0f);
                 const float su = cx * rc, sv = cy * rc;
-                any_inb |= (su > 2.f) & (su < Wf - 2.f) & (sv > 2.f) & (sv < Hf - 2.f);
-                any_front |= z > 0.f;
+                any_inb |= mine & (su > 2.f) & (su < Wf - 2.f) & (sv > 2.f) & (sv < Hf - 2.f);
+                any_front |= mine & (z > 0.f);
                 const float sx = fminf(fmaxf(su - 0.5f, -1.0f), Wf);
                 const float sy = fminf(fmaxf(sv - 0.5f, -1.0f), Hf);
                 const float x0f = floorf(sx), y0f = floorf(sy);
@@ -616,70 +620,88 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
                 const float wy1 = (y0 + 1 < a.H) ? fy : 0.f;
                 const int xa0 = min(max(x0, 0), a.W - 1), xa1 = min(x0 + 1, a.W - 1);
                 const int ya0 = min(max(y0, 0), a.H - 1), ya1 = min(y0 + 1, a.H - 1);
-                const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
-                const float *sb = a.src + (size_t)b * a.src_bs + (size_t)k * N * kCc + 4 * q;
-                const float maskv = z > 0.f ? 1.f : 0.f;
-                float part = 0.f;
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const f32x4 t00 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa0) * kCc + 16 * cb);
-                    const f32x4 t01 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya0 * a.W + xa1) * kCc + 16 * cb);
-                    const f32x4 t10 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa0) * kCc + 16 * cb);
-                    const f32x4 t11 = *reinterpret_cast<const f32x4 *>(sb + (size_t)(ya1 * a.W + xa1) * kCc + 16 * cb);
-                    f32x4 wv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) wv[e] = fmaf(w11, t11[e], fmaf(w10, t10[e], fmaf(w01, t01[e], w00 * t00[e])));
-                    // per-quarter partial of <warped, cur> in channel order: block cb's 4 channels of this quarter
-                    float pc = wv[0] * cur4[cb][0];
-                    pc = fmaf(wv[1], cur4[cb][1], pc); pc = fmaf(wv[2], cur4[cb][2], pc); pc = fmaf(wv[3], cur4[cb][3], pc);
-                    part += pc;
-#pragma unroll
-                    for (int i = 0; i < kNS; ++i) {
-                        const f32x4 A = gW1[((size_t)(k * CB + cb) * kNS + i) * 64 + lane];
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
-                    }
-                }
-                part += __shfl_xor(part, 16, 64);
-                part += __shfl_xor(part, 32, 64);
-                const float dotv = part * maskv;
-                const bool mine = (k & 3) == q;
-                const int jk = k >> 2;
-#pragma unroll
-                for (int j = 0; j < kJmax; ++j) {
-                    const bool sel = mine && jk == j;
-                    m[7 * j + 0] = sel ? maskv : m[7 * j + 0];
-                    m[7 * j + 1] = sel ? z : m[7 * j + 1];
-                    m[7 * j + 2] = sel ? dotv : m[7 * j + 2];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kJmax; ++j) {
-                // ray / ray angle of this quarter's j-th view (cost_volume.py:630-659)
-                const int v = q + 4 * j;
-                if (j < J && v < K) {
-                    const float *t = pb + kWsT + 4 * v;
+                const int own_pk = (ya0 * a.W + xa0) | ((xa1 - xa0) << 30) | ((ya1 - ya0) << 31);
+                const float own_w00 = wx0 * wy0, own_w01 = wx1 * wy0, own_w10 = wx0 * wy1, own_w11 = wx1 * wy1;
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f, ang = 0.f;
+                {
+                    const float *t = pb + kWsT + 4 * vs;
                     const float ax = Xx - t[0], ay = Xy - t[1], az = Xz - t[2];
                     const float in = 1.0f / fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-12f);
-                    const float e0 = ax * in, e1 = ay * in, e2 = az * in;
+                    e0 = ax * in; e1 = ay * in; e2 = az * in;
                     const float n1 = fmaxf(sqrtf(crx * crx + cry * cry + crz * crz), 1e-5f);
                     const float n2 = fmaxf(sqrtf(e0 * e0 + e1 * e1 + e2 * e2), 1e-5f);
-                    m[7 * j + 3] = (crx * e0 + cry * e1 + crz * e2) / (n1 * n2);
-                    m[7 * j + 4] = e0; m[7 * j + 5] = e1; m[7 * j + 6] = e2;
+                    ang = (crx * e0 + cry * e1 + crz * e2) / (n1 * n2);
                 }
-            }
+                const float maskv = z > 0.f ? 1.f : 0.f;
+                float own_dot = 0.f;
+
+                struct Tap { f32x4 t00[CB], t01[CB], t10[CB], t11[CB]; };
+                struct Wts { float w00, w01, w10, w11; };
+                auto issue = [&](int kq) {  // view 4 j + kq: address from its owner quarter kq
+                    const int pk = __builtin_amdgcn_ds_bpermute(bp0 + 64 * kq, own_pk);
+                    const int o00 = (pk & 0x3fffffff) * (kCc * 4) + 16 * q;
+                    const int o01 = o00 + ((pk >> 30) & 1) * (kCc * 4);
+                    const int ystep = (int)((unsigned)pk >> 31) * (a.W * kCc * 4);
+                    const int so = __builtin_amdgcn_readfirstlane((4 * j + kq) * N * (kCc * 4));
+                    Tap t;
 #pragma unroll
-            for (int jj = 1; jj <= kJmax; ++jj)
-                if (J == jj) m[7 * jj] = depth;
+                    for (int cb = 0; cb < CB; ++cb) {
+                        t.t00[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o00 + 64 * cb, so, 0));
+                        t.t01[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o01 + 64 * cb, so, 0));
+                        t.t10[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o00 + ystep + 64 * cb, so, 0));
+                        t.t11[cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsS, o01 + ystep + 64 * cb, so, 0));
+                    }
+                    return t;
+                };
+                auto weights = [&](int kq) {
+                    auto bperm = [&](float x) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp0 + 64 * kq, __builtin_bit_cast(int, x))); };
+                    Wts w;
+                    w.w00 = bperm(own_w00); w.w01 = bperm(own_w01); w.w10 = bperm(own_w10); w.w11 = bperm(own_w11);
+                    return w;
+                };
+                const int nv = min(4, K - 4 * j);  // views of this group (wave-uniform)
+                Tap cur = issue(0);
+                Wts wc = weights(0);
 #pragma unroll
-            for (int c = 0; c < 2 * kJmax; ++c) {
-                if (c < MB) {
+                for (int kq = 0; kq < 4; ++kq) {
+                    if (kq >= nv) break;
+                    Tap nxt = cur;
+                    Wts wn = wc;
+                    if (kq + 1 < 4 && kq + 1 < nv) { nxt = issue(kq + 1); wn = weights(kq + 1); }
+                    float part = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        f32x4 wv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            wv[e] = fmaf(wc.w11, cur.t11[cb][e], fmaf(wc.w10, cur.t10[cb][e], fmaf(wc.w01, cur.t01[cb][e], wc.w00 * cur.t00[cb][e])));
+                        // per-quarter partial of <warped, cur> in channel order: block cb's 4 channels of this quarter
+                        float pc = wv[0] * cur4[cb][0];
+                        pc = fmaf(wv[1], cur4[cb][1], pc); pc = fmaf(wv[2], cur4[cb][2], pc); pc = fmaf(wv[3], cur4[cb][3], pc);
+                        part += pc;
+#pragma unroll
+                        for (int i = 0; i < kNS; ++i) {
+                            const f32x4 A = gW1[((size_t)((4 * j + kq) * CB + cb) * kNS + i) * 64 + lane];
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wv[kk], acc1[i], 0, 0, 0);
+                        }
+                    }
+                    part += __shfl_xor(part, 16, 64);
+                    part += __shfl_xor(part, 32, 64);
+                    own_dot = (kq == q) ? part : own_dot;
+                    cur = nxt;
+                    wc = wn;
+                }
+                // ---- metadata of view group j: two blocks of four slots per quarter (zero weights where a view is absent, but keep the operands finite)
+                const f32x4 mb0 = mine ? (f32x4){maskv, z, own_dot * maskv, ang} : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 mb1 = mine ? (f32x4){e0, e1, e2, (j == 0 && q == 0) ? depth : 0.f} : (f32x4){0.f, 0.f, 0.f, (j == 0 && q == 0) ? depth : 0.f};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
 #pragma unroll
                     for (int i = 0; i < kNS; ++i) {
-                        const f32x4 A = gW1[((size_t)(K * CB + c) * kNS + i) * 64 + lane];
+                        const f32x4 A = gW1[((size_t)(K * CB + 2 * j + c) * kNS + i) * 64 + lane];
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], m[4 * c + kk], acc1[i], 0, 0, 0);
-                        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                        for (int kk = 0; kk < 4; ++kk) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], c == 0 ? mb0[kk] : mb1[kk], acc1[i], 0, 0, 0);
                     }
                 }
             }
@@ -721,8 +743,13 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
             } else if (q == 0 && live) {
                 a.vol[((size_t)b * a.D + d) * N + p] = val;
             }
-            // overall mask: the reference overwrites it every plane, the LAST plane survives
-            if (q == 0 && live && a.mask != nullptr && d == a.D - 1) a.mask[(size_t)b * N + p] = (any_front && any_inb) ? 1 : 0;
+            // overall mask: the reference overwrites it every plane, the LAST plane survives; the flags of the four quarters' own views are OR-ed
+            if (a.mask != nullptr && d == a.D - 1) {
+                int fl = (any_inb ? 1 : 0) | (any_front ? 2 : 0);
+                fl |= __shfl_xor(fl, 16, 64);
+                fl |= __shfl_xor(fl, 32, 64);
+                if (q == 0 && live) a.mask[(size_t)b * N + p] = (fl == 3) ? 1 : 0;
+            }
         }
     }
 }
@@ -1122,6 +1149,7 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     if (own_planes) { dmin = dmax = 1.f; planes_d = nullptr; }
     if (B < 0 || K <= 0 || H <= 0 || W <= 0 || D <= 0 || !(dmin > 0.f) || !(dmax > 0.f)) return IDH_EINVAL;
     const bool generic = C != kC || K > kMaxK;  // fv_mlp_gen_k: matching_feature_dims 32, up to IDH_MAX_SOURCE_VIEWS views
+    if ((long long)K * H * W * C * 4 >= (1ll << 31)) return IDH_EUNSUPPORTED;  // (taps through a buffer descriptor per frame: 32-bit byte offsets)
     if ((C != kC && C != 2 * kC) || K > IDH_MAX_SOURCE_VIEWS || D > 4096 || (generic && f16x3)) return IDH_EUNSUPPORTED;
     if (B == 0) return IDH_OK;
     if (!cur_nhwc || !src_nhwc || !src_K_44 || !src_E_44 || !src_poses_44 || !cur_invK_44 || !w1_voxel_packed ||
@@ -1143,7 +1171,7 @@ static int feature_volume_impl(const float *cur_nhwc, const float *src_nhwc, con
     const int N = H * W;
     a.cur_bs = (long long)N * C; a.src_bs = (long long)K * N * C;
     a.J = K <= kMaxK ? 2 : (K + 3) / 4;  // views per lane quarter (the packed W1 columns follow the same rule: feature_mlp_column_maps)
-    a.MB = (7 * a.J + 1 + 3) / 4;
+    a.MB = 2 * a.J;  // fv_mlp_gen_k: eight metadata slots per view group (two 16-column blocks)
     if (opts) {
         if (opts->cur_batch_stride) a.cur_bs = opts->cur_batch_stride;
         if (opts->src_batch_stride) a.src_bs = opts->src_batch_stride;

@@ -141,7 +141,9 @@ const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D);
  *                    (quarter 0, k-step 0).  The K per-view "valid" columns are NOT in the blob: those inputs are identically 1 (z is
  *                    clamped to 1e-5 before the z > 0 test, geometry_utils.py:86), so the caller adds their weight columns to `b1`
  *                    (implicit-depth_amd/cost_volume.py: feature_mlp_column_maps(fold_mask=True), feature_mlp_mask_columns).  The generic
- *                    (K > 8 / C = 32) and f16x3 kernels keep the seven-slot layout with the mask column (fold_mask=False).
+ *                    kernel (K > 8 / C = 32, fv_mlp_gen_k) takes EIGHT slots per view group j (views q + 4j): [valid, z, dot, ray angle |
+ *                    ray xyz, plane depth (group 0, quarter 0) / 0] = 2 ceil(K/4) blocks (layout="gen8"); the f16x3 kernel keeps the
+ *                    seven-slot packing with the mask column (the default of feature_mlp_column_maps).
  *   w1_pixel_packed  per-pixel columns [cur feats 16 | cur ray 3 + pad], MFMA fragment order
  *   w1_pose_rowmajor (128, 3K) columns of the pose-distance / R / t measures (folded into a
  *                    per-batch-element bias on the device)
