@@ -53,6 +53,15 @@ def test_feature_mlp_column_maps_are_a_permutation_of_the_reference_layout():
         n_in = 16 * (K + 1) + 10 * K + 4
         assert sorted(used) == list(range(n_in)), "every reference MLP input column appears exactly once"
         assert len(vox) == 16 * (K + 4) and len(pix) == 32 and len(pose) == 3 * K
+    # fv_mlp_gen_k's layout: eight metadata slots per view group, two blocks per group, every column exactly once
+    for K, C in ((9, 16), (12, 16), (16, 16), (7, 32), (3, 32)):
+        vox, pix, pose = cv.feature_mlp_column_maps(K, C, layout="gen8")
+        used = [c for c in vox + pix + pose if c >= 0]
+        assert sorted(used) == list(range(C * (K + 1) + 10 * K + 4)), (K, C)
+        J = 2 if K <= 8 else -(-K // 4)
+        assert len(vox) == C * K + 16 * 2 * J and len(pix) == C + 16
+        plane = C * (K + 1) + 2 * K
+        assert vox[C * K:].index(plane) == 16 + 3, "plane depth: group 0, second block, quarter 0, slot 3"
     # fv_mlp_k's layout: the per-view "valid" columns (identically-1 inputs) go to the bias, everything else appears exactly once
     for K in (1, 2, 7, 8):
         vox, pix, pose = cv.feature_mlp_column_maps(K, fold_mask=True)
