@@ -213,6 +213,14 @@ class HotPath(nn.Module):
 
             if infer_depth or prior is not None or prior_inputs is not None:
                 raise _lib.IdhError("frame_chain excludes prior / prior_inputs / infer_depth")
+            if not getattr(self.binary_mlp, "use_prior", False):
+                raise _lib.IdhError("frame_chain needs an occlusion MLP built with use_prior=True")
+            for k in ("world_T_cam_b44", "cam_T_world_b44", "K_s0_b44", "invK_s0_b44"):
+                if k not in frame_chain or tuple(frame_chain[k].shape) != (B, 4, 4):
+                    raise _lib.IdhError(f"frame_chain[{k!r}] must be ({B}, 4, 4): one pose / intrinsics matrix per frame of the batch")
+            if (frame_chain.get("prior_prediction") is None) != (frame_chain.get("prior_cam_T_world") is None):
+                raise _lib.IdhError("frame_chain: prior_prediction and prior_cam_T_world come together (both None at the first frame of a sequence)")
+            _lib.require_cuda_f32(*[t for t in frame_chain.values() if t is not None])
             f0 = final[0]
             prev_pred, prev_cTw = frame_chain.get("prior_prediction"), frame_chain.get("prior_cam_T_world")
             pred = torch.empty(B, rendered_depth.shape[1], f0.H, f0.W, device=dev)

@@ -152,6 +152,7 @@ const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D);
  *   lowest_bhw       (B,H,W) or NULL; mask_bhw (B,H,W) uint8 "overall mask" of the LAST plane or
  *                    NULL; planes_d (D) or NULL (written together with lowest_bhw)
  *   workspace        >= idh_feature_volume_workspace_bytes(B)
+ * One frame's K source maps are addressed through a buffer descriptor: K*H*W*C*4 bytes must stay below 2 GiB (else IDH_EUNSUPPORTED).
  */
 size_t idh_feature_volume_workspace_bytes(int B);
 int idh_feature_volume_fwd(const float *cur_nhwc, const float *src_nhwc, const float *src_K_44,
