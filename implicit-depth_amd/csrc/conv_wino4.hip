@@ -348,6 +348,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 #ifndef IDH_W4_RING
 #define IDH_W4_RING 3
 #endif
+#ifndef IDH_W4_PRIO  // wave priority by phase (bit 0: input transform, bit 1: epilogue, bit 2: MFMA loop run at priority 1; else 0)
+#define IDH_W4_PRIO 0
+#endif
+#define W4_PRIO(bit) __builtin_amdgcn_s_setprio((IDH_W4_PRIO >> (bit)) & 1)
     constexpr int kRing = IDH_W4_RING;  // (divides 18; measured 1: -7 ... -39 %, 2: 0 ... -12 %, 6: -6 ... -9 %: more rows in flight cost more at the issue of the other loads than they hide)
     f32x4 Af[kRing];
     auto ldA = [&](int slot, int so) {
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
             auto ldB = [&](int j) { Bf[j] = *(lds_cf32x4 *)(lds + kVr + (j / 9) * (64 * 144) + vbase + 16 * (j % 9)); };
 #endif
             constexpr int kAheadB = 2;
+            if (IDH_W4_PRIO) W4_PRIO(2);
 #pragma unroll
             for (int j = 0; j < kAheadB; ++j) ldB(j);
 #pragma unroll
@@ -471,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
             }
             W4T(tr0 + 5);
             // transform(S + 1): halo(S + 1) -> V(S + 1)
+            if (IDH_W4_PRIO) W4_PRIO(0);
             transform_q(pl1, kVw);
             W4T(tr0 + 6);
             __syncthreads();
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
 
         // ---- epilogue: Y = A^T M A; lane = 4 consecutive channels of the 4x4 pixels of tile (ty, tx)
         W4T(70);
+        if (IDH_W4_PRIO) W4_PRIO(1);
 #ifdef IDH_ABL_W4_NOEPI
 #pragma unroll
         for (int p = 0; p < 36; ++p) asm volatile("" ::"v"(acc[p]));

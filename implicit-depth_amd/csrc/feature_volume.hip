@@ -337,6 +337,11 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
             float m8 = q + 4 < K ? P.own[1].z : 0.f;
             // Software-pipelined view loop: the tap address of view k+1 is fetched from its owner quarter and its 4 tap loads are issued before
             // the bilinear blend / 32 MFMAs of view k, so L2 latency hides under matrix work; the weights follow with the address.
+            // Wave priority: layer 1 (taps, blend, metadata, activation: the vector-heavy half of a plane) runs at priority 2, layers 2 / 3 at 0.
+            // The SIMD's two waves drift into opposite halves and the arbiter then gives the vector-heavy wave its issue slots while the other
+            // wave's back-to-back MFMAs fill the matrix pipe: 15.2 -> 14.6 ms at 32 frames; raising layer 3 as well, or only the view loop, or the
+            // next plane's prologue: 14.8 - 15.1 (profiles/r05/experiments.md).
+            __builtin_amdgcn_s_setprio(2);
             constexpr int KU = KT > 0 ? KT : kMaxK;
 #pragma unroll
             for (int k = 0; k < KU; ++k) {
@@ -419,6 +424,7 @@ __global__ __launch_bounds__(512) void fv_mlp_k(const FvArgs a) {
                 for (int r = 0; r < 4; ++r) acc1[i][r] = lrelu01(acc1[i][r]);
                 acc2[i] = *reinterpret_cast<const f32x4 *>(s_b2 + 16 * i + 4 * q);
             }
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int c = 0; c < kNS; ++c) {
 #pragma unroll
@@ -586,6 +592,7 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
         for (int d = d0; d < d1; ++d) {
             const float depth = fv_plane(a, b, p, d);
             const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
+            __builtin_amdgcn_s_setprio(2);  // (layer 1 high, layers 2 / 3 low: see fv_mlp_k)
             f32x4 acc1[kNS];
 #pragma unroll
             for (int i = 0; i < kNS; ++i) acc1[i] = pre[i];
@@ -712,6 +719,7 @@ __global__ __launch_bounds__(512) void fv_mlp_gen_k(const FvArgs a) {
                 for (int r = 0; r < 4; ++r) acc1[i][r] = lrelu01(acc1[i][r]);
                 acc2[i] = *reinterpret_cast<const f32x4 *>(s_b2 + 16 * i + 4 * q);
             }
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int c = 0; c < kNS; ++c) {
 #pragma unroll
@@ -841,6 +849,7 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
         for (int d = d0; d < d1; ++d) {
             const float depth = fv_plane(a, b, p, d);
             const float Xx = depth * rx, Xy = depth * ry, Xz = depth * rz;
+            __builtin_amdgcn_s_setprio(2);  // (gather and layer 1 high, layers 2 / 3 low: see fv_mlp_k; dropping before layer 1 instead: half the gain)
             f32x4 X[12];  // [0..3] metadata blocks, [4 + k] warped features of view k
 #pragma unroll
             for (int j = 0; j < 12; ++j) X[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -979,6 +988,7 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
                     for (int r = 0; r < 4; ++r) h[i][r] = lrelu01(fmaf(acc[i][r], sx * sw[r], pre[i][r]));
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             // ---- layer 2 (same scheme on the hidden vector) -> LeakyReLU -> layer 3 ----------------
             float s = 0.f;
             {

@@ -249,7 +249,11 @@ __global__ __launch_bounds__(bin_threads(F16)) void binary_mlp_k(const BinArgs a
                     for (int r = 0; r < 4; ++r) acc[i][0][r] = fmaf(a2[i][r], sx * sw[r], acc[i][0][r]);
                 }
             } else {
+                // wave priority: the MFMA block at 0, the activations either side of it at 2 (3.66 -> 3.60 ms at 32 frames x 8 planes; the
+                // other way round 3.62; profiles/r05/experiments.md - the larger effect of the same idea is in fv_mlp_k)
+                __builtin_amdgcn_s_setprio(0);
                 dense128<TM>(h1, sW2, lane, acc);
+                __builtin_amdgcn_s_setprio(2);
             }
             // ---- layer 3: logit = w3 . ELU(h2) + b3; reduce over the 4 lane quarters ----------
 #pragma unroll

@@ -11,6 +11,8 @@ D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 H, W = 96, 128
 dev = torch.device("cuda:0")
+if os.environ.get("MLP_MATH"):
+    cv.DEFAULT_MLP_MATH = os.environ["MLP_MATH"]  # (fp32 | f16x3)
 d = {k: v.to(dev) for k, v in syn.cost_volume_inputs(B, K, 16, H, W, seed=0).items()}
 d["min_depth"], d["max_depth"] = 0.25, 5.0
 m = cv.FeatureVolumeManager(H, W, D, num_source_views=K).to(dev)
