@@ -42,16 +42,20 @@ constexpr int kWsHom = 0, kWsT = 192, kWsInvK = 256, kWsBias = 272;
 static_assert(kWsT == 12 * IDH_MAX_SOURCE_VIEWS && kWsInvK == kWsT + 4 * IDH_MAX_SOURCE_VIEWS && kWsBias + kHid <= 400, "workspace layout");
 constexpr int kWsStrideReal = 400;
 
-// LeakyReLU(0.01), three vector instructions (multiply, compare, select).  max(x, 0.01 x) would be two - but fmaxf() in IEEE mode canonicalises its
-// operand with an extra v_max (three again), and a bare v_max_f32 through inline asm is NOT safe here: hipcc does not track the MFMA -> VALU
-// wait states for inline asm operands, and fv_mlp_k<8> with its layer-2 chunks scheduled freely produced wrong values with it (measured,
-// profiles/r05/experiments.md; the ~0.1 ms it saved is not worth a hazard the compiler cannot see).
+// LeakyReLU(0.01) as max(x, 0.01 x) in TWO vector instructions: v_mul + gfx950's v_maximum3_f32 (IEEE-754-2019 maximum: NaN propagates, -0 < +0), which
+// the compiler emits for __builtin_elementwise_maximum without the canonicalising v_max that fmaxf() puts in front of an MFMA result (three
+// instructions, like multiply / compare / select).  Same values as the select form for every input, NaN and -0 included.  (A bare v_max_f32
+// through inline asm is NOT an option: hipcc does not track the MFMA -> VALU wait states of inline-asm operands, and fv_mlp_k<8> produced
+// wrong values with it; profiles/r05/experiments.md.)
 __device__ __forceinline__ float lrelu01(float x) {
 #ifdef IDH_ABL_FV2_NOACT
     return x;
 #endif
-    return x >= 0.f ? x : x * 0.01f;
+    return __builtin_elementwise_maximum(x, x * 0.01f);
 }
+// (the split-precision kernel keeps the select form: there the two-instruction forms - this one or fmaxf on the canonical fma result - measure
+// 8.60 ms against 8.38 at 32 frames, with 16 B more scratch; profiles/r05/experiments.md)
+__device__ __forceinline__ float lrelu01_sel(float x) { return x >= 0.f ? x : x * 0.01f; }
 
 __device__ __forceinline__ float fv_depth_plane(int i, int D, float dmin, float dmax) {
     float ramp = 0.f;
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
                 for (int i = 0; i < kNS; ++i) {
                     const f32x4 sw = *reinterpret_cast<const f32x4 *>(sw1g + 16 * i + 4 * q);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h[i][r] = lrelu01(fmaf(acc[i][r], sx * sw[r], pre[i][r]));
+                    for (int r = 0; r < 4; ++r) h[i][r] = lrelu01_sel(fmaf(acc[i][r], sx * sw[r], pre[i][r]));
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -1024,7 +1028,7 @@ __global__ __launch_bounds__(512) void fv_mlp_f16_k(const FvArgs a, const float 
                     const f32x4 b2 = *reinterpret_cast<const f32x4 *>(s_b2 + 16 * i + 4 * q);
                     const f32x4 w3 = *reinterpret_cast<const f32x4 *>(s_w3 + 16 * i + 4 * q);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s = fmaf(w3[r], lrelu01(fmaf(acc[i][r], sx * sw[r], b2[r])), s);
+                    for (int r = 0; r < 4; ++r) s = fmaf(w3[r], lrelu01_sel(fmaf(acc[i][r], sx * sw[r], b2[r])), s);
                 }
             }
             s += __shfl_xor(s, 16, 64);
