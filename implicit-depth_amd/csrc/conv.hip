@@ -797,36 +797,57 @@ __global__ __launch_bounds__(256) void pack_weight_k(const float *__restrict__ w
 
 // bilinear x2 (align_corners=False): out[2i] = .25 in[i-1] + .75 in[i], out[2i+1] = .75 in[i] + .25 in[i+1],
 // indices clamped at the border; evaluated as h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11).
+// One thread = one low-resolution pixel x 4 channels -> the 2x2 output pixels it centres: 9 loads for 4 stores (4 per store
+// with one thread per output pixel), the three horizontally blended rows shared by the two output rows (the same expression tree
+// per output, so the same bits), and one 32-bit index decomposition per quad - with a thread per output the kernel was
+// bound by its integer divisions, not by HBM (round 5: 3.7 -> TB/s of the 4.6 GB a 32-frame step moves through it).
 __device__ __forceinline__ void upsample2_body(const float *__restrict__ in, float *__restrict__ out, int N, int H, int W, int C,
                                                int in_cs, int out_cs, unsigned blk, unsigned nblk) {
-    const int cq = C >> 2;
-    const int Ho = 2 * H, Wo = 2 * W;
-    const long long total = (long long)N * Ho * Wo * cq;
-    for (long long t = blk * 256ll + threadIdx.x; t < total; t += nblk * 256ll) {
-        const int q = (int)(t % cq);
-        long long p = t / cq;
-        const int x = (int)(p % Wo);
-        p /= Wo;
-        const int y = (int)(p % Ho);
-        const int n = (int)(p / Ho);
-        const int iy = y >> 1, ix = x >> 1;
-        int y0, y1, x0, x1;
-        float hy0, hy1, wx0, wx1;
-        if (y & 1) { y0 = iy; y1 = min(iy + 1, H - 1); hy0 = 0.75f; hy1 = 0.25f; }
-        else { y0 = max(iy - 1, 0); y1 = iy; hy0 = 0.25f; hy1 = 0.75f; }
-        if (x & 1) { x0 = ix; x1 = min(ix + 1, W - 1); wx0 = 0.75f; wx1 = 0.25f; }
-        else { x0 = max(ix - 1, 0); x1 = ix; wx0 = 0.25f; wx1 = 0.75f; }
+    const unsigned cq = (unsigned)C >> 2;
+    const int Wo = 2 * W;
+    const unsigned total = (unsigned)N * H * W * cq;  // (host-checked: < 2^31)
+    constexpr float lo = 0.25f, hi = 0.75f;
+    for (unsigned t = blk * 256u + threadIdx.x; t < total; t += nblk * 256u) {
+        const unsigned q = t % cq;
+        unsigned p = t / cq;
+        const int ix = (int)(p % (unsigned)W);
+        p /= (unsigned)W;
+        const int iy = (int)(p % (unsigned)H);
+        const int n = (int)(p / (unsigned)H);
+        const int xm = max(ix - 1, 0), xp = min(ix + 1, W - 1);
+        const int ym = max(iy - 1, 0), yp = min(iy + 1, H - 1);
         const float *b = in + (size_t)n * H * W * in_cs + 4 * q;
-        const float4 p00 = *reinterpret_cast<const float4 *>(b + ((size_t)y0 * W + x0) * in_cs);
-        const float4 p01 = *reinterpret_cast<const float4 *>(b + ((size_t)y0 * W + x1) * in_cs);
-        const float4 p10 = *reinterpret_cast<const float4 *>(b + ((size_t)y1 * W + x0) * in_cs);
-        const float4 p11 = *reinterpret_cast<const float4 *>(b + ((size_t)y1 * W + x1) * in_cs);
-        float4 o;
-        o.x = hy0 * (wx0 * p00.x + wx1 * p01.x) + hy1 * (wx0 * p10.x + wx1 * p11.x);
-        o.y = hy0 * (wx0 * p00.y + wx1 * p01.y) + hy1 * (wx0 * p10.y + wx1 * p11.y);
-        o.z = hy0 * (wx0 * p00.z + wx1 * p01.z) + hy1 * (wx0 * p10.z + wx1 * p11.z);
-        o.w = hy0 * (wx0 * p00.w + wx1 * p01.w) + hy1 * (wx0 * p10.w + wx1 * p11.w);
-        *reinterpret_cast<float4 *>(out + (((size_t)n * Ho + y) * Wo + x) * out_cs + 4 * q) = o;
+        const float *r0 = b + (size_t)ym * W * in_cs, *r1 = b + (size_t)iy * W * in_cs, *r2 = b + (size_t)yp * W * in_cs;
+        float4 v[3][3];
+        v[0][0] = *reinterpret_cast<const float4 *>(r0 + (size_t)xm * in_cs);
+        v[0][1] = *reinterpret_cast<const float4 *>(r0 + (size_t)ix * in_cs);
+        v[0][2] = *reinterpret_cast<const float4 *>(r0 + (size_t)xp * in_cs);
+        v[1][0] = *reinterpret_cast<const float4 *>(r1 + (size_t)xm * in_cs);
+        v[1][1] = *reinterpret_cast<const float4 *>(r1 + (size_t)ix * in_cs);
+        v[1][2] = *reinterpret_cast<const float4 *>(r1 + (size_t)xp * in_cs);
+        v[2][0] = *reinterpret_cast<const float4 *>(r2 + (size_t)xm * in_cs);
+        v[2][1] = *reinterpret_cast<const float4 *>(r2 + (size_t)ix * in_cs);
+        v[2][2] = *reinterpret_cast<const float4 *>(r2 + (size_t)xp * in_cs);
+        // even output column 2ix: taps (ix-1, ix) with weights (.25, .75); odd column 2ix+1: taps (ix, ix+1) with (.75, .25)
+        float4 e[3], o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            e[r].x = lo * v[r][0].x + hi * v[r][1].x; e[r].y = lo * v[r][0].y + hi * v[r][1].y;
+            e[r].z = lo * v[r][0].z + hi * v[r][1].z; e[r].w = lo * v[r][0].w + hi * v[r][1].w;
+            o[r].x = hi * v[r][1].x + lo * v[r][2].x; o[r].y = hi * v[r][1].y + lo * v[r][2].y;
+            o[r].z = hi * v[r][1].z + lo * v[r][2].z; o[r].w = hi * v[r][1].w + lo * v[r][2].w;
+        }
+        // even output row 2iy: rows (iy-1, iy) with (.25, .75); odd row 2iy+1: rows (iy, iy+1) with (.75, .25)
+        float4 o00, o01, o10, o11;
+        o00.x = lo * e[0].x + hi * e[1].x; o00.y = lo * e[0].y + hi * e[1].y; o00.z = lo * e[0].z + hi * e[1].z; o00.w = lo * e[0].w + hi * e[1].w;
+        o01.x = lo * o[0].x + hi * o[1].x; o01.y = lo * o[0].y + hi * o[1].y; o01.z = lo * o[0].z + hi * o[1].z; o01.w = lo * o[0].w + hi * o[1].w;
+        o10.x = hi * e[1].x + lo * e[2].x; o10.y = hi * e[1].y + lo * e[2].y; o10.z = hi * e[1].z + lo * e[2].z; o10.w = hi * e[1].w + lo * e[2].w;
+        o11.x = hi * o[1].x + lo * o[2].x; o11.y = hi * o[1].y + lo * o[2].y; o11.z = hi * o[1].z + lo * o[2].z; o11.w = hi * o[1].w + lo * o[2].w;
+        float *d = out + (((size_t)n * 2 * H + 2 * iy) * Wo + 2 * ix) * out_cs + 4 * q;
+        *reinterpret_cast<float4 *>(d) = o00;
+        *reinterpret_cast<float4 *>(d + out_cs) = o01;
+        *reinterpret_cast<float4 *>(d + (size_t)Wo * out_cs) = o10;
+        *reinterpret_cast<float4 *>(d + (size_t)Wo * out_cs + out_cs) = o11;
     }
 }
 
@@ -1372,7 +1393,8 @@ int level_kind(const PreparedConv &pc) {
 
 int check_upsample(const idh_op &op) {
     const idh_conv_src &s = op.src[0];
-    if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0) return IDH_EINVAL;
+    if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0 || s.H <= 0 || s.W <= 0) return IDH_EINVAL;
+    if ((long long)op.N * s.H * s.W * (s.Cin >> 2) >= (1ll << 31)) return IDH_EUNSUPPORTED;  // (upsample2_body: 32-bit quad index)
     return IDH_OK;
 }
 
@@ -1435,8 +1457,8 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                         c.out = o.out; c.out_cs = o.out_cs; c.M = o.N; c.S = 1;
                         pc.a = c;
                         const long long tot = (long long)o.N * 4 * us.H * us.W * (us.Cin >> 2);
-                        const long long natural = idh_cdiv(tot, 256);
-                        pc.blocks = (unsigned)std::min<long long>(natural, kLevelUpsampleBlocks);
+                        const long long natural = idh_cdiv(tot, 256);  // (output float4s: the measure the thresholds were tuned in)
+                        pc.blocks = (unsigned)std::min<long long>(idh_cdiv(tot / 4, 256), kLevelUpsampleBlocks);  // one thread per 2x2 quad
                         // a large upsample (batch >= 2 at the top resolutions) runs at HBM speed on its own grid of thousands
                         // of blocks; squeezed into 512 grid-stride blocks it is slower than the launch it saves
                         kinds[run] = natural <= kLevelUpsampleNatural ? LV_UP2 : -1;
@@ -1488,9 +1510,9 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                     if (rc == IDH_OK) rc = launch_reduces(pcs, 1, st);
                     used = 1;
                 } else {
-                    const long long tot = (long long)op.N * 4 * s.H * s.W * (s.Cin >> 2);
-                    int grid = idh_cdiv(tot, 256);
-                    if (grid > 8192) grid = 8192;
+                    const long long quads = (long long)op.N * s.H * s.W * (s.Cin >> 2);  // one thread per 2x2 output quad x 4 channels
+                    int grid = idh_cdiv(quads, 256);
+                    if (grid > 32768) grid = 32768;
                     IDH_LAUNCH(upsample2_k, dim3(grid), dim3(256), 0, st, s.in, op.out, op.N, s.H, s.W, s.Cin, s.cs, op.out_cs);
                     IDH_CHECK_LAUNCH();
                     rc = IDH_OK;
