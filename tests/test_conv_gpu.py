@@ -206,6 +206,32 @@ def test_conv_block_relu_and_use_bn_flag():
         assert rel_err(out.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 1, 1), (2, 64, 5, 7), (3, 32, 12, 16), (1, 256, 3, 9), (33, 64, 48, 64)])
+def test_upsample2_matches_interpolate_on_strided_slices(shape):
+    """upsample2_k (one thread per 2x2 output quad, clamped 3x3 neighbourhood): F.interpolate(scale_factor=2, mode="bilinear",
+    align_corners=False) (utils/generic_utils.py:94-103 of the reference's ``upsample``) on odd sizes, 1x1 maps, a source that is a channel
+    slice of a wider buffer and a destination slice of a concat buffer whose other channels must stay untouched (level_k's copy of the body runs in test_level_merged_launches_*)."""
+    import torch.nn.functional as F
+    from implicit_depth_amd import nhwc
+
+    N, C, H, W = shape
+    dev = torch.device("cuda")
+    p = nhwc.Plan(dev)
+    src = p.buffer(N, H, W, C + 16)
+    cat = p.buffer(N, 2 * H, 2 * W, 2 * C + 16)
+    g = torch.Generator().manual_seed(N * 1000 + C + H)
+    xt = torch.randn(N, H, W, C + 16, generator=g).to(dev)
+    src.dense().copy_(xt)
+    cat.dense().fill_(7.0)
+    p.upsample2(src.slice(16, C), cat.slice(C, C))
+    p.schedule()
+    p.run()
+    ref = F.interpolate(xt[..., 16:].permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    got = cat.dense()
+    assert float((got[..., C:2 * C].double() - ref).abs().max()) < 1e-6
+    assert bool((got[..., :C] == 7.0).all()) and bool((got[..., 2 * C:] == 7.0).all())
+
+
 def test_fused_upsample_concat_is_bit_identical_to_materialised():
     """nhwc.FUSE_UPSAMPLE: the decoder's x2 bilinear upsampling + concat interpolated inside the consumer conv's halo
     loader (idh_conv_src.up_*) instead of upsample2_k writing a concat buffer — same blend expression, so the outputs
