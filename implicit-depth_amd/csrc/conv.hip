@@ -1209,6 +1209,16 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
     a.M = (int)M; a.steps_total = steps; a.act = op.act; a.slope = op.slope;
     a.S = op.split_k > 1 ? op.split_k : 1;
     if (a.S > steps) a.S = steps;
+    // A lone 3x3 stride-2 conv (conv1 of a stride-2 BasicBlock) asked onto the LDS-staged kernel (tile_m 8 / 9): it runs as the kernel's
+    // stride-2 SECOND source (halo de-interleaved by column parity) behind an empty first source (no chunks: its loops do not execute,
+    // its descriptors have zero range).
+    if (a.s[0].ks == 3 && a.s[0].stride == 2 && !a.s[1].in && (op.tile_m == 8 || op.tile_m == 9) && a.s[0].pad_mode == IDH_PAD_ZEROS &&
+        !a.s[0].up_in[0] && !a.s[0].norm && op.Wo >= kLT_W && (op.Cout % 32) == 0 && (op.tile_n == 0 ? (op.Cout % 64) == 0 : op.tile_n == 2)) {
+        a.s[1] = a.s[0];
+        ConvSrc e{};
+        e.in = a.s[1].in; e.w = a.s[1].w; e.ks = 3; e.stride = 1; e.pad_mode = IDH_PAD_ZEROS;  // cblocks = H = W = cs = 0
+        a.s[0] = e;
+    }
     // LDS-staged kernel for the dominant shape family: tile_m 8 / 9 request the 8- / 4-row tile,
     // 0 = auto (8-row)
     // LDS kernels: tile_n = output sub-tiles of 16 channels per workgroup (0 = 4 -> 64 channels; 2; 1)

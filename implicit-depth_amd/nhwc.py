@@ -366,6 +366,23 @@ def lds_eligible(srcs, cout: int, Wo: int, pad_mode: int) -> bool:
     return True
 
 
+# A lone 3x3 stride-2 conv (conv1 of a stride-2 BasicBlock, layers.py:62-66) on the LDS-staged kernel's stride-2 loader (the one the strided
+# projections use: halo de-interleaved by column parity, every tap's fragment read conflict-free) instead of the direct-fragment kernel, which
+# re-reads each input pixel 9 times through L1 (46-55 % MFMA-busy).  Below S2_FIRST_MIN_BLOCKS 4-row workgroups the direct kernel stays: at
+# one or two frames it is a member of the level launch (level_k).
+S2_FIRST = True
+S2_FIRST_MIN_BLOCKS = 512
+
+
+def s2_first_eligible(srcs, cout: int, N: int, Ho: int, Wo: int, pad_mode: int) -> bool:
+    if not S2_FIRST or len(srcs) != 1:
+        return False
+    (v0, c0) = srcs[0]
+    if c0.kernel_size[0] != 3 or c0.stride[0] != 2 or pad_mode != PAD_ZEROS or cout % 32 or Wo < 16 or isinstance(v0, CatView):
+        return False
+    return N * (-(-Wo // 16)) * (-(-Ho // 4)) * (cout // (16 * lds_subtiles(cout))) >= S2_FIRST_MIN_BLOCKS
+
+
 def lds_subtiles(cout: int) -> int:
     """16-channel output sub-tiles per workgroup of the LDS-staged kernel (the op's tile_n): 64 channels when the
     layer has them, else 32 / 16 (the matching encoder's 128 -> 16 conv)."""
@@ -537,6 +554,10 @@ class Plan:
                 blocks64 = out.N * (-(-out.H // 4)) * (-(-out.W // 16)) * (conv.out_channels // 64) * split
                 if blocks64 < NARROW_TILE_BELOW:
                     tn = 1 if blocks64 < NARROWEST_TILE_BELOW else 2
+            tn = 0 if tn == 4 else tn
+        elif self.math == "fp32" and norm is None and s2_first_eligible(srcs, conv.out_channels, out.N, out.H, out.W, pad_mode):
+            tm, split = choose_lds_tile(out.N, out.H, out.W, conv.out_channels, ceil16(x.C) // 16)
+            tn = lds_subtiles(conv.out_channels)
             tn = 0 if tn == 4 else tn
         else:
             tm, tn, split = choose_tiles(M, conv.out_channels, steps)
@@ -867,7 +888,8 @@ def build_flags() -> tuple:
     """Module-level switches that shape a plan at build time (part of every plan-cache key: toggling one takes effect on the
     next call instead of silently replaying a plan built under the old setting)."""
     return (WINO_GROUP, FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
-            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINOGRAD4_PROJ, WINO4_MIN_TILES, WINO4_MIN_FILL, BUFFER_REUSE, REUSE_MIN_BYTES, DEFAULT_MATH)
+            SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINOGRAD4_PROJ, WINO4_MIN_TILES, WINO4_MIN_FILL, BUFFER_REUSE, REUSE_MIN_BYTES, DEFAULT_MATH,
+            S2_FIRST, S2_FIRST_MIN_BLOCKS)
 
 
 def _plan_cache(module: nn.Module) -> PlanCache:

@@ -50,6 +50,32 @@ def test_basic_block_vs_oracle(shape):
     assert rel_err(bb(x2.cuda()).cpu(), ref2) < TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 64), (1, 128, 256, 31, 45), (3, 48, 96, 24, 40), (1, 256, 384, 24, 32), (2, 16, 64, 9, 33)])
+def test_stride2_first_conv_on_the_lds_loader_vs_oracle(shape):
+    """nhwc.S2_FIRST: conv1 of a stride-2 BasicBlock (layers.py:62-66) through the LDS-staged kernel's stride-2 loader (an empty first
+    source + the strided 3x3 as the second one) instead of conv_mfma_k - forced here at every size (threshold 0), incl. odd maps, 32-channel
+    tiles (Cout = 96), a 16-channel input and split K; against the fp64 oracle, and the plan must really hold an 8- / 4-row stride-2 op."""
+    from implicit_depth_amd import nhwc
+    from implicit_depth_amd.layers import BasicBlock
+
+    N, cin, cout, H, W = shape
+    bb = BasicBlock(cin, cout, 2)
+    syn.fill_state_dict(bb, seed=cin + cout + 1)
+    x = syn.randn((N, cin, H, W), 5, "x")
+    ref = onet.basic_block(x.double(), {k: v.double() for k, v in _cpu_sd(bb).items()}, 2)
+    old, nhwc.S2_FIRST_MIN_BLOCKS = nhwc.S2_FIRST_MIN_BLOCKS, 0
+    try:
+        y = bb.cuda()(x.cuda()).cpu()
+        plan = next(iter(bb.__dict__["_idh_plans"].values()))[0]
+        hit = [op for op in plan.ops if op.kind == nhwc.OP_CONV and op.src[0].stride == 2 and not op.src[1].in_ and op.tile_m in (8, 9)]
+        assert len(hit) == 1
+    finally:
+        nhwc.S2_FIRST_MIN_BLOCKS = old
+        bb.__dict__.pop("_idh_plans", None)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < TOL
+
+
 def test_weight_update_invalidates_packed_cache():
     from implicit_depth_amd.layers import BasicBlock
 
