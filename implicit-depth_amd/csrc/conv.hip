@@ -258,6 +258,17 @@ constexpr int lds_a2_slots(int RW) { return (8 * RW + 1) * 4 * 2 * kHalo2Wh; }  
 constexpr int lds_a_slots(int RW, bool S2) { return S2 ? (lds_a2_slots(RW) > lds_a_slots(RW) ? lds_a2_slots(RW) : lds_a_slots(RW)) : lds_a_slots(RW); }
 constexpr int lds_b_slots(int NJ) { return 9 * 4 * 16 * NJ; }
 
+// 1x1 second source (BasicBlock's fused projection): its 16-channel chunks are staged SEVERAL per barrier pair.  One chunk is only the tile's
+// centre pixels + a 4 x kN panel and feeds 4 * RW * NJ MFMAs per wave - a ninth of a 3x3 chunk - so with one chunk per round the two
+// barriers and the commit dominate (a 640-channel projection: 40 rounds).  Chunk 0 of a round keeps the halo image's place in sA, the
+// panels of all chunks and the centre images of chunks 1.. share sB (idle between the 3x3 chunks and here): as many chunks as fit, at most 4.
+constexpr int lds_c1_slots(int RW) { return 4 * RW * 4 * kHaloW; }  // centre image of one 1x1 chunk, rows padded like the halo's
+constexpr int lds_g1(int RW, int NJ) {
+    int g = 1;
+    while (g < 4 && (g + 1) * 4 * 16 * NJ + g * lds_c1_slots(RW) <= lds_b_slots(NJ)) ++g;
+    return g;
+}
+
 // sA / sB: the workgroup's LDS images (declared by the kernel so that a kernel hosting several instantiations
 // of this body — level_k — allocates them once)
 // NORM: source 0 is read through a per-(image, channel) normalisation + activation (idh_conv_src.norm): the statistics
@@ -309,8 +320,17 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     // chunk list = [source-0 chunks][source-1 chunks]; this block's split owns [t0,t1)
     const int nc0 = a.s[0].cblocks;
     const int nc1 = a.s[1].in ? a.s[1].cblocks : 0;
-    const int t0 = (int)((long long)(nc0 + nc1) * sp / a.S);
-    const int t1 = (int)((long long)(nc0 + nc1) * (sp + 1) / a.S);
+    // split boundaries in COST units, not chunks: a 3x3 chunk is 9 taps of MFMAs + one staging round, a 1x1 chunk one tap and (batched,
+    // lds_g1) a fraction of a round - about a ninth (measured flat between 4 and 9, tools/r05/job_c3.sh).  With equal weights the first split of a
+    // BasicBlock's conv2 + projection got all 3x3 chunks and the last ones only 1x1 chunks: the launch took as long as the unsplit 3x3 part.
+    const int kW3 = a.MT > 0 ? a.MT : 9;  // (tuning: IDH_SPLIT_W3 through the otherwise unused MT)
+    const int w1 = S2 ? kW3 : 1;
+    const int T = kW3 * nc0 + w1 * nc1;
+    auto split_bound = [&](int s_) {
+        const int b = (int)((long long)T * s_ / a.S);
+        return b <= kW3 * nc0 ? (b + kW3 - 1) / kW3 : nc0 + (b - kW3 * nc0 + w1 - 1) / w1;
+    };
+    const int t0 = split_bound(sp), t1 = split_bound(sp + 1);
 
     // ---- staging: global -> registers (prefetch) -> LDS -----------------------------------
     // A slots are enumerated (hy, hx, q) with q fastest so that 4 consecutive lanes read the 64
@@ -628,6 +648,59 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
                 __syncthreads();
                 if (c + 1 < hi) issue2(c + 1);
                 compute2();
+            }
+        } else if constexpr (!UP && lds_g1(RW, NJ) > 1) {
+            // rounds of G1 chunks (see lds_g1): same chunk order and MFMA order as one chunk per round, so the same bits
+            constexpr int G1 = lds_g1(RW, NJ);
+            constexpr int kB1 = 4 * kN, kC1 = lds_c1_slots(RW);
+            f32x4 qa[G1][kCLoads], qb[G1];
+            auto issue1b = [&](int c) {
+#pragma unroll
+                for (int g = 0; g < G1; ++g)
+                    if (c + g < hi) {
+#pragma unroll
+                        for (int k = 0; k < kCLoads; ++k)
+                            qa[g][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsC, voffC[k], 64 * (c + g), 0));
+                        qb[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW1, voffB1, (c + g) * 4 * a.Cout_pad * 16, 0));
+                    }
+            };
+            if (lo < hi) issue1b(lo);
+#pragma unroll 1
+            for (int c = lo; c < hi; c += G1) {
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < G1; ++g)
+                    if (c + g < hi) {
+#pragma unroll
+                        for (int k = 0; k < kCLoads; ++k) {
+                            const int slot = tid + 256 * k;
+                            const int q = slot & 3, pix = slot >> 2;
+                            const int py = pix >> 4, px = pix & 15;
+                            if (g == 0) sA[((py + 1) * 4 + q) * kHaloW + px + 1] = qa[g][k];
+                            else sB[G1 * kB1 + (g - 1) * kC1 + (py * 4 + q) * kHaloW + px] = qa[g][k];
+                        }
+                        if (tid < kB1) sB[g * kB1 + tid] = qb[g];
+                    }
+                __syncthreads();
+                if (c + G1 < hi) issue1b(c + G1);
+#pragma unroll
+                for (int g = 0; g < G1; ++g)
+                    if (c + g < hi) {
+                        f32x4 A[RW], Bf[NJ];
+#pragma unroll
+                        for (int i = 0; i < RW; ++i)
+                            A[i] = g == 0 ? sA[((RW * wave + i + 1) * 4 + h) * kHaloW + ln + 1]
+                                          : sB[G1 * kB1 + (g - 1) * kC1 + ((RW * wave + i) * 4 + h) * kHaloW + ln];
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) Bf[j] = sB[g * kB1 + h * kN + 16 * j + ln];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int i = 0; i < RW; ++i)
+#pragma unroll
+                                for (int j = 0; j < NJ; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bf[j][kk], A[i][kk], acc[i][j], 0, 0, 0);
+                    }
             }
         } else {
             if (lo < hi) issue1(lo);
@@ -1265,6 +1338,7 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
         if (a.S > chunks) a.S = chunks;
         a.NT = op.Cout / (16 * nj);
+        { static const int w3 = getenv("IDH_SPLIT_W3") ? atoi(getenv("IDH_SPLIT_W3")) : 0; a.MT = w3; }
         pc.nj = nj;
         pc.la = LdsConvArgs{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + rows - 1) / rows};
         const long long blocks = (long long)a.S * op.N * pc.la.tiles_x * pc.la.tiles_y * a.NT;

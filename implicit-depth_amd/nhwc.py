@@ -399,6 +399,7 @@ NARROWEST_TILE_BELOW = 0  # below this many 64-channel workgroups use 16-channel
 
 SPLIT_MIN_CHUNKS = 6
 SPLIT_MAX = 16
+PROJ_CHUNK_WEIGHT = 0.5  # a 1x1 (projection) chunk in units of a 3x3 chunk when the split-K factor is chosen (1.0 / 0.5 / 0.25 measured: B=1 2.353 / 2.330 / 2.343 ms, B=4 5.135 / 5.099 / 5.110)
 
 
 def choose_lds_tile(N: int, Ho: int, Wo: int, cout: int, chunks: int):
@@ -545,7 +546,8 @@ class Plan:
         elif use_wino:
             tm, tn, split = TILE_WINO, 0, 1
         elif lds_eligible(srcs, conv.out_channels, out.W, pad_mode):
-            chunks = sum(ceil16(v.C) // 16 for v, _ in srcs)
+            # split-K factor from the chunk count in units of a 3x3 chunk: a 1x1 (projection) chunk is PROJ_CHUNK_WEIGHT of one
+            chunks = int(sum((ceil16(v.C) // 16) * (1.0 if cv.kernel_size[0] == 3 else PROJ_CHUNK_WEIGHT) for v, cv in srcs))
             tm, split = choose_lds_tile(out.N, out.H, out.W, conv.out_channels, chunks)
             if tm == 8 and FUSED_UP_ROWS == 4 and any(isinstance(v, CatView) for v, _ in srcs):
                 tm = 9
