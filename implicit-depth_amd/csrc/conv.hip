@@ -1110,13 +1110,15 @@ __global__ __launch_bounds__(256) void pointwise_head_k(const float *__restrict_
 // reduction: per-(image, pixel-chunk) channel sums -> per-thread combine in the apply kernel.
 constexpr int kInChunk = 1024;  // pixels per partial
 
-__global__ __launch_bounds__(256) void instnorm_stats_k(const float *__restrict__ in, int cs, int C, int HW, int nchunks,
-                                                        float *__restrict__ part) {  // part[n][chunk][2][C]
-    extern __shared__ float red[];  // 256 * 8 floats
+// blockDim.x = 256, or 1024 when the launch has too few (image, chunk) pairs to fill the chip (one frame: 8 images x 12 chunks): the chunk
+// partition - and with it the workspace layout of the C ABI - stays, a chunk's pixels are spread over four times the threads
+__global__ __launch_bounds__(1024) void instnorm_stats_k(const float *__restrict__ in, int cs, int C, int HW, int nchunks,
+                                                         float *__restrict__ part) {  // part[n][chunk][2][C]
+    extern __shared__ float red[];  // blockDim.x * 8 floats
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int cq = C >> 2;                 // channel quads
     const int q = threadIdx.x % cq;
-    const int prow = threadIdx.x / cq, pstep = 256 / cq;  // host guarantees cq divides 256
+    const int prow = threadIdx.x / cq, pstep = (int)blockDim.x / cq;  // host guarantees cq divides 256
     const int p0 = chunk * kInChunk, p1 = min(HW, p0 + kInChunk);
     // sums of (x - pivot) and (x - pivot)^2 with pivot = the image's first pixel: E[x^2] - mean^2 on the raw values cancels
     // catastrophically for a channel whose |mean| is large against its spread (~(mean/std)^2 * 1e-7 relative; a biased 1x1 conv on
@@ -1132,12 +1134,11 @@ __global__ __launch_bounds__(256) void instnorm_stats_k(const float *__restrict_
     float *mine = red + threadIdx.x * 8;
     for (int e = 0; e < 4; ++e) { mine[e] = s[e]; mine[4 + e] = ss[e]; }
     __syncthreads();
-    if (threadIdx.x < cq) {  // fixed-order combine over the pstep rows: deterministic
-        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r = 0; r < pstep; ++r)
-            for (int e = 0; e < 8; ++e) a[e] += red[(r * cq + threadIdx.x) * 8 + e];
-        float *o = part + ((size_t)(n * nchunks + chunk) * 2) * C + 4 * threadIdx.x;
-        for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[C + e] = a[4 + e]; }
+    if (threadIdx.x < 8 * cq) {  // fixed-order combine over the pstep rows (deterministic), one thread per (channel quad, sum)
+        const int qq = threadIdx.x >> 3, e = threadIdx.x & 7;
+        float a = 0.f;
+        for (int r = 0; r < pstep; ++r) a += red[(r * cq + qq) * 8 + e];
+        part[((size_t)(n * nchunks + chunk) * 2 + (e >> 2)) * C + 4 * qq + (e & 3)] = a;
     }
 }
 
@@ -1673,7 +1674,8 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                     op.N <= 0 || op.N > 65535)
                     return IDH_EINVAL;
                 const int nchunks = idh_cdiv(HW, kInChunk);
-                IDH_LAUNCH(instnorm_stats_k, dim3(nchunks, op.N), dim3(256), 256 * 8 * sizeof(float), st, s.in, s.cs, C, HW,
+                const int sthreads = ((long long)nchunks * op.N < 512 && C >= 64) ? 1024 : 256;
+                IDH_LAUNCH(instnorm_stats_k, dim3(nchunks, op.N), dim3(sthreads), sthreads * 8 * sizeof(float), st, s.in, s.cs, C, HW,
                                    nchunks, op.ws);
                 IDH_CHECK_LAUNCH();
                 float *stats = op.ws + (size_t)op.N * nchunks * 2 * C;
