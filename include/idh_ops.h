@@ -87,7 +87,9 @@ typedef struct idh_op {
     float slope;
     int32_t split_k;      /* 1 = no split */
     int32_t tile_m, tile_n; /* direct kernel: wave tile in 16-wide MFMA sub-tiles (1,2,4), 0 = auto;
-                               tile_m = 8 / 9 selects the LDS-staged kernel with 8- / 4-row tiles;
+                               tile_m = 8 / 9 selects the LDS-staged kernel with 8- / 4-row tiles (3x3 stride 1 [+ a 1x1 or a
+                               3x3 stride-2 second source], or a LONE 3x3 stride-2 zero-padded source with Cout % 32 == 0 and
+                               Wo >= 16 - conv1 of a stride-2 BasicBlock - which runs on the kernel's stride-2 loader);
                                tile_m = IDH_SPLIT_F16X3 selects the split-precision
                                kernel (3x3 stride 1, one source, Cout % 64 == 0; src[0].w =
                                idh_pack_conv_weight_split output of the same mode); there tile_n = 8
