@@ -323,7 +323,7 @@ __device__ __forceinline__ void conv3x3_lds_body(const LdsConvArgs &la, unsigned
     // split boundaries in COST units, not chunks: a 3x3 chunk is 9 taps of MFMAs + one staging round, a 1x1 chunk one tap and (batched,
     // lds_g1) a fraction of a round - about a ninth (measured flat between 4 and 9, tools/r05/job_c3.sh).  With equal weights the first split of a
     // BasicBlock's conv2 + projection got all 3x3 chunks and the last ones only 1x1 chunks: the launch took as long as the unsplit 3x3 part.
-    const int kW3 = a.MT > 0 ? a.MT : 9;  // (tuning: IDH_SPLIT_W3 through the otherwise unused MT)
+    constexpr int kW3 = 9;
     const int w1 = S2 ? kW3 : 1;
     const int T = kW3 * nc0 + w1 * nc1;
     auto split_bound = [&](int s_) {
@@ -1339,7 +1339,6 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
         if (a.S > chunks) a.S = chunks;
         a.NT = op.Cout / (16 * nj);
-        { static const int w3 = getenv("IDH_SPLIT_W3") ? atoi(getenv("IDH_SPLIT_W3")) : 0; a.MT = w3; }
         pc.nj = nj;
         pc.la = LdsConvArgs{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + rows - 1) / rows};
         const long long blocks = (long long)a.S * op.N * pc.la.tiles_x * pc.la.tiles_y * a.NT;
