@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a tuning build: IDH_SPLIT_W3 was read by csrc/conv.hip only while this sweep ran; the shipped kernel has the weight as a constant)
 export TMPDIR=/tmp
 for b in 1 4; do
  for w in 3 4 6 9; do for pw in 1.0 0.5 0.25; do
