@@ -1087,6 +1087,86 @@ __global__ __launch_bounds__(256, 4) void pointwise_nchw_k(const PwNchwArgs a) {
     }
 }
 
+// IDH_OP_POINTWISE_UP: out = W . x (+ bias) + up2(low) - a 1x1 convolution of an NHWC tensor plus the x2 bilinear upsampling (align_corners=False,
+// upsample2_k's expression) of a half-resolution NHWC tensor of Cout channels.  It is the projection branch of the decoder blocks whose input is
+// cat(right, up(lo), up(lo2)) (networks.py:52-77: BasicBlock's downsample(x), layers.py:86-92): a 1x1 convolution commutes with bilinear
+// upsampling (the interpolation weights sum to one), so W . cat = W_a . right + up(W_b . lo + W_c . lo2) - two thirds of the projection run at a
+// quarter of the pixels, and conv2 takes the sum as an ordinary residual instead of multiplying 192 channels in its epilogue.
+//   * D^T = W . X^T as in pointwise_nchw_k: the packed weights ([ci / 4][co] float4, idh_pack_conv_weight ks = 1) LDS-resident, lane (ln, h) loads
+//     channels 16c + 4h .. + 3 of pixel ln (one 16-byte load per 16-channel block), a wave owns 16 pixels x Cout channels, a workgroup 64 pixels;
+//   * epilogue: the lane's 4 consecutive output channels of its pixel + the bilinear blend of the same channels of the 4 low-resolution
+//     neighbours (4 x NT 16-byte loads, L2-resident: the low map is a quarter of the output), one 16-byte store per 16-channel block.
+// HBM-bound (reads Cin, writes Cout floats per pixel).  Cin == Cout in {64, 128} (every decoder level that takes the F(4x4) kernel).
+struct PwUpArgs {
+    const float *in, *w, *bias, *low;
+    float *out;
+    int H, W, in_cs, low_cs, out_cs, tiles_per_img;
+    long long tiles;
+};
+
+template <int C16, int NT>
+__global__ __launch_bounds__(256) void pointwise_up_k(const PwUpArgs a) {
+    constexpr int kCout = 16 * NT;
+    extern __shared__ f32x4 sWu[];  // [4 * C16][kCout]
+    {
+        const f32x4 *g = reinterpret_cast<const f32x4 *>(a.w);
+        for (int i = threadIdx.x; i < 4 * C16 * kCout; i += 256) sWu[i] = g[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ln = lane & 15, h = lane >> 4;
+    const int HW = a.H * a.W, Hl = a.H >> 1, Wl = a.W >> 1;
+    for (long long tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+        const int n = (int)(tile / a.tiles_per_img);
+        const int p = (int)(tile - (long long)n * a.tiles_per_img) * kPwTile + 16 * wave + ln;
+        const bool ok = p < HW;
+        const int pc = ok ? p : 0;
+        const float *ip = a.in + ((size_t)n * HW + pc) * a.in_cs + 4 * h;
+        f32x4 x[C16];
+#pragma unroll
+        for (int c = 0; c < C16; ++c) x[c] = *reinterpret_cast<const f32x4 *>(ip + 16 * c);
+        // low-resolution neighbours and weights of output pixel (y, xq): exactly upsample2_body's
+        const int y = pc / a.W, xq = pc - y * a.W;
+        const int iy = y >> 1, ix = xq >> 1;
+        int y0, y1, x0, x1;
+        float hy0, hy1, wx0, wx1;
+        if (y & 1) { y0 = iy; y1 = min(iy + 1, Hl - 1); hy0 = 0.75f; hy1 = 0.25f; }
+        else { y0 = max(iy - 1, 0); y1 = iy; hy0 = 0.25f; hy1 = 0.75f; }
+        if (xq & 1) { x0 = ix; x1 = min(ix + 1, Wl - 1); wx0 = 0.75f; wx1 = 0.25f; }
+        else { x0 = max(ix - 1, 0); x1 = ix; wx0 = 0.25f; wx1 = 0.75f; }
+        const float *lb = a.low + (size_t)n * Hl * Wl * a.low_cs + 4 * h;
+        const float *t00 = lb + ((size_t)y0 * Wl + x0) * a.low_cs, *t01 = lb + ((size_t)y0 * Wl + x1) * a.low_cs;
+        const float *t10 = lb + ((size_t)y1 * Wl + x0) * a.low_cs, *t11 = lb + ((size_t)y1 * Wl + x1) * a.low_cs;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + 16 * j + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        int opaque = 0;  // (keeps the weight fragments' LDS reads inside the tile loop: hoisted they are 4 * C16 * NT registers)
+        asm volatile("" : "+s"(opaque));
+        const f32x4 *sWt = sWu + opaque;
+#pragma unroll
+        for (int c = 0; c < C16; ++c)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 A = sWt[(4 * c + h) * kCout + 16 * j + ln];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], x[c][kk], acc[j], 0, 0, 0);
+            }
+        if (ok) {
+            float *o = a.out + ((size_t)n * HW + p) * a.out_cs + 4 * h;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 p00 = *reinterpret_cast<const f32x4 *>(t00 + 16 * j), p01 = *reinterpret_cast<const f32x4 *>(t01 + 16 * j);
+                const f32x4 p10 = *reinterpret_cast<const f32x4 *>(t10 + 16 * j), p11 = *reinterpret_cast<const f32x4 *>(t11 + 16 * j);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][e] + (hy0 * (wx0 * p00[e] + wx1 * p01[e]) + hy1 * (wx0 * p10[e] + wx1 * p11[e]));
+                *reinterpret_cast<f32x4 *>(o + 16 * j) = v;
+            }
+        }
+    }
+}
+
 // 1x1 conv to a single channel: one thread per pixel
 __global__ __launch_bounds__(256) void pointwise_head_k(const float *__restrict__ in, const float *__restrict__ w,
                                                         const float *__restrict__ bias, float *__restrict__ out,
@@ -1655,6 +1735,25 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 pa.tiles = (long long)op.N * pa.tiles_per_img;
                 const int grid = (int)std::min<long long>(pa.tiles, 256 * 4 * 4);
                 IDH_LAUNCH(pointwise_nchw_k, dim3(grid), dim3(256), 0, st, pa);
+                IDH_CHECK_LAUNCH();
+                break;
+            }
+            case IDH_OP_POINTWISE_UP: {
+                // src[0] = x (N, H, W, Cin) + idh_pack_conv_weight(Cout, Cin, 1); src[1].in = the half-resolution map (N, H/2, W/2, Cout), src[1].cs its stride
+                const idh_conv_src &lo = op.src[1];
+                if (!s.in || !s.w || !lo.in || !op.out || op.N <= 0 || s.H <= 0 || s.W <= 0 || (s.H & 1) || (s.W & 1) || (s.cs & 3) || (lo.cs & 3) || (op.out_cs & 3) ||
+                    s.cs < s.Cin || lo.cs < op.Cout || op.out_cs < op.Cout || ((uintptr_t)s.in & 15) || ((uintptr_t)lo.in & 15) || ((uintptr_t)op.out & 15) ||
+                    ((uintptr_t)s.w & 15) || (op.bias && ((uintptr_t)op.bias & 15)) || lo.H != s.H / 2 || lo.W != s.W / 2)
+                    return IDH_EINVAL;
+                if (s.Cin != op.Cout || (s.Cin != 64 && s.Cin != 128) || (long long)s.H * s.W >= (1ll << 31)) return IDH_EUNSUPPORTED;
+                PwUpArgs pa{};
+                pa.in = s.in; pa.w = s.w; pa.bias = op.bias; pa.low = lo.in; pa.out = op.out;
+                pa.H = s.H; pa.W = s.W; pa.in_cs = s.cs; pa.low_cs = lo.cs; pa.out_cs = op.out_cs;
+                pa.tiles_per_img = idh_cdiv(s.H * s.W, kPwTile);
+                pa.tiles = (long long)op.N * pa.tiles_per_img;
+                const int grid = (int)std::min<long long>(pa.tiles, 256 * 8);
+                if (s.Cin == 64) IDH_LAUNCH((pointwise_up_k<4, 4>), dim3(grid), dim3(256), 16 * 64 * sizeof(f32x4), st, pa);
+                else IDH_LAUNCH((pointwise_up_k<8, 8>), dim3(grid), dim3(256), 32 * 128 * sizeof(f32x4), st, pa);
                 IDH_CHECK_LAUNCH();
                 break;
             }

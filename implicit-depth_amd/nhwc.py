@@ -25,7 +25,7 @@ from torch import nn
 from . import _lib
 
 # --- ctypes mirrors of include/idh_ops.h -------------------------------------------------
-OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD, OP_INSTNORM, OP_UPSAMPLE2_NEAREST, OP_COPY, OP_POINTWISE_NCHW = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OP_CONV, OP_UPSAMPLE2, OP_IMPORT, OP_EXPORT, OP_SPLITK, OP_HEAD, OP_INSTNORM, OP_UPSAMPLE2_NEAREST, OP_COPY, OP_POINTWISE_NCHW, OP_POINTWISE_UP = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 ACT_NONE, ACT_LRELU, ACT_ELU = 0, 1, 2
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 
@@ -399,6 +399,12 @@ NARROWEST_TILE_BELOW = 0  # below this many 64-channel workgroups use 16-channel
 
 SPLIT_MIN_CHUNKS = 6
 SPLIT_MAX = 16
+# decoder in_conv blocks: projection of the upsampled concat slices at low resolution (Plan.basic_block_upcat, pointwise_up_k).  Built, parity-tested,
+# and OFF: at B = 32 the conv plan takes 28.80 against 28.53 ms with it.  Per 192x256 block the F(4x4) projection phase it removes costs 338 us
+# (783 -> 445 us for conv2: that phase already runs at ~80 % of the matrix rate), pointwise_up_k + the low-resolution 1x1 conv that replace it
+# 270 + 68 us, both HBM-bound (profiles/r05/experiments.md 3b).
+PROJ_LOWRES = False
+PROJ_LOWRES_MIN_TILES = 1536
 PROJ_CHUNK_WEIGHT = 0.5  # a 1x1 (projection) chunk in units of a 3x3 chunk when the split-K factor is chosen (1.0 / 0.5 / 0.25 measured: B=1 2.353 / 2.330 / 2.343 ms, B=4 5.135 / 5.099 / 5.110)
 
 
@@ -595,6 +601,29 @@ class Plan:
         self._arr = None
         return out
 
+    def pointwise_up(self, x: View, conv: nn.Conv2d, low: View, out: View):
+        """out = conv1x1(x) + upsample2(low) (IDH_OP_POINTWISE_UP, csrc/conv.hip pointwise_up_k)."""
+        if conv.kernel_size[0] != 1 or conv.in_channels != x.C or conv.out_channels != out.C or low.C != out.C or (2 * low.H, 2 * low.W) != (x.H, x.W):
+            raise _lib.IdhError("pointwise_up: a 1x1 conv of x plus the x2 upsampling of a half-resolution map with the output's channels")
+        op = Op()
+        op.kind, op.N = OP_POINTWISE_UP, x.N
+        w = packed_weight(conv)
+        self.keep.append(w)
+        s = op.src[0]
+        s.in_, s.w, s.cs, s.H, s.W, s.Cin, s.ks, s.stride = x.ptr, w.data_ptr(), x.cs, x.H, x.W, x.C, 1, 1
+        l = op.src[1]
+        l.in_, l.cs, l.H, l.W, l.Cin = low.ptr, low.cs, low.H, low.W, low.C
+        if conv.bias is not None:
+            b = conv.bias.detach().contiguous()
+            self.keep.append(b)
+            op.bias = b.data_ptr()
+        op.out, op.out_cs, op.Ho, op.Wo, op.Cout = out.ptr, out.cs, out.H, out.W, out.C
+        self.flops += 2 * x.N * x.H * x.W * conv.out_channels * conv.in_channels
+        self.ops.append(op)
+        self.meta.append({"reads": [_region(x), _region(low)], "writes": [_region(out)]})
+        self._arr = None
+        return out
+
     def instance_norm(self, x: View, out: Optional[View], act=ACT_NONE, slope=0.2):
         """nn.InstanceNorm2d(C) (no affine, eps 1e-5) optionally followed by LeakyReLU.  ``out=None``: statistics only —
         returns the (N, 2, C) mean / rstd tensor for a consumer conv that normalises on load (``conv(..., norm=...)``)."""
@@ -727,6 +756,54 @@ class Plan:
         else:
             self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, x2=x, conv2=blk.downsample[0])
         self.release(h)  # the block's intermediate dies with conv2
+        return out
+
+    def basic_block_upcat(self, cat: View, lows: List[View], blk) -> Optional[View]:
+        """BasicBlock on cat = [right | up(lows[0]) | up(lows[1])...] (the UNet++ decoders' in_conv, networks.py:52-77) with the projection
+        branch split by linearity: a 1x1 conv commutes with bilinear upsampling (its weights sum to one, so the bias may sit on either side),
+        ``downsample(cat) = W_a right + up(W_b lo + W_c lo2 + b)``.  Two thirds of the projection run at a quarter of the pixels
+        (one 1x1 conv on the low-resolution maps), ``pointwise_up_k`` adds the right slice's share, and conv2 takes the sum as an ordinary
+        residual - the F(4x4) kernel's plain + residual instance instead of its projection phase over 3 x planes channels.  Same function as
+        ``basic_block(cat, blk)`` up to fp32 rounding.  Returns None (caller falls back) where it does not apply: small grids (the extra
+        launches cost more than the projection phase there), widths the pointwise kernel does not have."""
+        ds = blk.downsample[0] if blk.downsample is not None else None
+        planes = blk.conv1.out_channels
+        c = planes
+        if (not PROJ_LOWRES or self.math != "fp32" or ds is None or ds.kernel_size[0] != 1 or ds.stride[0] != 1 or planes not in (64, 128) or
+                not 1 <= len(lows) <= 2 or cat.C != c * (1 + len(lows)) or any(l.C != c or (2 * l.H, 2 * l.W) != (cat.H, cat.W) for l in lows)):
+            return None
+        if cat.N * (-(-cat.H // 8)) * (-(-cat.W // 32)) * (planes // 64) < PROJ_LOWRES_MIN_TILES:
+            return None
+        key = (ds.weight.data_ptr(), _lib.param_version(ds.weight), None if ds.bias is None else _lib.param_version(ds.bias), str(ds.weight.device))
+        parts = getattr(ds, "_idh_proj_parts", None)
+        if parts is None or parts[0] != key:
+            with torch.no_grad():
+                mods = []
+                for i in range(1 + len(lows)):
+                    m = nn.Conv2d(c, planes, 1, bias=(i == 1 and ds.bias is not None)).to(ds.weight.device)
+                    m.weight.copy_(ds.weight[:, i * c:(i + 1) * c])
+                    if m.bias is not None:
+                        m.bias.copy_(ds.bias)
+                    m.requires_grad_(False)
+                    mods.append(m)
+            parts = (key, mods)
+            ds._idh_proj_parts = parts
+        wa, wb = parts[1][0], parts[1][1]
+        wc = parts[1][2] if len(lows) == 2 else None
+        plo = self.buffer(cat.N, lows[0].H, lows[0].W, planes)
+        if wc is None:
+            self.conv(lows[0], wb, plo)
+        else:
+            self.conv(lows[0], wb, plo, x2=lows[1], conv2=wc)
+        r = self.buffer(cat.N, cat.H, cat.W, planes)
+        self.pointwise_up(cat.slice(0, c), wa, plo, r)
+        h = self.buffer(cat.N, cat.H, cat.W, planes)
+        self.conv(cat, blk.conv1, h, act=ACT_LRELU, slope=0.2)
+        out = self.buffer(cat.N, cat.H, cat.W, planes)
+        self.conv(h, blk.conv2, out, act=ACT_LRELU, slope=0.2, res=r)
+        self.release(h)
+        self.release(r)
+        self.release(plo)
         return out
 
     # scheduling ----------------------------------------------------------------------
@@ -891,7 +968,7 @@ def build_flags() -> tuple:
     next call instead of silently replaying a plan built under the old setting)."""
     return (WINO_GROUP, FUSE_UPSAMPLE, FUSED_UP_ROWS, MERGE_LEVELS, FUSE_HEAD_NORM, FUSE_HEAD_IMPORT, NARROW_TILE_BELOW, NARROWEST_TILE_BELOW, SPLIT_MIN_CHUNKS,
             SPLIT_MAX, SPLIT_MIN_BLOCKS, WINOGRAD, WINO_MIN_TILES, WINO_MIN_FILL, WINOGRAD4, WINOGRAD4_PROJ, WINO4_MIN_TILES, WINO4_MIN_FILL, BUFFER_REUSE, REUSE_MIN_BYTES, DEFAULT_MATH,
-            S2_FIRST, S2_FIRST_MIN_BLOCKS)
+            S2_FIRST, S2_FIRST_MIN_BLOCKS, PROJ_CHUNK_WEIGHT, PROJ_LOWRES, PROJ_LOWRES_MIN_TILES)
 
 
 def _plan_cache(module: nn.Module) -> PlanCache:
@@ -1024,13 +1101,17 @@ def build_decoder(p: Plan, dec, feats: List[View]):
                 if (lo.H * 2, lo.W * 2) != (xi.H, xi.W):
                     raise _lib.IdhError("decoder pyramid levels must differ by exactly x2")
                 p.upsample2(lo, cat.slice(cout, cout))
-                p.release(lo)  # (liveness reuse: these temporaries have no reader after this point)
+                lows = [lo]
                 if has_up:
                     lo2 = p.basic_block(outputs[-1], dec.convs[f"up_conv_{i + 1}{j}"])
                     p.upsample2(lo2, cat.slice(2 * cout, cout))
-                    p.release(lo2)
-            y0 = p.basic_block(cat, seq[0])
+                    lows.append(lo2)
+            y0 = p.basic_block_upcat(cat, lows, seq[0]) if isinstance(cat, View) else None
+            if y0 is None:
+                y0 = p.basic_block(cat, seq[0])
             if isinstance(cat, View):
+                for l in lows:
+                    p.release(l)  # (liveness reuse: these temporaries have no reader after this point)
                 p.release(cat)
             y = p.basic_block(y0, seq.conv_0)
             p.release(y0)

@@ -36,6 +36,12 @@ enum {
     IDH_OP_POINTWISE_NCHW = 10, /* 1x1 conv 64 -> 128 read straight from a dense (N,64,H,W) tensor into an NHWC slice: the first
                                    layer of the matching-encoder head (networks.py:279) without a layout-import pass;
                                    src[0].w = idh_pack_conv_weight(128, 64, 1); other widths: IDH_EUNSUPPORTED */
+    IDH_OP_POINTWISE_UP = 11, /* out = W . x (+ bias) + up2(low): a 1x1 conv of an NHWC tensor plus the x2 bilinear upsampling (IDH_OP_UPSAMPLE2's
+                                 expression) of a half-resolution NHWC tensor of Cout channels - the projection branch of the decoder blocks on
+                                 cat(right, up(lo), up(lo2)) (networks.py:52-77, layers.py:86-92), whose upsampled two thirds are projected at low
+                                 resolution because a 1x1 conv commutes with bilinear upsampling.  src[0] = x (N,H,W,Cin), w =
+                                 idh_pack_conv_weight(Cout, Cin, 1); src[1].in / .cs / .H / .W = the (N,H/2,W/2,Cout) map; Cin == Cout in {64, 128},
+                                 H and W even; other shapes: IDH_EUNSUPPORTED */
     IDH_OP_INSTNORM = 7     /* nn.InstanceNorm2d (no affine, eps 1e-5) [+ LeakyReLU] on NHWC; matching-encoder
                                head networks.py:279-283.  ws: N*(ceil(HW/1024)+1)*2*C floats (chunk partials + mean/rstd);
                                out == NULL: statistics only — float[N][2][C] at ws + N*ceil(HW/1024)*2*C, for a

@@ -258,6 +258,67 @@ def test_upsample2_matches_interpolate_on_strided_slices(shape):
     assert bool((got[..., :C] == 7.0).all()) and bool((got[..., 2 * C:] == 7.0).all())
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 10, 14), (1, 128, 6, 18), (3, 64, 32, 48)])
+def test_pointwise_up_matches_conv1x1_plus_interpolate(shape):
+    """IDH_OP_POINTWISE_UP (pointwise_up_k): out = conv1x1(x) + F.interpolate(low, x2, bilinear, align_corners=False), x a channel slice of a
+    wider concat buffer, sizes that leave a ragged last 64-pixel tile; against fp64 torch."""
+    import torch.nn.functional as F
+    from torch import nn
+    from implicit_depth_amd import nhwc
+
+    N, C, Hl, Wl = shape
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(C + Hl)
+    conv = nn.Conv2d(C, C, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.1)
+        conv.bias.copy_(torch.randn(C, generator=g))
+    conv.to(dev)
+    p = nhwc.Plan(dev)
+    cat = p.buffer(N, 2 * Hl, 2 * Wl, 3 * C)
+    low = p.buffer(N, Hl, Wl, C)
+    out = p.buffer(N, 2 * Hl, 2 * Wl, C)
+    xt = torch.randn(N, 2 * Hl, 2 * Wl, 3 * C, generator=g).to(dev)
+    lt = torch.randn(N, Hl, Wl, C, generator=g).to(dev)
+    cat.dense().copy_(xt)
+    low.dense().copy_(lt)
+    p.pointwise_up(cat.slice(0, C), conv, low, out)
+    p.schedule()
+    p.run()
+    ref = F.conv2d(xt[..., :C].permute(0, 3, 1, 2).double(), conv.weight.double(), conv.bias.double()) + \
+        F.interpolate(lt.permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=False)
+    assert rel_err(out.dense().permute(0, 3, 1, 2).cpu(), ref.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_decoder_low_resolution_projection_matches_the_fused_projection(batch):
+    """nhwc.PROJ_LOWRES: the in_conv blocks of the UNet++ decoders with the projection of the upsampled concat slices evaluated at low resolution
+    (Plan.basic_block_upcat: W cat = W_a right + up(W_b lo + W_c lo2), conv2 + residual) - forced at every size here - against the default plan
+    (projection fused into conv2) and, through it, the reference goldens; the plan must really hold the pointwise-up ops."""
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd import nhwc
+
+    dec = net.BDDecoderPP([24, 64, 128, 256, 384])
+    syn.fill_state_dict(dec, seed=21)
+    dec.cuda()
+    feats = [t.cuda() for t in syn.encoder_pyramid(batch, 256, 384, seed=5, channels=(24, 64, 128, 256, 384))]
+    old = nhwc.PROJ_LOWRES, nhwc.PROJ_LOWRES_MIN_TILES
+    try:
+        nhwc.PROJ_LOWRES = False
+        dec.__dict__.pop("_idh_plans", None)
+        ref = {k: v.clone() for k, v in dec(feats).items()}
+        nhwc.PROJ_LOWRES, nhwc.PROJ_LOWRES_MIN_TILES = True, 0
+        dec.__dict__.pop("_idh_plans", None)
+        got = {k: v.clone() for k, v in dec(feats).items()}
+        plan = next(iter(dec.__dict__["_idh_plans"].values()))[0]
+        assert sum(1 for op in plan.ops if op.kind == nhwc.OP_POINTWISE_UP) >= 4
+    finally:
+        nhwc.PROJ_LOWRES, nhwc.PROJ_LOWRES_MIN_TILES = old
+        dec.__dict__.pop("_idh_plans", None)
+    for k in ref:
+        assert rel_err(got[k].cpu(), ref[k].cpu()) < 2e-5, k
+
+
 def test_fused_upsample_concat_is_bit_identical_to_materialised():
     """nhwc.FUSE_UPSAMPLE: the decoder's x2 bilinear upsampling + concat interpolated inside the consumer conv's halo
     loader (idh_conv_src.up_*) instead of upsample2_k writing a concat buffer — same blend expression, so the outputs

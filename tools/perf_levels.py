@@ -8,6 +8,8 @@ from bench import HotPathWorkload
 import argparse
 a = argparse.Namespace(batch=int(sys.argv[1]) if len(sys.argv) > 1 else 4, views=7, planes=64, height=384, width=512, volume="mlp")
 if os.environ.get("WINO_MIN_TILES"): nhwc.WINO_MIN_TILES = int(os.environ["WINO_MIN_TILES"])  # 0 < n: Winograd threshold; huge = off
+if os.environ.get("IDH_PROJ_LOWRES"): nhwc.PROJ_LOWRES = bool(int(os.environ["IDH_PROJ_LOWRES"]))
+if os.environ.get("IDH_PROJ_LOWRES_MIN"): nhwc.PROJ_LOWRES_MIN_TILES = int(os.environ["IDH_PROJ_LOWRES_MIN"])
 if os.environ.get("IDH_PROJ_W"): nhwc.PROJ_CHUNK_WEIGHT = float(os.environ["IDH_PROJ_W"])
 if len(sys.argv) > 2: nhwc.NARROW_TILE_BELOW = int(sys.argv[2])  # narrow (32-channel) tiles below this many workgroups
 if len(sys.argv) > 5: nhwc.SPLIT_MIN_CHUNKS = int(sys.argv[5])
