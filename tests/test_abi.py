@@ -36,7 +36,7 @@ def test_error_strings_and_host_only_entry_points():
     from implicit_depth_amd import _lib
 
     L = _lib.lib()
-    assert L.idh_version() >= 103
+    assert L.idh_version() >= 104
     assert L.idh_error_string(0) == b"ok"
     assert b"workspace" in L.idh_error_string(-4)
     # argument validation happens before any launch: safe without a GPU
