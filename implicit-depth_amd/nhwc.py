@@ -228,7 +228,8 @@ BUFFER_REUSE = True
 REUSE_MIN_BYTES = 64 << 20
 WINOGRAD4 = True
 WINOGRAD4_PROJ = True  # ... also for the blocks with a fused 1x1 projection (conv3x3_wino4_k<true>)
-WINO4_MIN_TILES = 384
+WINO4_MIN_TILES = 768  # (re-swept late in round 5, tools/perf_levels.py: 384 / 768 -> conv plan 8.73 / 8.64 ms at B = 8, 12.88 / 12.67 at B = 12, equal at 4, 16, 24, 32: a
+# level of exactly 384 tile groups - 0.75 of a round of the 512 resident workgroups - runs no faster than the grouped F(2x2) launch of the level)
 WINO4_MIN_FILL = 0.85
 
 

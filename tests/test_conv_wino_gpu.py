@@ -167,7 +167,7 @@ def test_default_plan_uses_wino_at_bench_batch():
     from implicit_depth_amd import nhwc
 
     conv, proj = nn.Conv2d(64, 64, 3, 1, 1).cuda(), nn.Conv2d(32, 64, 1).cuda()
-    for B, H, W, want, want_proj in ((8, 96, 128, nhwc.TILE_WINO4, nhwc.TILE_WINO4), (2, 96, 128, nhwc.TILE_WINO, nhwc.TILE_WINO), (1, 24, 32, None, None)):
+    for B, H, W, want, want_proj in ((16, 96, 128, nhwc.TILE_WINO4, nhwc.TILE_WINO4), (2, 96, 128, nhwc.TILE_WINO, nhwc.TILE_WINO), (1, 24, 32, None, None)):
         x, x2 = torch.randn(B, H, W, 64, device="cuda"), torch.randn(B, H, W, 32, device="cuda")
         p = nhwc.Plan(x.device)
         p.conv(nhwc.View(x, 0, 64), conv, p.buffer(B, H, W, 64))

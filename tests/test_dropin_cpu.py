@@ -170,13 +170,14 @@ def test_winograd_kernel_selection_rules():
     c64, c192, c16 = nn.Conv2d(64, 64, 3, 1, 1), nn.Conv2d(192, 64, 3, 1, 1), nn.Conv2d(16, 64, 3, 1, 1)
     proj, s2, c32 = nn.Conv2d(32, 64, 1), nn.Conv2d(64, 64, 3, 2, 1), nn.Conv2d(64, 32, 3, 1, 1)
     Z, L, E = nhwc.PAD_ZEROS, nhwc.ACT_LRELU, 2
-    assert nhwc.WINO4_MIN_TILES == 384 and nhwc.WINOGRAD4
-    # bench batch: every level down to 24x32 (32 * 3 * 1 * 4 = 384 tiles at 256 channels)
+    assert nhwc.WINO4_MIN_TILES == 768 and nhwc.WINOGRAD4
+    # bench batch: every level down to 48x64 (32 * 6 * 2 * 2 = 768 tiles at 128 channels); the 24x32 level (384 tile groups) stays with the grouped F(2x2) launch
     assert nhwc.wino4_eligible([(V(), c64)], 64, 32, 192, 256, Z, L)
     assert nhwc.wino4_eligible([(V(), c192)], 64, 32, 96, 128, Z, nhwc.ACT_NONE)
-    assert nhwc.wino4_eligible([(V(), nn.Conv2d(256, 256, 3, 1, 1))], 256, 32, 24, 32, Z, L)
-    # tile count: B = 8 @96x128 has 8 * 12 * 4 = 384, B = 4 has 192; one frame never qualifies
-    assert nhwc.wino4_eligible([(V(), c64)], 64, 8, 96, 128, Z, L) and not nhwc.wino4_eligible([(V(), c64)], 64, 4, 96, 128, Z, L)
+    assert nhwc.wino4_eligible([(V(), nn.Conv2d(128, 128, 3, 1, 1))], 128, 32, 48, 64, Z, L)
+    assert not nhwc.wino4_eligible([(V(), nn.Conv2d(256, 256, 3, 1, 1))], 256, 32, 24, 32, Z, L)
+    # tile count: B = 16 @96x128 has 16 * 12 * 4 = 768, B = 8 has 384; one frame never qualifies
+    assert nhwc.wino4_eligible([(V(), c64)], 64, 16, 96, 128, Z, L) and not nhwc.wino4_eligible([(V(), c64)], 64, 8, 96, 128, Z, L)
     assert not nhwc.wino4_eligible([(V(), c64)], 64, 1, 192, 256, Z, L)
     # shape family
     assert nhwc.wino4_eligible([(V(), c64), (V(), proj)], 64, 32, 192, 256, Z, L), "fused 1x1 projection: conv3x3_wino4_k<true>"

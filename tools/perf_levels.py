@@ -7,6 +7,7 @@ from implicit_depth_amd import nhwc, _lib
 from bench import HotPathWorkload
 import argparse
 a = argparse.Namespace(batch=int(sys.argv[1]) if len(sys.argv) > 1 else 4, views=7, planes=64, height=384, width=512, volume="mlp")
+if os.environ.get("WINO4_MIN_TILES"): nhwc.WINO4_MIN_TILES = int(os.environ["WINO4_MIN_TILES"])
 if os.environ.get("WINO_MIN_TILES"): nhwc.WINO_MIN_TILES = int(os.environ["WINO_MIN_TILES"])  # 0 < n: Winograd threshold; huge = off
 if os.environ.get("IDH_PROJ_LOWRES"): nhwc.PROJ_LOWRES = bool(int(os.environ["IDH_PROJ_LOWRES"]))
 if os.environ.get("IDH_PROJ_LOWRES_MIN"): nhwc.PROJ_LOWRES_MIN_TILES = int(os.environ["IDH_PROJ_LOWRES_MIN"])
