@@ -1557,7 +1557,7 @@ int level_kind(const PreparedConv &pc) {
 
 int check_upsample(const idh_op &op) {
     const idh_conv_src &s = op.src[0];
-    if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0 || s.H <= 0 || s.W <= 0) return IDH_EINVAL;
+    if (!s.in || !op.out || (s.Cin & 3) || (s.cs & 3) || (op.out_cs & 3) || op.N <= 0 || s.H <= 0 || s.W <= 0 || s.Cin <= 0) return IDH_EINVAL;
     if ((long long)op.N * s.H * s.W * (s.Cin >> 2) >= (1ll << 31)) return IDH_EUNSUPPORTED;  // (upsample2_body: 32-bit quad index)
     return IDH_OK;
 }
