@@ -960,11 +960,9 @@ __global__ __launch_bounds__(256) void copy_nhwc_k(const float *__restrict__ in,
 }
 
 // (N,C,HW) dense -> NHWC slice with channel stride out_cs; LDS tile keeps both sides coalesced
-__global__ __launch_bounds__(256) void import_nchw_k(const float *__restrict__ src, float *__restrict__ dst, int C,
-                                                     int HW, int out_cs) {
-    __shared__ float tile[32][65];
-    const int img = blockIdx.z;
-    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
+__device__ __forceinline__ void import_nchw_body(const float *__restrict__ src, float *__restrict__ dst, int C, int HW, int out_cs, int bx, int by, int img,
+                                                 float (&tile)[32][65]) {
+    const int p0 = bx * 64, c0 = by * 32;
     const float *s = src + (size_t)img * C * HW;
     float *d = dst + (size_t)img * HW * out_cs;
     for (int i = threadIdx.x; i < 64 * 32; i += 256) {
@@ -976,6 +974,32 @@ __global__ __launch_bounds__(256) void import_nchw_k(const float *__restrict__ s
         const int c = i & 31, p = i >> 5;
         if (p0 + p < HW && c0 + c < C) d[(size_t)(p0 + p) * out_cs + c0 + c] = tile[c][p];
     }
+}
+
+__global__ __launch_bounds__(256) void import_nchw_k(const float *__restrict__ src, float *__restrict__ dst, int C,
+                                                     int HW, int out_cs) {
+    __shared__ float tile[32][65];
+    import_nchw_body(src, dst, C, HW, out_cs, blockIdx.x, blockIdx.y, blockIdx.z, tile);
+}
+
+// The layout imports of one dependency level (the five maps of the image-encoder pyramid, bd_model.py:218) as ONE grid: at one frame each is a
+// 5-us launch of a few dozen blocks.  Same body, same values.
+constexpr int kMaxImport = 8;
+struct ImportGroupArgs {
+    int n;
+    unsigned start[kMaxImport + 1];
+    struct { const float *src; float *dst; int C, HW, out_cs, nbx, nby; } d[kMaxImport];
+};
+__global__ __launch_bounds__(256) void import_nchw_group_k(const ImportGroupArgs g) {
+    __shared__ float tile[32][65];
+    int idx = 0;
+    for (int i = 1; i < g.n; ++i)
+        if (blockIdx.x >= g.start[i]) idx = i;
+    const auto &m = g.d[idx];
+    const unsigned local = blockIdx.x - g.start[idx];
+    const int bx = (int)(local % (unsigned)m.nbx);
+    const unsigned r = local / (unsigned)m.nbx;
+    import_nchw_body(m.src, m.dst, m.C, m.HW, m.out_cs, bx, (int)(r % (unsigned)m.nby), (int)(r / (unsigned)m.nby), tile);
 }
 
 __global__ __launch_bounds__(256) void export_nchw_k(const float *__restrict__ src, float *__restrict__ dst, int C,
@@ -1696,6 +1720,32 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                 break;
             }
             case IDH_OP_NCHW_TO_NHWC: {
+                // consecutive imports that share a (non-zero) group id are mutually independent (one dependency level): one grid
+                ImportGroupArgs g{};
+                unsigned cursor = 0;
+                int run = 0;
+                for (int j = i; j < n && run < kMaxImport; ++j) {
+                    const idh_op &o = ops[j];
+                    if (o.kind != IDH_OP_NCHW_TO_NHWC || (j > i && (op.group == 0 || o.group != op.group))) break;
+                    const idh_conv_src &os = o.src[0];
+                    if (!os.in || !o.out || o.N <= 0 || o.N > 65535 || os.H <= 0 || os.W <= 0 || os.Cin <= 0) return IDH_EINVAL;
+                    const int HWj = os.H * os.W;
+                    const long long blocks = (long long)idh_cdiv(HWj, 64) * idh_cdiv(os.Cin, 32) * o.N;
+                    if (blocks > kLevelMaxBlocks * 8ll || cursor + blocks >= (1ll << 31)) break;  // a large import keeps its own 3-D grid
+                    g.d[run].src = os.in; g.d[run].dst = o.out; g.d[run].C = os.Cin; g.d[run].HW = HWj; g.d[run].out_cs = o.out_cs;
+                    g.d[run].nbx = idh_cdiv(HWj, 64); g.d[run].nby = idh_cdiv(os.Cin, 32);
+                    g.start[run] = cursor;
+                    cursor += (unsigned)blocks;
+                    ++run;
+                }
+                if (run > 1) {
+                    g.n = run;
+                    g.start[run] = cursor;
+                    IDH_LAUNCH(import_nchw_group_k, dim3(cursor), dim3(256), 0, st, g);
+                    IDH_CHECK_LAUNCH();
+                    i += run - 1;
+                    break;
+                }
                 if (!s.in || !op.out || op.N <= 0 || op.N > 65535) return IDH_EINVAL;
                 const int HW = s.H * s.W;
                 IDH_LAUNCH(import_nchw_k, dim3(idh_cdiv(HW, 64), idh_cdiv(s.Cin, 32), op.N), dim3(256), 0, st, s.in,

@@ -832,6 +832,8 @@ class Plan:
             return (1, 0)
         if MERGE_LEVELS and op.kind == OP_UPSAMPLE2:
             return (2, 0)
+        if MERGE_LEVELS and op.kind == OP_IMPORT:
+            return (2, 1)  # the layout imports of a level: adjacent and under the level's group id -> one import_nchw_group_k grid when they are small
         return (3, 0)
 
     def schedule_segments(self, n_first: int) -> int:
