@@ -69,7 +69,14 @@ def parse(argv=None):
     ap.add_argument("--mlp-math", default="fp32", choices=["fp32", "f16x3"], help="arithmetic of the MLP kernels (feature volume)")
     ap.add_argument("--math", default=None, choices=["fp32", "f16x3"],
                     help="shorthand: sets --conv-math, and --mlp-math f16x3 when f16x3")
-    ap.add_argument("--no-split-line", action="store_true", help="skip the secondary split-precision measurement")
+    ap.add_argument("--split-line", action="store_true",
+                    help="also time the opt-in split-precision (f16x3) kernels on the same inputs -> the `split_precision` object (frozen code path, "
+                         "never `value`; off by default since round 6)")
+    ap.add_argument("--no-split-line", action="store_true", help=argparse.SUPPRESS)  # round <= 5 spelling of the default
+    ap.add_argument("--no-process-group", action="store_true",
+                    help="--gpus 1 without a launcher: do NOT create the 1-rank RCCL group (the default creates it so that the N = 1 record "
+                         "exercises ncclAllGather too)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the `parity` object (frames of the timed batch re-run one at a time)")
     ap.add_argument("--no-extras", action="store_true", help="skip the warp_match / temporal objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -293,13 +300,43 @@ class HotPathWorkload:
     def frames_per_step(self):
         return self.B
 
-    def _forward(self, **kw):
-        d = self.d
+    def _forward(self, frames=None, **kw):
+        """``frames``: a slice of the batch (the `parity` object re-runs single frames through the same modules)"""
+        d, pyr, rd, l1 = self.d, self.pyr, self.rd, self.l1
+        if frames is not None:
+            d = {k: (v[frames] if v.shape[0] == self.B and v.dim() > 1 and k not in ("min_depth", "max_depth") else v) for k, v in d.items()}
+            pyr, rd, l1 = [t[frames] for t in pyr], rd[frames], (l1[frames] if l1 is not None else None)
         if self.head:
-            return self.model(None, None, self.pyr, d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"], rendered_depth=self.rd,
-                              matching_layer1=self.l1, **kw)
-        return self.model(d["cur_feats"], d["src_feats"], self.pyr, d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
-                          rendered_depth=self.rd, **kw)
+            return self.model(None, None, pyr, d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"], rendered_depth=rd,
+                              matching_layer1=l1, return_mask=True, **kw)  # return_mask=True: the reference's eval call, test_bd.py:200-208
+        return self.model(d["cur_feats"], d["src_feats"], pyr, d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"],
+                          rendered_depth=rd, return_mask=True, **kw)
+
+    def parity(self):
+        """Numerical evidence for the TIMED plan (its kernel mix — F(4x4) / F(2x2) / direct by tile counts — and its buffer aliasing exist only at
+        this batch size): frames 0, B/2 and B-1 of the timed output against the same frames run ONE AT A TIME through the same modules (a
+        one-frame plan: no F(4x4) layer, no recycled buffer, other split-K factors; the one-frame plan is what tests/test_bdmodel_gpu.py pins to the
+        reference's full-size goldens).  Scale-relative max error of the logits (bar: 1e-4, BASELINE.json), mismatch rates of the discrete
+        outputs (arg-max depth, overall mask)."""
+        from implicit_depth_amd import nhwc
+
+        big = {k: v.clone() for k, v in self.out.items() if torch.is_tensor(v)}
+        ops = [op for op in next(iter(self.model._plans.values()))["plan"].ops if op.kind == nhwc.OP_CONV]
+        plan = next(iter(self.model._plans.values()))["plan"]
+        res = {"frames": sorted({0, self.B // 2, self.B - 1}), "tolerance": 1e-4,
+               "timed_plan": {"convs": len(ops), "wino4": sum(op.tile_m == nhwc.TILE_WINO4 for op in ops), "wino2": sum(op.tile_m == nhwc.TILE_WINO for op in ops),
+                              "recycled_buffers": int(getattr(plan, "recycled", 0))}}
+        rel, low, msk = [], [], []
+        for b in res["frames"]:
+            one = self._forward(frames=slice(b, b + 1))
+            ref = one["pred_0"]
+            rel.append(float((big["pred_0"][b:b + 1] - ref).abs().max() / ref.abs().max()))
+            low.append(float(((big["lowest_cost_bhw"][b:b + 1] - one["lowest_cost_bhw"]).abs() > 1e-5).float().mean()))
+            if one.get("overall_mask_bhw") is not None:
+                msk.append(float((big["overall_mask_bhw"][b:b + 1] != one["overall_mask_bhw"]).float().mean()))
+        res.update(frame0_vs_b1_rel=rel[0], worst_frame_vs_b1_rel=max(rel), lowest_mismatch_rate=max(low), mask_mismatch_rate=max(msk) if msk else None,
+                   ok=bool(max(rel) < 1e-4 and max(low) < 5e-3 and (not msk or max(msk) < 2e-3)))
+        return res
 
     def step(self, ev=None):
         if ev is not None:
@@ -636,33 +673,86 @@ def _median(xs):
 
 
 # ------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher: start the N ranks ourselves — one process per GPU under
+    torch.distributed.run, the reference's process-per-GPU model (train.py:124,135) — and pass rank 0's JSON line through as the
+    only stdout line; everything else the ranks print goes to stderr.  Refuses (rc != 0) only when the box has fewer than N GPUs
+    (unless --ranks-on-device puts every rank on one device, the gloo test rig)."""
+    import subprocess
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.ranks_on_device is None and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this box exposes {have} GPU(s) to torch; one process per GPU needs {args.gpus}")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or args.gpus) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench.py] self-launch:", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if line is None and t.startswith("{") and t.endswith("}") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        raise SystemExit(f"bench.py self-launch of {args.gpus} ranks failed (rc {rc}, {'no JSON line' if line is None else 'JSON line seen'})")
+    rec = json.loads(line)
+    rec["launcher"] = "self (python -m torch.distributed.run, started by bench.py)"
+    print(json.dumps(rec), flush=True)
+
+
 def main():
     args = parse()
+    under_launcher = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and not under_launcher:
+        return _self_launch(args)
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if args.ranks_on_device is not None and args.dist_backend == "nccl" and world > 1:
         raise SystemExit("--ranks-on-device with more than one rank needs --dist-backend gloo (RCCL refuses duplicate devices)")
     dev_index = local_rank if args.ranks_on_device is None else args.ranks_on_device
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: cuda:{dev_index} does not exist ({torch.cuda.device_count()} GPU(s) visible)")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     # strong scaling: the global batch is fixed (32 ScanNet-shaped tuples) and sharded by frame
     global_batch = args.batch
     counts = shard_counts(global_batch, world)
     args.batch = counts[rank]  # frames of THIS rank
-    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun: exercise RCCL even at N=1
+    # A process group always exists (a 1-rank RCCL group at N = 1 without a launcher: the N = 1 record then exercises the path's one
+    # collective, ncclAllGather, too) unless --no-process-group asks for the bare single process.
+    use_dist = under_launcher or not args.no_process_group
+    dist_error = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")  # host-side collectives (tensors are staged through the CPU below)
+        if not under_launcher:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        try:
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)  # host-side collectives (tensors are staged through the CPU below)
+        except Exception as e:  # a lone process can still be measured; N > 1 cannot
+            if world > 1:
+                raise
+            use_dist, dist_error = False, f"{type(e).__name__}: {e}"
     host_coll = use_dist and args.dist_backend == "gloo"
 
     wl = WORKLOADS[args.workload](args, device, rank)
@@ -697,12 +787,16 @@ def main():
 
     elapsed, per_step = timed(wl)
     kernel_ms = sum(per_step) / max(len(per_step), 1)
+    parity = None
+    if wl.name == "hot_path" and not args.no_parity and rank == 0:
+        with torch.inference_mode():
+            parity = wl.parity()
     frames_per_step_total = sum(counts)
 
     # Secondary line (same run, same inputs and weights): the hot path with the fp32-equivalent
     # split-precision kernels (f16x3 convs + MLPs).  `value` above stays the fp32-MFMA path.
     split = None
-    if wl.name == "hot_path" and args.conv_math == "fp32" and args.mlp_math == "fp32" and not args.no_split_line:
+    if wl.name == "hot_path" and args.conv_math == "fp32" and args.mlp_math == "fp32" and args.split_line:
         a2 = copy.copy(args)
         a2.conv_math, a2.mlp_math = "f16x3", "f16x3"
         wl2 = HotPathWorkload(a2, device, rank)
@@ -720,7 +814,27 @@ def main():
     from implicit_depth_amd.dist import all_gather_metrics
 
     local_rows = wl.metrics().float().contiguous()
-    m = all_gather_metrics(local_rows.cpu() if host_coll else local_rows, counts=counts)
+    send = local_rows.cpu() if host_coll else local_rows
+    m = all_gather_metrics(send, counts=counts)
+    # evidence of the collective: wall time of the metric all-gather (median of 20 after the first, which carries RCCL's lazy
+    # communicator setup), the world size the process group itself reports, and one device record per rank gathered through it
+    allgather_us = first_allgather_us = ranks_reported = devices = None
+    if use_dist:
+        def one_gather():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            all_gather_metrics(send, counts=counts)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e6
+
+        first_allgather_us = one_gather()
+        allgather_us = _median([one_gather() for _ in range(20)])
+        ranks_reported = dist.get_world_size()
+        pr = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "device": str(device), "name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None),
+                "uuid": str(getattr(pr, "uuid", "")) or None, "frames": counts[rank], "pid": os.getpid()}
+        devices = [None] * ranks_reported
+        dist.all_gather_object(devices, mine)
     frames_total = frames_per_step_total * args.steps
     if args.rank_report:
         os.makedirs(args.rank_report, exist_ok=True)
@@ -789,8 +903,19 @@ def main():
             "config": dict(wl.config(), global_batch=frames_per_step_total),
             "roofline": roof,
             "gathered_metric_rows": int(m.shape[0]),
+            # the process group behind the barriers / MAX all-reduce / metric all-gather of this run ("nccl" = RCCL)
             "dist_backend": (args.dist_backend if use_dist else None),
+            "ranks": ranks_reported,
+            "devices": devices,
+            "allgather_us": allgather_us,
+            "allgather_first_call_us": first_allgather_us,
+            "allgather_payload_bytes_per_rank": int(local_rows.numel() * 4),
+            "launcher": ("torch.distributed.run" if under_launcher else "none (single process" + (", 1-rank process group)" if use_dist else ")")),
         }
+        if dist_error is not None:
+            out["dist_init_error"] = dist_error
+        if parity is not None:
+            out["parity"] = parity
         if args.ranks_on_device is not None:
             out["note_ranks_on_device"] = (f"all {world} ranks ran on cuda:{args.ranks_on_device} (code-path exercise of the N > 1 branch on a 1-GPU box; "
                                            "the rate is NOT a multi-GPU measurement)")

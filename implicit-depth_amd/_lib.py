@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IDH_LIB") or os.path.join(_HERE, "lib", "libidh.so")
 
 _lib = None
-MIN_ABI_VERSION = 104
+MIN_ABI_VERSION = 105
 
 f32p = C.c_void_p  # device pointers travel as integers
 

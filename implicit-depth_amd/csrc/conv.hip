@@ -1215,33 +1215,54 @@ __global__ __launch_bounds__(256) void pointwise_head_k(const float *__restrict_
 constexpr int kInChunk = 1024;  // pixels per partial
 
 // blockDim.x = 256, or 1024 when the launch has too few (image, chunk) pairs to fill the chip (one frame: 8 images x 12 chunks): the chunk
-// partition - and with it the workspace layout of the C ABI - stays, a chunk's pixels are spread over four times the threads
+// partition - and with it the workspace layout of the C ABI - stays, a chunk's pixels are spread over four times the threads.
+// The reduction TREE does not depend on the block size: a chunk is always summed as SUB * blockDim.x / (C/4) "rows" (row r takes pixels
+// p0 + r, p0 + r + rows, ...) that are then combined in row order; a 256-thread block of the C >= 64 case carries the four rows a
+// 1024-thread block would give to four threads (SUB = 4), so a frame's statistics are bit-identical whether it is normalised alone
+// (1024 threads) or inside a large batch (256 threads).
+template <int SUB>
 __global__ __launch_bounds__(1024) void instnorm_stats_k(const float *__restrict__ in, int cs, int C, int HW, int nchunks,
                                                          float *__restrict__ part) {  // part[n][chunk][2][C]
-    extern __shared__ float red[];  // blockDim.x * 8 floats
+    extern __shared__ float red[];  // SUB * blockDim.x * 8 floats
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int cq = C >> 2;                 // channel quads
     const int q = threadIdx.x % cq;
     const int prow = threadIdx.x / cq, pstep = (int)blockDim.x / cq;  // host guarantees cq divides 256
+    const int rows = SUB * pstep;
     const int p0 = chunk * kInChunk, p1 = min(HW, p0 + kInChunk);
     // sums of (x - pivot) and (x - pivot)^2 with pivot = the image's first pixel: E[x^2] - mean^2 on the raw values cancels
     // catastrophically for a channel whose |mean| is large against its spread (~(mean/std)^2 * 1e-7 relative; a biased 1x1 conv on
     // ReLU features); shifted by any sample of the distribution the two terms are both of the order of the variance
     const float4 pv = *reinterpret_cast<const float4 *>(in + (size_t)n * HW * cs + 4 * q);
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int p = p0 + prow; p < p1; p += pstep) {
-        const float4 v = *reinterpret_cast<const float4 *>(in + ((size_t)n * HW + p) * cs + 4 * q);
-        const float d0 = v.x - pv.x, d1 = v.y - pv.y, d2 = v.z - pv.z, d3 = v.w - pv.w;
-        s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
-        ss[0] = fmaf(d0, d0, ss[0]); ss[1] = fmaf(d1, d1, ss[1]); ss[2] = fmaf(d2, d2, ss[2]); ss[3] = fmaf(d3, d3, ss[3]);
+    float s[SUB][4], ss[SUB][4];
+#pragma unroll
+    for (int u = 0; u < SUB; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[u][e] = ss[u][e] = 0.f;
+    for (int p = p0 + prow; p < p1; p += rows) {
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) {  // row prow + u * pstep
+            const int pp = p + u * pstep;
+            if (pp < p1) {
+                const float4 v = *reinterpret_cast<const float4 *>(in + ((size_t)n * HW + pp) * cs + 4 * q);
+                const float d0 = v.x - pv.x, d1 = v.y - pv.y, d2 = v.z - pv.z, d3 = v.w - pv.w;
+                s[u][0] += d0; s[u][1] += d1; s[u][2] += d2; s[u][3] += d3;
+                ss[u][0] = fmaf(d0, d0, ss[u][0]); ss[u][1] = fmaf(d1, d1, ss[u][1]); ss[u][2] = fmaf(d2, d2, ss[u][2]); ss[u][3] = fmaf(d3, d3, ss[u][3]);
+            }
+        }
     }
-    float *mine = red + threadIdx.x * 8;
-    for (int e = 0; e < 4; ++e) { mine[e] = s[e]; mine[4 + e] = ss[e]; }
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) {
+        float *mine = red + ((size_t)(prow + u * pstep) * cq + q) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mine[e] = s[u][e]; mine[4 + e] = ss[u][e]; }
+    }
     __syncthreads();
-    if (threadIdx.x < 8 * cq) {  // fixed-order combine over the pstep rows (deterministic), one thread per (channel quad, sum)
-        const int qq = threadIdx.x >> 3, e = threadIdx.x & 7;
+    // fixed-order combine over the rows (deterministic), one thread per (channel quad, sum); 8 * cq may exceed the block (C >= 128 at 256 threads)
+    for (int t = threadIdx.x; t < 8 * cq; t += blockDim.x) {
+        const int qq = t >> 3, e = t & 7;
         float a = 0.f;
-        for (int r = 0; r < pstep; ++r) a += red[(r * cq + qq) * 8 + e];
+        for (int r = 0; r < rows; ++r) a += red[(r * cq + qq) * 8 + e];
         part[((size_t)(n * nchunks + chunk) * 2 + (e >> 2)) * C + 4 * qq + (e & 3)] = a;
     }
 }
@@ -1442,6 +1463,13 @@ int prep_conv(const idh_op &op, PreparedConv &pc) {
         const int rows = op.tile_m == 9 ? 4 : 8;
         const int chunks = a.s[0].cblocks + (a.s[1].in ? a.s[1].cblocks : 0);
         if (a.S > chunks) a.S = chunks;
+        {   // the kernel draws the split boundaries in cost units (9 per 3x3 chunk, 1 per 1x1 chunk, conv3x3_lds_body): more splits than whole
+            // 3x3-chunk costs would leave some of them empty (all-zero partials written and reduced for nothing)
+            const int w1 = (a.s[1].in && a.s[1].ks == 3) ? 9 : 1;
+            const int T = 9 * a.s[0].cblocks + (a.s[1].in ? w1 * a.s[1].cblocks : 0);
+            const int smax = T / 9 > 1 ? T / 9 : 1;
+            if (a.S > smax) a.S = smax;
+        }
         a.NT = op.Cout / (16 * nj);
         pc.nj = nj;
         pc.la = LdsConvArgs{a, (op.Wo + kLT_W - 1) / kLT_W, (op.Ho + rows - 1) / rows};
@@ -1822,9 +1850,13 @@ extern "C" int idh_run_ops(const idh_op *ops, int n, void *stream) {
                     op.N <= 0 || op.N > 65535)
                     return IDH_EINVAL;
                 const int nchunks = idh_cdiv(HW, kInChunk);
+                // C >= 64: the chunk is summed as 1024 / (C/4) rows at either block size (bit-identical statistics at every batch size)
                 const int sthreads = ((long long)nchunks * op.N < 512 && C >= 64) ? 1024 : 256;
-                IDH_LAUNCH(instnorm_stats_k, dim3(nchunks, op.N), dim3(sthreads), sthreads * 8 * sizeof(float), st, s.in, s.cs, C, HW,
-                                   nchunks, op.ws);
+                if (C >= 64 && sthreads == 256)
+                    IDH_LAUNCH(instnorm_stats_k<4>, dim3(nchunks, op.N), dim3(256), 1024 * 8 * sizeof(float), st, s.in, s.cs, C, HW, nchunks, op.ws);
+                else
+                    IDH_LAUNCH(instnorm_stats_k<1>, dim3(nchunks, op.N), dim3(sthreads), sthreads * 8 * sizeof(float), st, s.in, s.cs, C, HW,
+                                       nchunks, op.ws);
                 IDH_CHECK_LAUNCH();
                 float *stats = op.ws + (size_t)op.N * nchunks * 2 * C;
                 IDH_LAUNCH(instnorm_finalize_k, dim3(op.N), dim3(256), 0, st, op.ws, s.in, s.cs, C, HW, nchunks, stats);

@@ -89,6 +89,8 @@ struct BinArgs {
     const float *thr_logits;  // ... and logit(threshold) per bin; null -> the constant thr_logit
     int n_thr;
     const float *sw2;     // F16 kernel: per-row scale of the f16-packed W2 (w2 then points to idh_pack_mlp_weight_f16 output)
+    int feat_unaligned;   // feature rows are not 16-byte aligned (cs % 4 != 0 or an odd base: the reference's [depth | feat | prior] rows
+                          // of 65 / 66 floats, networks.py:106-115, read in place): dword loads instead of one dwordx4
 };
 
 // Persistent 512- / 768-thread workgroups (one per CU): W2 (64 KiB) and, when it fits, the feature part
@@ -154,7 +156,11 @@ __global__ __launch_bounds__(bin_threads(F16)) void binary_mlp_k(const BinArgs a
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 Bf[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (cok) Bf[t] = *reinterpret_cast<const f32x4 *>(a.feat + (size_t)mrow[t] * a.cs + 16 * c + 4 * q);
+                if (cok) {
+                    const float *fp = a.feat + (size_t)mrow[t] * a.cs + 16 * c + 4 * q;
+                    if (a.feat_unaligned) Bf[t] = (f32x4){fp[0], fp[1], fp[2], fp[3]};
+                    else Bf[t] = *reinterpret_cast<const f32x4 *>(fp);
+                }
             }
 #pragma unroll
             for (int i = 0; i < kNS; ++i) {
@@ -450,13 +456,16 @@ extern "C" int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, c
                                   const float *prior_bphw, int has_prior, float prior_const, const float *w1f_packed,
                                   const float *w2_packed, const float *vecs6x128, int B, int P, int HW,
                                   float *out_bphw, void *stream) {
-    if (B < 0 || P < 0 || HW <= 0 || Cf <= 0 || (Cf & 3) || (feat_cs & 3) || feat_cs < Cf) return IDH_EINVAL;
+    if (B < 0 || P < 0 || HW <= 0 || Cf <= 0 || (Cf & 3) || feat_cs < Cf) return IDH_EINVAL;
     if (B == 0 || P == 0) return IDH_OK;
     if (!feat_nhwc || !depth_bphw || !w1f_packed || !w2_packed || !vecs6x128 || !out_bphw) return IDH_EINVAL;
+    if (reinterpret_cast<uintptr_t>(feat_nhwc) & 3) return IDH_EINVAL;
     const long long M = (long long)B * HW;
     if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
     BinArgs a{feat_nhwc, depth_bphw, prior_bphw, w1f_packed, w2_packed, vecs6x128, out_bphw,
-              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0, nullptr};
+              (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0, nullptr, 0};
+    // any row stride / any 4-byte-aligned base (ABI 105): rows that are not 16-byte aligned are read with dword loads
+    a.feat_unaligned = ((feat_cs & 3) || (reinterpret_cast<uintptr_t>(feat_nhwc) & 15)) ? 1 : 0;
     return binary_mlp_launch(a, B, stream);
 }
 

@@ -165,9 +165,13 @@ def binary_mlp_forward(net, inputs: List[torch.Tensor], max_scale_only: bool = F
         n_feat = x.shape[-1] - (2 if net.use_prior else 1)
         lead = x.shape[:-1]
         rows = x.reshape(1, -1, 1, x.shape[-1])  # (B=1, H=M, W=1, Cin)
-        feat = rows[..., 1 : 1 + n_feat].contiguous()
         depth = rows[..., 0].reshape(1, 1, -1, 1)
         prior = rows[..., 1 + n_feat].reshape(1, 1, -1, 1) if net.use_prior else None
-        y = occlusion_logits(net, feat, 0, n_feat, depth, prior, scale=s)
+        if mlp_math_of(net) == "fp32":
+            # the reference's [depth | features | prior] rows are read IN PLACE (row stride Cin = 65 / 66 floats, features from column 1:
+            # idh_binary_mlp_fwd takes any stride since ABI 105) - no copy of the 64-channel slice per call (bd_model.py:293-304 makes 8)
+            y = occlusion_logits(net, rows, 1, n_feat, depth, prior, scale=s)
+        else:  # the frozen split-precision kernels keep the 16-byte row alignment
+            y = occlusion_logits(net, rows[..., 1 : 1 + n_feat].contiguous(), 0, n_feat, depth, prior, scale=s)
         outs[f"pred_{s}"] = y.reshape(*lead, 1)
     return outs

@@ -1105,16 +1105,24 @@ def build_decoder(p: Plan, dec, feats: List[View]):
                     raise _lib.IdhError("decoder pyramid levels must differ by exactly x2")
                 p.upsample2(lo, cat.slice(cout, cout))
                 lows = [lo]
+                # (liveness reuse) the half-resolution maps have no reader after their upsampling - unless the low-resolution projection
+                # (basic_block_upcat, PROJ_LOWRES) is going to read them again in in_conv's first block
+                hold_lows = PROJ_LOWRES
+                if not hold_lows:
+                    p.release(lo)
                 if has_up:
                     lo2 = p.basic_block(outputs[-1], dec.convs[f"up_conv_{i + 1}{j}"])
                     p.upsample2(lo2, cat.slice(2 * cout, cout))
                     lows.append(lo2)
+                    if not hold_lows:
+                        p.release(lo2)
             y0 = p.basic_block_upcat(cat, lows, seq[0]) if isinstance(cat, View) else None
             if y0 is None:
                 y0 = p.basic_block(cat, seq[0])
             if isinstance(cat, View):
-                for l in lows:
-                    p.release(l)  # (liveness reuse: these temporaries have no reader after this point)
+                if hold_lows:
+                    for l in lows:
+                        p.release(l)
                 p.release(cat)
             y = p.basic_block(y0, seq.conv_0)
             p.release(y0)

@@ -25,7 +25,9 @@ extern "C" {
 
 enum {
     IDH_OP_CONV = 1,        /* implicit-GEMM conv on fp32 MFMA (layers.py:59-75 convs)       */
-    IDH_OP_UPSAMPLE2 = 2,   /* bilinear x2, align_corners=False (generic_utils.py:94-103)    */
+    IDH_OP_UPSAMPLE2 = 2,   /* bilinear x2, align_corners=False (generic_utils.py:94-103).  32-bit element indices since ABI 104:
+                               N*H*W*C/4 (input channel quads) and the same count of the output must stay below 2^31 - i.e. inputs
+                               under 32 GiB - else IDH_EUNSUPPORTED (no 64-bit-index variant is kept; split the batch) */
     IDH_OP_NCHW_TO_NHWC = 3,/* strided layout import: (N,C,H,W) -> NHWC slice                */
     IDH_OP_NHWC_TO_NCHW = 4,/* strided layout export: NHWC slice -> (N,C,H,W)                */
     IDH_OP_SPLITK_REDUCE = 5,/* sum split-K partials + bias + residual + activation          */

@@ -189,6 +189,47 @@ def test_instance_norm_of_a_channel_with_a_large_mean():
     assert rel_err(out.dense().cpu(), ref.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("C", [16, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("N", [1, 260])
+def test_instance_norm_every_accepted_width_and_block_size(C, N):
+    """IDH_OP_INSTNORM accepts every C with (C/4) | 256: the statistics kernel's combine must cover all 8 * C/4 (quad, sum) slots whatever
+    the block size (round-5 advisor: C >= 256 at 256 threads left slots unwritten).  N = 1 takes the 1024-thread launch (few (image, chunk)
+    pairs), N = 260 the 256-thread one (>= 512 pairs)."""
+    from implicit_depth_amd import nhwc
+
+    H, W = 33, 33  # two chunks of 1024 pixels, the second partial
+    g = torch.Generator(device="cuda").manual_seed(C + N)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g) * torch.linspace(0.5, 3.0, C, device="cuda") + torch.linspace(-2.0, 2.0, C, device="cuda")
+    p = nhwc.Plan(x.device)
+    out = p.buffer(N, H, W, C)
+    out.buf.fill_(float("nan"))
+    p.instance_norm(nhwc.View(x, 0, C), out)
+    p.run()
+    ref = torch.nn.functional.instance_norm(x.permute(0, 3, 1, 2).double()).permute(0, 2, 3, 1)
+    err = ((out.dense().double() - ref).abs().max() / ref.abs().max()).item()  # (NaN if any slot of the statistics was left unwritten)
+    assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("C", [64, 128])
+def test_instance_norm_statistics_do_not_depend_on_the_batch_size(C):
+    """The reduction tree of instnorm_stats_k is fixed (1024 / (C/4) rows per chunk at either block size): frame 0 normalised alone
+    (1024-thread blocks) and inside a 48-image batch (256-thread blocks) are bit-identical."""
+    from implicit_depth_amd import nhwc
+
+    H, W = 96, 128
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(48, H, W, C, device="cuda", generator=g) * 3 + 1
+
+    def run(n):
+        p = nhwc.Plan(x.device)
+        out = p.buffer(n, H, W, C)
+        p.instance_norm(nhwc.View(x[:n].contiguous(), 0, C), out)
+        p.run()
+        return out.dense().clone()
+
+    assert torch.equal(run(1)[0], run(48)[0])
+
+
 @pytest.mark.parametrize("reg", [False, True])
 def test_skip_decoder_golden(reg):
     """SkipDecoder / SkipDecoderRegression (networks_fast.py): ELU convs, nearest x2, concat, 1x1 heads."""

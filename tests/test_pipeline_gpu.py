@@ -254,3 +254,75 @@ def test_bench_n2_branch_on_one_gpu_over_gloo(tmp_path):
     log = os.path.join(root, "gpurun_out", "bench_n2_gloo_one_gpu.json")
     os.makedirs(os.path.dirname(log), exist_ok=True)
     json.dump({"bench_line": out, "ranks": ranks}, open(log, "w"), indent=1)
+
+
+def _bench_line(argv, timeout=900, env=None):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, cwd=root,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), f"stdout must be exactly one JSON line, got {len(lines)}: {r.stdout[:500]}"
+    return json.loads(lines[0]), r.stderr
+
+
+def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT an outer launcher (the driver's command shape): bench.py starts one process per rank itself
+    (torch.distributed.run, 127.0.0.1 rendezvous) and forwards rank 0's JSON line as the only stdout line.  On the 1-GPU box both
+    ranks share cuda:0 over gloo; the line must carry the process group's own evidence: backend, world size, one device record per
+    rank, the all-gather time.  Reference analogue: Lightning's process-per-GPU launch train.py:124,135."""
+    import json
+
+    rep = tmp_path / "ranks"
+    out, err = _bench_line(["--gpus", "2", "--batch", "5", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--ranks-on-device", "0",
+                            "--no-extras", "--no-cpu-baseline", "--no-parity", "--rank-report", str(rep)])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["dist_backend"] == "gloo" and out["config"]["global_batch"] == 5
+    assert out["gathered_metric_rows"] == 5 and out["allgather_us"] > 0 and out["launcher"].startswith("self")
+    assert [d["rank"] for d in out["devices"]] == [0, 1] and [d["frames"] for d in out["devices"]] == [3, 2]
+    assert len({d["pid"] for d in out["devices"]}) == 2, "one PROCESS per rank"
+    ranks = [json.load(open(rep / f"rank{i}.json")) for i in range(2)]
+    assert [r_["frames"] for r_ in ranks] == [[0, 3], [3, 5]] and all(r_["gathered_rows_match_local"] for r_ in ranks)
+    assert "self-launch" in err
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """--gpus N above torch.cuda.device_count() (and no --ranks-on-device): rc != 0 with a clear message, nothing launched"""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, cwd=root)
+    assert r.returncode != 0 and "one process per GPU" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")
+
+
+def test_bench_n1_runs_under_a_one_rank_rccl_group():
+    """The driver's N = 1 command (`python bench.py --gpus 1 ...`, no launcher) creates a 1-rank RCCL group: barriers, the MAX all-reduce
+    and the metric all-gather go through ncclAllGather / ncclAllReduce, and the line says so.  The rate must not depend on the group:
+    within 3 % of the same run with --no-process-group (measured: < 1 %)."""
+    import os
+
+    common = ["--gpus", "1", "--batch", "8", "--steps", "12", "--warmup", "3", "--no-extras", "--no-cpu-baseline"]
+    a, _ = _bench_line(common)
+    assert a["dist_backend"] == "nccl" and a["ranks"] == 1 and len(a["devices"]) == 1 and a["devices"][0]["frames"] == 8, a.get("dist_init_error")
+    assert a["allgather_us"] > 0 and a["gathered_metric_rows"] == 8
+    assert a["parity"]["ok"] and a["parity"]["worst_frame_vs_b1_rel"] < 1e-4, a["parity"]
+    b, _ = _bench_line(common + ["--no-process-group", "--no-parity"])
+    assert b["dist_backend"] is None and b["ranks"] is None
+    ratio = a["value"] / b["value"]
+    print(f"N=1 under a 1-rank RCCL group {a['value']:.1f} frames/s, bare process {b['value']:.1f}: ratio {ratio:.4f}; all-gather {a['allgather_us']:.0f} us")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    import json
+
+    json.dump({"with_group": a, "bare": b, "ratio": ratio}, open(os.path.join(root, "gpurun_out", "bench_n1_rccl_vs_bare.json"), "w"), indent=1)
+    assert 0.97 < ratio < 1.03, ratio
