@@ -101,8 +101,14 @@ _SIGS = {
 }
 
 
+def _all_sigs():
+    from . import net_abi  # (structs of include/idh_net.h live there; imported lazily: net_abi imports this module)
+
+    return {**_SIGS, **net_abi.SIGS}
+
+
 def declared_symbols():
-    return sorted(_SIGS)
+    return sorted(_all_sigs())
 
 
 def lib():
@@ -115,7 +121,7 @@ def lib():
                 "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)."
             )
         h = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
+        for name, (res, args) in _all_sigs().items():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args

@@ -146,3 +146,38 @@ def test_hot_kernels_compile_without_scratch():
     for name in ("conv3x3_wino4_k<true, false>", "conv3x3_wino4_k<false, true>", "conv3x3_wino4_k<false, false>", "fv_mlp_k<7>", "fv_mlp_k<0>"):
         assert name in rows, (name, sorted(rows))
         assert rows[name] == 0, (name, rows[name])
+
+
+def test_network_entry_point_size_queries_run_without_a_gpu():
+    """include/idh_net.h: the *_sizes queries are host-only (plan building + idh_count_launches).  At the bench shapes the UNet++ plan of
+    a 32-frame batch must hold the F(4x4) layers and recycle activation buffers; bad arguments come back as error codes."""
+    import ctypes as C
+
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd import net_abi as na
+    from implicit_depth_amd import networks as net
+
+    L = _lib.lib()
+    keep = []
+    cve = net.CVEncoder(64, [48, 64, 160, 256], [64, 128, 256, 384])
+    dec = net.DepthDecoderPP([24] + cve.num_ch_enc)
+    blocks, heads = na.unetpp_blocks(dec, keep)
+    assert heads is not None and len(blocks) == na.UNETPP_BLOCKS
+    feats = na.tensors([na.nchw(None, 24, 192, 256)] + [na.nhwc(None, c, 96 >> i, 128 >> i) for i, c in enumerate([64, 128, 256, 384])])
+    fouts = na.tensors([na.nhwc(None, c, 192 >> i, 256 >> i) for i, c in enumerate([64, 64, 128, 256])])
+    sz = {}
+    for N in (1, 32):
+        s = na.NetSizes()
+        assert L.idh_unetpp_sizes(blocks, na.UNETPP_BLOCKS, heads, N, feats, fouts, C.byref(s)) == 0
+        sz[N] = s.as_dict()
+    assert sz[1]["wino4"] == 0 and sz[32]["wino4"] >= 60 and sz[32]["recycled"] >= 8 and sz[32]["launches"] > 0 and sz[1]["ops"] == sz[32]["ops"]
+    assert sz[32]["workspace_floats"] > sz[1]["workspace_floats"] > 0 and sz[32]["weight_floats"] > 0
+    s = na.NetSizes()
+    assert L.idh_unetpp_sizes(blocks, 48, heads, 1, feats, fouts, C.byref(s)) == -1  # wrong block count
+    bad = na.tensors([na.nchw(None, 24, 192, 256)] + [na.nhwc(None, c, 96 >> i, 100) for i, c in enumerate([64, 128, 256, 384])])
+    assert L.idh_unetpp_sizes(blocks, na.UNETPP_BLOCKS, heads, 1, bad, fouts, C.byref(s)) == -1  # pyramid levels must halve
+    cb = na.cvencoder_blocks(cve, keep)
+    cost = na.nhwc(None, 64, 96, 128)
+    img = na.tensors([na.nchw(None, c, 96 >> i, 128 >> i) for i, c in enumerate([48, 64, 160, 256])])
+    outs = na.tensors([na.nhwc(None, c, 96 >> i, 128 >> i) for i, c in enumerate([64, 128, 256, 384])])
+    assert L.idh_cvencoder_sizes(cb, 4, 32, C.byref(cost), img, outs, C.byref(s)) == 0 and s.ops == 28 and s.wino4 > 0
