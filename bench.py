@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="hot_path", choices=["hot_path", "warp_match_dot", "temporal"])
+    ap.add_argument("--workload", default="hot_path", choices=["hot_path", "warp_match_dot", "temporal", "fused_forward", "module_swap"])
     ap.add_argument("--batch", type=int, default=32, help="GLOBAL frames per step (BASELINE.json configs[3]: batch_size=32), sharded over the GPUs")
     ap.add_argument("--views", type=int, default=0, help="source views K; 0 = 7 for --volume mlp (reference-native 8-frame tuple = 1 cur + 7 src), 8 for --volume dot (BASELINE.json literal)")
     ap.add_argument("--volume", default="mlp", choices=["mlp", "dot"], help="mlp = FeatureVolumeManager (every shipped BDModel config), dot = CostVolumeManager")
@@ -641,7 +641,143 @@ class TemporalWorkload(HotPathWorkload):
         return torch.stack([o.mean((1, 2, 3)), torch.sigmoid(o).mean((1, 2, 3))], 1)
 
 
-WORKLOADS = {"warp_match_dot": WarpMatchDot, "hot_path": HotPathWorkload, "temporal": TemporalWorkload}
+class _RunOpts:
+    """the fields of the reference's options object that BDModel.forward reads (options.py; implicit_depth.yaml)"""
+    matching_scale = 1
+    min_matching_depth = 0.25
+    max_matching_depth = 5.0
+    use_prior = False
+    bd_edge_regularision = False
+    cv_encoder_type = "multi_scale_encoder"
+
+
+def _standin_bdmodel(K, H, W, D, volume, golden_weights=False):
+    """An object with the attribute tree of the reference's BDModel (bd_model.py:41-141): stand-in backbones (syn.StubImageEncoder /
+    syn.StubResnetStem - the third-party timm / antialiased_cnns networks are not in this image) and the hot-path modules as
+    `dropin.convert` leaves them."""
+    import implicit_depth_amd.synthetic as syn
+    from implicit_depth_amd import networks as net
+    from implicit_depth_amd.cost_volume import CostVolumeManager, FeatureVolumeManager
+
+    m = torch.nn.Module()
+    m.encoder = syn.StubImageEncoder()
+    m.cost_volume = FeatureVolumeManager(H, W, D, num_source_views=K) if volume == "mlp" else CostVolumeManager(H, W, D)
+    stem = syn.StubResnetStem()
+    m.matching_model = net.ResnetMatchingEncoder([stem.conv1, stem.bn1, stem.relu, stem.maxpool, stem.layer1], 16)
+    m.cost_volume_net = net.CVEncoder(D, [48, 64, 160, 256], [64, 128, 256, 384])
+    m.depth_decoder = net.BDDecoderPP([24] + m.cost_volume_net.num_ch_enc)
+    m.binary_mlp = net.BinaryMLPNetwork(m.depth_decoder.num_ch_dec, mlp_size=128, use_prior=False)
+    m.run_opts = _RunOpts()
+    m.thresholder = None
+    syn.fill_state_dict(m, seed=30)  # (name-keyed: the tensors tests/golden/gen_golden.py gave the reference's BDModel)
+    if volume == "mlp" and not golden_weights:
+        syn.fill_state_dict(m.cost_volume.mlp, seed=99, gain=1.4)  # (the hot_path workload's feature-volume weights: O(1) volume values)
+    return m
+
+
+def _reference_shaped_forward(m, cur_data, src_data, return_mask=True):
+    """The call sequence of the reference's BDModel.forward at test time (bd_model.py:175-311, run_mlp_val :412-442), module by module,
+    on a model whose hot-path attributes were swapped by `dropin.convert` - what a reference user gets from the one-line module swap of
+    INTEGRATION.md 1: NCHW tensors between the modules, torch.cat per query plane, 8 BinaryMLPNetwork calls."""
+    o = m.run_opts
+    ms = o.matching_scale
+    cur_image, src_image = cur_data["image_b3hw"], src_data["image_b3hw"]
+    src_K, cur_invK = src_data[f"K_s{ms}_b44"], cur_data[f"invK_s{ms}_b44"]
+    src_cam_T_cur_cam = src_data["cam_T_world_b44"] @ cur_data["world_T_cam_b44"].unsqueeze(1)   # :196-204
+    cur_cam_T_src_cam = cur_data["cam_T_world_b44"].unsqueeze(1) @ src_data["world_T_cam_b44"]
+    cur_feats = list(m.encoder(cur_image))                                                      # :218
+    frames = torch.cat([cur_image.unsqueeze(1), src_image], 1)                                  # compute_matching_feats :143-173 (batched form)
+    feats = m.matching_model(frames.flatten(0, 1)).unflatten(0, frames.shape[:2])
+    mc, msrc = feats[:, 0], feats[:, 1:].contiguous()
+    min_depth = torch.tensor(o.min_matching_depth).type_as(src_K).view(1, 1, 1, 1)
+    max_depth = torch.tensor(o.max_matching_depth).type_as(src_K).view(1, 1, 1, 1)
+    cost_volume, lowest_cost, _, overall_mask = m.cost_volume(cur_feats=mc, src_feats=msrc, src_extrinsics=src_cam_T_cur_cam, src_poses=cur_cam_T_src_cam,
+                                                              src_Ks=src_K, cur_invK=cur_invK, min_depth=min_depth, max_depth=max_depth,
+                                                              return_mask=return_mask)                   # :235-245
+    cv_feats = m.cost_volume_net(cost_volume, cur_feats[ms:])                                   # :253-258
+    feature_outputs = m.depth_decoder(cur_feats[:ms] + cv_feats)                                # :261
+    outputs = None
+    rendered_depth = cur_data["rendered_depth"]
+    features = feature_outputs["feature_s0_b1hw"]
+    for idx in range(rendered_depth.shape[1]):                                                  # :293-304
+        model_inputs = [torch.cat((rendered_depth[:, idx:idx + 1], features), 1).permute(0, 2, 3, 1)]   # run_mlp_val :415-436
+        cur = {k: v.permute(0, 3, 1, 2) for k, v in m.binary_mlp(model_inputs, max_scale_only=True).items()}
+        outputs = cur if outputs is None else {k: torch.cat((v, cur[k]), 1) for k, v in outputs.items()}
+    outputs["lowest_cost_bhw"], outputs["overall_mask_bhw"] = lowest_cost, overall_mask
+    return outputs
+
+
+class FusedForwardWorkload:
+    """What a reference user calls and the reference times (test_bd.py:196-212): `model("test", cur_data, src_data, return_mask=True)` on
+    raw 512x384 image tuples - with `model.forward = dropin.fused_forward(model)` installed.  The stand-in backbones run
+    as torch modules INSIDE the timed region (they are not the third-party networks: the figure shows the cost of the call shape - dict handling,
+    pose products, the stem / encoder hand-off - not of EfficientNetV2-S)."""
+
+    name = "fused_forward"
+    bound = "mfma"
+    scaling = "strong"
+    P = 8
+    mode = "fused"
+
+    def __init__(self, args, device, rank):
+        import implicit_depth_amd.synthetic as syn
+        from implicit_depth_amd.dropin import convert, fused_forward
+
+        self.B, self.K, self.D = args.batch, args.views, args.planes
+        self.Hi, self.Wi = args.height, args.width
+        self.volume = args.volume
+        self.model = _standin_bdmodel(self.K, self.Hi // 4, self.Wi // 4, self.D, self.volume).to(device).eval()
+        cur, src = syn.frame_tuple(self.B, self.K, self.Hi, self.Wi, seed=rank, P=self.P)
+        self.cur = {k: v.to(device) for k, v in cur.items()}
+        self.src = {k: v.to(device) for k, v in src.items()}
+        self._checksum = float(cur["image_b3hw"].double().sum()) + float(src["cam_T_world_b44"].double().sum())
+        if self.mode == "fused":
+            self.fwd = fused_forward(self.model)
+        else:
+            convert(self.model)  # (idempotent: the attributes already are drop-ins)
+            self.fwd = lambda phase, c, s_, return_mask=True: _reference_shaped_forward(self.model, c, s_, return_mask)
+        self.out = None
+        self.dominant_kernel = None
+
+    def input_checksum(self):
+        return self._checksum
+
+    def frames_per_step(self):
+        return self.B
+
+    def config(self):
+        what = ("dropin.fused_forward(model): BDModel.forward's signature, one fused HotPath pass behind the stand-in backbones" if self.mode == "fused" else
+                "dropin.convert(model) + the reference's own forward sequence: module by module, NCHW between modules, 8 BinaryMLPNetwork calls")
+        return {"workload": f"{self.name}: {what}; raw {self.Wi}x{self.Hi} images, K={self.K} source views, D={self.D} planes, {self.P} query planes, fp32; "
+                            "stand-in image encoder / ResNet stem (torch) inside the timed region",
+                "per_gpu_batch": self.B, "source_views": self.K, "depth_planes": self.D, "query_planes": self.P, "volume": self.volume}
+
+    def metric(self):
+        return (f"frames/sec (BDModel.forward call shape via {'dropin.fused_forward' if self.mode == 'fused' else 'dropin.convert (module swap)'}, "
+                f"{self.Wi}x{self.Hi}, {self.D} planes, {self.K + 1}-frame tuple, stand-in backbones in the timed region)")
+
+    def step(self, ev=None):
+        if ev is not None:
+            ev[0].record()
+        self.out = self.fwd("test", self.cur, self.src, return_mask=True)
+        if ev is not None:
+            ev[1].record()
+
+    def metrics(self):
+        o = self.out["pred_0"]
+        return torch.stack([o.mean((1, 2, 3)), torch.sigmoid(o).mean((1, 2, 3))], 1)
+
+    def cpu_baseline(self, seconds):
+        return None
+
+
+class ModuleSwapWorkload(FusedForwardWorkload):
+    name = "module_swap"
+    mode = "swap"
+
+
+WORKLOADS = {"warp_match_dot": WarpMatchDot, "hot_path": HotPathWorkload, "temporal": TemporalWorkload, "fused_forward": FusedForwardWorkload,
+             "module_swap": ModuleSwapWorkload}
 
 
 def _pmc_traffic(key):
@@ -709,11 +845,30 @@ def _self_launch(args):
         raise SystemExit(f"bench.py self-launch of {args.gpus} ranks failed (rc {rc}, {'no JSON line' if line is None else 'JSON line seen'})")
     rec = json.loads(line)
     rec["launcher"] = "self (python -m torch.distributed.run, started by bench.py)"
-    print(json.dumps(rec), flush=True)
+    _emit(json.dumps(rec))
+
+
+_JSON_FD = None
+
+
+def _claim_stdout():
+    """stdout carries exactly ONE line: the JSON record.  Native libraries write there too (RCCL prints its version banner to the C stdout when
+    the first communicator is created), so fd 1 is pointed at stderr for the life of the process and the record goes to a private duplicate of
+    the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line: str):
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
 
 
 def main():
     args = parse()
+    _claim_stdout()
     under_launcher = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -848,7 +1003,11 @@ def main():
                                                                       torch.nan_to_num(local_rows.cpu(), nan=-7.0)))}, f)
 
     if rank == 0:
-        if wl.bound == "hbm":
+        if not hasattr(wl, "conv_only_ms") and wl.bound != "hbm":
+            # call-shape workloads (fused_forward / module_swap): the kernels are the hot path's; its line carries the roofline
+            roof = {"bound": "mfma", "achieved": None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                    "note": "same kernels as --workload hot_path, whose line prices the dominant one; this workload measures the call shape"}
+        elif wl.bound == "hbm":
             rl_alg = wl.algorithmic_bytes_per_launch()
             achieved = rl_alg / (kernel_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -966,6 +1125,33 @@ def main():
                                    # (HotPath.forward(frame_chain=...): same outputs as F single-frame steps, tests/test_temporal_gpu.py).  Throughput of a
                                    # recorded scan (the reference's inference.py), at a latency of one step per frame
                                    "frames_in_flight": {"2": temporal_run(1, 2)[0], "4": temporal_run(1, 4)[0]}}
+            if world == 1:
+                # What a reference user calls (test_bd.py:196-212): model("test", cur_data, src_data, return_mask=True) from raw images, with the
+                # stand-in backbones inside the timed region - through dropin.fused_forward and through the one-line module swap (dropin.convert +
+                # the reference's own forward sequence).  Same weights (name-keyed seeds) and inputs on both: their logits must agree.
+                def call_shape(cls):
+                    w = cls(copy.copy(args), device, rank)
+                    with torch.inference_mode():
+                        for _ in range(3):
+                            w.step()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(10):
+                            w.step()
+                        torch.cuda.synchronize()
+                        el_ = (time.perf_counter() - t0) / 10
+                    return w, {"value": w.B / el_, "unit": "frames/s", "ms_per_step": el_ * 1e3, "steps": 10, "per_gpu_batch": w.B,
+                               "fraction_of_hot_path_rate": (w.B / el_) / (frames_total / elapsed), "config": w.config()["workload"]}
+
+                wf, rf = call_shape(FusedForwardWorkload)
+                pf = wf.out["pred_0"].clone()
+                del wf
+                torch.cuda.empty_cache()
+                wm, rm = call_shape(ModuleSwapWorkload)
+                rm["logits_max_abs_diff_vs_fused_forward_over_max_abs"] = float((wm.out["pred_0"] - pf).abs().max() / pf.abs().max())
+                del wm, pf
+                torch.cuda.empty_cache()
+                out["extra"] = {"fused_forward": rf, "module_swap": rm}
             if args.volume == "mlp" and args.views != 8:
                 # BASELINE.json's literal "8 source views" through the whole path (the headline is the reference-native 8-frame
                 # tuple = 7 source views): same batch, D, head and query planes, K = 8
@@ -987,8 +1173,10 @@ def main():
                 del w8
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+            cb = wl.cpu_baseline(args.cpu_seconds)
+            if cb is not None:
+                out["cpu_baseline"] = cb
+        _emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 

@@ -62,6 +62,7 @@ _SIGS = {
     "idh_packed_mlp_weight_floats": (C.c_size_t, [C.c_int]),
     "idh_pack_mlp_weight": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idh_binary_mlp_fwd": (C.c_int, [f32p, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
+    "idh_binary_mlp_strided_fwd": (C.c_int, [f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
     "idh_binary_mlp_f16x3_fwd": (C.c_int, [f32p, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_void_p]),
     "idh_feature_volume_workspace_bytes": (C.c_size_t, [C.c_int]),
     "idh_feature_volume_fwd": (

@@ -89,8 +89,12 @@ struct BinArgs {
     const float *thr_logits;  // ... and logit(threshold) per bin; null -> the constant thr_logit
     int n_thr;
     const float *sw2;     // F16 kernel: per-row scale of the f16-packed W2 (w2 then points to idh_pack_mlp_weight_f16 output)
-    int feat_unaligned;   // feature rows are not 16-byte aligned (cs % 4 != 0 or an odd base: the reference's [depth | feat | prior] rows
-                          // of 65 / 66 floats, networks.py:106-115, read in place): dword loads instead of one dwordx4
+    int feat_unaligned;   // 1: feature rows are not 16-byte aligned (cs % 4 != 0 or an odd base: the reference's [depth | feat | prior] rows
+                          // of 65 / 66 floats, networks.py:106-115, read in place): dword loads instead of one dwordx4.
+                          // 2: fully strided features, element (b, pix, c) at feat[b * feat_bs + pix * feat_ps + c * feat_chs] - the permuted view of
+                          // an NCHW tensor that run_mlp_val hands to the network (bd_model.py:415-439: cat along dim 1, then permute(0, 2, 3, 1))
+    long long feat_bs;
+    int feat_ps, feat_chs;
 };
 
 // Persistent 512- / 768-thread workgroups (one per CU): W2 (64 KiB) and, when it fits, the feature part
@@ -157,9 +161,15 @@ __global__ __launch_bounds__(bin_threads(F16)) void binary_mlp_k(const BinArgs a
             for (int t = 0; t < TM; ++t) {
                 Bf[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (cok) {
-                    const float *fp = a.feat + (size_t)mrow[t] * a.cs + 16 * c + 4 * q;
-                    if (a.feat_unaligned) Bf[t] = (f32x4){fp[0], fp[1], fp[2], fp[3]};
-                    else Bf[t] = *reinterpret_cast<const f32x4 *>(fp);
+                    if (a.feat_unaligned == 2) {  // planar / strided features: 16 consecutive pixels of a channel are one 64-byte run
+                        const int b = mrow[t] / a.HW;
+                        const float *fp = a.feat + (size_t)b * a.feat_bs + (size_t)(mrow[t] - b * a.HW) * a.feat_ps + (size_t)(16 * c + 4 * q) * a.feat_chs;
+                        Bf[t] = (f32x4){fp[0], fp[(size_t)a.feat_chs], fp[2 * (size_t)a.feat_chs], fp[3 * (size_t)a.feat_chs]};
+                    } else {
+                        const float *fp = a.feat + (size_t)mrow[t] * a.cs + 16 * c + 4 * q;
+                        if (a.feat_unaligned) Bf[t] = (f32x4){fp[0], fp[1], fp[2], fp[3]};
+                        else Bf[t] = *reinterpret_cast<const f32x4 *>(fp);
+                    }
                 }
             }
 #pragma unroll
@@ -466,6 +476,21 @@ extern "C" int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, c
               (int)M, HW, P, feat_cs, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0, nullptr, 0};
     // any row stride / any 4-byte-aligned base (ABI 105): rows that are not 16-byte aligned are read with dword loads
     a.feat_unaligned = ((feat_cs & 3) || (reinterpret_cast<uintptr_t>(feat_nhwc) & 15)) ? 1 : 0;
+    return binary_mlp_launch(a, B, stream);
+}
+
+extern "C" int idh_binary_mlp_strided_fwd(const float *feat, long long feat_batch_stride, int feat_pixel_stride, int feat_channel_stride, int Cf,
+                                          const float *depth_bphw, const float *prior_bphw, int has_prior, float prior_const,
+                                          const float *w1f_packed, const float *w2_packed, const float *vecs6x128, int B, int P, int HW,
+                                          float *out_bphw, void *stream) {
+    if (B < 0 || P < 0 || HW <= 0 || Cf <= 0 || (Cf & 3) || feat_batch_stride < 0 || feat_pixel_stride <= 0 || feat_channel_stride <= 0) return IDH_EINVAL;
+    if (B == 0 || P == 0) return IDH_OK;
+    if (!feat || !depth_bphw || !w1f_packed || !w2_packed || !vecs6x128 || !out_bphw || (reinterpret_cast<uintptr_t>(feat) & 3)) return IDH_EINVAL;
+    const long long M = (long long)B * HW;
+    if (M >= (1ll << 31)) return IDH_EUNSUPPORTED;
+    BinArgs a{feat, depth_bphw, prior_bphw, w1f_packed, w2_packed, vecs6x128, out_bphw,
+              (int)M, HW, P, 0, Cf, has_prior, prior_const, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0, nullptr, 2,
+              feat_batch_stride, feat_pixel_stride, feat_channel_stride};
     return binary_mlp_launch(a, B, stream);
 }
 

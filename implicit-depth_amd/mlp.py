@@ -157,19 +157,37 @@ def sample_prior(rendered_depth: torch.Tensor, prior_prediction: torch.Tensor, c
 
 
 def binary_mlp_forward(net, inputs: List[torch.Tensor], max_scale_only: bool = False) -> Dict[str, torch.Tensor]:
+    """``BinaryMLPNetwork.forward(list of (..., Cin) tensors, max_scale_only)`` (reference networks.py:106-115); row = [depth | features |
+    (prior)].  fp32: the rows are read IN PLACE through ``idh_binary_mlp_strided_fwd`` whatever their strides - in particular the
+    ``permute(0, 2, 3, 1)`` view of an NCHW concat that ``BDModel.run_mlp_val`` passes (bd_model.py:415-439), whose channel planes the kernel
+    reads as they lie - so a module-swapped model pays no (B,H,W,65) materialisation and no copy of the feature slice per query plane."""
     scales = [0] if max_scale_only else list(net.scales)
     outs = {}
     for s in scales:
         x = inputs[s]
         _lib.require_cuda_f32(x)
-        n_feat = x.shape[-1] - (2 if net.use_prior else 1)
+        cin = x.shape[-1]
+        n_feat = cin - (2 if net.use_prior else 1)
         lead = x.shape[:-1]
-        rows = x.reshape(1, -1, 1, x.shape[-1])  # (B=1, H=M, W=1, Cin)
+        math = mlp_math_of(net)
+        if math == "fp32" and x.dim() == 4 and x.stride(1) == x.shape[2] * x.stride(2) and min(x.stride()) > 0:
+            # (B, H, W, Cin) with a uniform pixel stride: contiguous rows (pixel stride Cin, channel stride 1) or the permuted NCHW view (1, H*W)
+            B, H, W, _ = x.shape
+            w1p, w2p, vecs = _prepared(net.mlps[f"s{s}"], n_feat, net.use_prior, math)
+            depth = x[..., 0].reshape(B, 1, H * W).contiguous()
+            prior = x[..., 1 + n_feat].reshape(B, 1, H * W).contiguous() if net.use_prior else None
+            y = torch.empty(B, 1, H * W, device=x.device, dtype=torch.float32)
+            _lib.check(
+                _lib.lib().idh_binary_mlp_strided_fwd(x.data_ptr() + 4 * x.stride(3), x.stride(0), x.stride(2), x.stride(3), n_feat, depth.data_ptr(),
+                                                      _lib.ptr(prior), int(net.use_prior), -1.0, w1p.data_ptr(), w2p.data_ptr(), vecs.data_ptr(),
+                                                      B, 1, H * W, y.data_ptr(), _lib.stream_ptr()),
+                "idh_binary_mlp_strided_fwd")
+            outs[f"pred_{s}"] = y.reshape(*lead, 1)
+            continue
+        rows = x.reshape(1, -1, 1, cin)  # (B=1, H=M, W=1, Cin)
         depth = rows[..., 0].reshape(1, 1, -1, 1)
         prior = rows[..., 1 + n_feat].reshape(1, 1, -1, 1) if net.use_prior else None
-        if mlp_math_of(net) == "fp32":
-            # the reference's [depth | features | prior] rows are read IN PLACE (row stride Cin = 65 / 66 floats, features from column 1:
-            # idh_binary_mlp_fwd takes any stride since ABI 105) - no copy of the 64-channel slice per call (bd_model.py:293-304 makes 8)
+        if math == "fp32":  # row stride Cin = 65 / 66 floats, features from column 1: idh_binary_mlp_fwd takes any stride since ABI 105
             y = occlusion_logits(net, rows, 1, n_feat, depth, prior, scale=s)
         else:  # the frozen split-precision kernels keep the 16-byte row alignment
             y = occlusion_logits(net, rows[..., 1 : 1 + n_feat].contiguous(), 0, n_feat, depth, prior, scale=s)

@@ -202,7 +202,8 @@ int idh_feature_volume_f16x3_fwd(const float *cur_nhwc, const float *src_nhwc, c
  *   out[b,p,pix] = W3 . ELU(W2 . ELU(W1 . x + b1) + b2) + b3          (hidden width 128)
  * W1's feature columns and W2 are passed in MFMA fragment order (idh_pack_mlp_weight);
  * vecs6x128 = rows {b1, W1[:,depth], W1[:,prior], b2, W3[0,:], [b3,0,...]}.
- *   feat_nhwc  rows of Cf floats, feat_cs floats apart (B*HW rows)
+ *   feat_nhwc  rows of Cf floats, feat_cs floats apart (B*HW rows); any feat_cs >= Cf and any 4-byte-aligned base since ABI 105
+ *              (rows that are not 16-byte aligned - the reference's 65- / 66-float [depth | feat | prior] rows - are read with dword loads)
  *   depth_bphw (B,P,HW); prior_bphw (B,P,HW) or NULL (then prior_const is used when has_prior)
  *   out_bphw   (B,P,HW) logits
  */
@@ -212,6 +213,14 @@ int idh_binary_mlp_fwd(const float *feat_nhwc, int feat_cs, int Cf, const float 
                        const float *prior_bphw, int has_prior, float prior_const,
                        const float *w1f_packed, const float *w2_packed, const float *vecs6x128, int B,
                        int P, int HW, float *out_bphw, void *stream);
+/* The same pass over features with arbitrary strides: element (b, pix, c) at feat[b * feat_batch_stride + pix * feat_pixel_stride +
+ * c * feat_channel_stride] (floats).  (1, HW-contiguous planes) reads the channel planes of an NCHW tensor in place: BDModel.run_mlp_val
+ * (bd_model.py:415-439) concatenates [rendered_depth | feature_s0 | prior] along dim 1 and hands the MLP a permute(0, 2, 3, 1) VIEW of it -
+ * with this entry point the drop-in's BinaryMLPNetwork.forward reads that view without materialising (B,H,W,65) rows.  ABI 105. */
+int idh_binary_mlp_strided_fwd(const float *feat, long long feat_batch_stride, int feat_pixel_stride, int feat_channel_stride, int Cf,
+                               const float *depth_bphw, const float *prior_bphw, int has_prior, float prior_const,
+                               const float *w1f_packed, const float *w2_packed, const float *vecs6x128, int B, int P, int HW,
+                               float *out_bphw, void *stream);
 /* Same, with the per-plane 128x128 layer in "f16x3" split precision (w2_f16 from
  * idh_pack_mlp_weight_f16, csrc/split_f16.h) and ELU's exp on v_exp_f32: fp32-equivalent results
  * (tests/test_mlp_split_gpu.py) at a fraction of the fp32-MFMA cost. */

@@ -322,3 +322,34 @@ def test_fused_forward_from_raw_images_matches_reference_depthmodel():
         assert rel_err(out[f"log_depth_pred_s{i}_b1hw"].cpu(), g[f"log_depth_pred_s{i}_b1hw"]) < TOL
         assert rel_err(out[f"depth_pred_s{i}_b1hw"].cpu(), g[f"depth_pred_s{i}_b1hw"]) < 5 * TOL
     assert sorted(k for k in out if "depth_pred" in k) == sorted(k for k in g if "depth_pred" in k)
+
+
+@pytest.mark.parametrize("volume", ["dot", "mlp"])
+def test_bench_call_shape_workloads_match_reference_bdmodel(volume):
+    """bench.py's two call-shape workloads on the golden's tuple and weights: the module-swap forward (dropin.convert + the reference's own
+    call sequence bd_model.py:175-311, module by module, 8 BinaryMLPNetwork calls on the permuted NCHW view) and dropin.fused_forward must
+    both reproduce the reference's BDModel.forward (golden G5)."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from implicit_depth_amd.dropin import convert, fused_forward
+
+    g = load_golden(f"g5_bdmodel_{volume}")
+    K = int(g["K"])
+    m = bench._standin_bdmodel(K, 24, 32, 16, volume, golden_weights=True).cuda().eval()
+    cur, src = syn.frame_tuple(1, K, 96, 128, seed=31, P=3)
+    cur = {k: v.cuda() for k, v in cur.items()}
+    src = {k: v.cuda() for k, v in src.items()}
+    with torch.inference_mode():
+        swap = bench._reference_shaped_forward(convert(m), cur, src, return_mask=True)
+        fused = fused_forward(m)("test", cur, src, return_mask=True)
+    for out in (swap, fused):
+        assert rel_err(out["pred_0"].cpu(), g["pred_0"]) < TOL
+        assert ((out["lowest_cost_bhw"].cpu() - torch.as_tensor(g["lowest_cost"])).abs() > 1e-5).float().mean().item() < 5e-3
+        if volume == "mlp":
+            assert (out["overall_mask_bhw"].cpu() != torch.as_tensor(g["overall_mask"])).float().mean().item() < 2e-3
+    assert rel_err(swap["pred_0"].cpu(), fused["pred_0"].cpu()) < TOL

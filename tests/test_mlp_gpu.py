@@ -48,6 +48,29 @@ def test_module_interface_matches_oracle(use_prior):
     assert rel_err(out["pred_0"].cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("use_prior", [False, True])
+def test_module_interface_reads_the_references_permuted_view_in_place(use_prior):
+    """BDModel.run_mlp_val (bd_model.py:415-439) concatenates [depth | feature_s0 | prior] along dim 1 (NCHW) and passes
+    ``model_inputs.permute(0, 2, 3, 1)`` - a strided VIEW.  The drop-in reads its channel planes in place (idh_binary_mlp_strided_fwd): same
+    bits as the contiguous (B,H,W,Cin) rows, no copy of the tensor."""
+    m, feat, rd, pri = _setup(use_prior)
+    m.cuda()
+    parts = [rd[:, 0:1], feat] + ([pri[:, 0:1]] if use_prior else [])
+    x_nchw = torch.cat(parts, 1).cuda()
+    view = x_nchw.permute(0, 2, 3, 1)
+    assert not view.is_contiguous()
+    rows = view.contiguous()
+    a = m([view], max_scale_only=True)["pred_0"]
+    b = m([rows], max_scale_only=True)["pred_0"]
+    assert a.shape == b.shape == (*view.shape[:3], 1) and torch.equal(a, b)
+    ref = onet.binary_mlp(rows.cpu().double(), {k: v.detach().cpu().double() for k, v in m.state_dict().items()})
+    assert rel_err(a.cpu(), ref) < TOL
+    # two frames, odd size, a batch-strided view (every second frame of a larger tensor)
+    big = torch.randn(4, x_nchw.shape[1], 7, 9, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    v2 = big[::2].permute(0, 2, 3, 1)
+    assert torch.equal(m([v2], max_scale_only=True)["pred_0"], m([v2.contiguous()], max_scale_only=True)["pred_0"])
+
+
 def test_prior_absent_is_minus_one_and_odd_sizes():
     from implicit_depth_amd import networks as net
     from implicit_depth_amd.mlp import occlusion_logits
