@@ -446,10 +446,12 @@ class Plan {
     std::map<std::tuple<int, int, int, int>, std::vector<int>> free_;
 };
 
-bool tensor_ok(const idh_tensor *t, bool need_ptr) {
+// `read`: the tensor is read by a conv (whole 16-channel blocks: an odd channel count must be a zero-padded buffer of its own); a tensor that is
+// only written may be any 16-byte-aligned channel slice
+bool tensor_ok(const idh_tensor *t, bool need_ptr, bool read = true) {
     if (!t || t->C <= 0 || t->H <= 0 || t->W <= 0) return false;
     if (t->layout != IDH_LAYOUT_NHWC && t->layout != IDH_LAYOUT_NCHW) return false;
-    if (t->layout == IDH_LAYOUT_NHWC && (t->cs < t->C || (t->cs & 3) || ((t->C & 15) && t->cs != ceil16(t->C)))) return false;
+    if (t->layout == IDH_LAYOUT_NHWC && (t->cs < t->C || (t->cs & 3) || (read && (t->C & 15) && t->cs != ceil16(t->C)))) return false;
     if (need_ptr && (!t->ptr || ((uintptr_t)t->ptr & 15))) return false;
     return true;
 }
@@ -473,7 +475,7 @@ void output_done(Plan &p, const idh_tensor &t, const View &v) {
 // ---- the three networks ---------------------------------------------------------------------------------------------------------------------
 int build_basic_block(Plan &p, const idh_block_params *blk, int N, const idh_tensor *x, const idh_tensor *out) {
     const bool run = p.mode() == MODE_RUN;
-    if (!blk || N <= 0 || !tensor_ok(x, run) || !tensor_ok(out, run) || x->C != blk->conv1.cin || out->C != blk->conv1.cout) return IDH_EINVAL;
+    if (!blk || N <= 0 || !tensor_ok(x, run) || !tensor_ok(out, run, false) || x->C != blk->conv1.cin || out->C != blk->conv1.cout) return IDH_EINVAL;
     const View xin = input_view(p, *x, N);
     const View o = output_view(p, *out, N);
     p.basic_block(xin, *blk, &o);
