@@ -3,8 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B]
 
-One "step" = one pass of the hot path over the GLOBAL batch of 32 synthetic frames (BASELINE.json
-configs[3]), sharded by frame over the GPUs (strong scaling: total work fixed, 32/N frames per GPU).
+One "step" = one pass of the hot path over one batch of 32 synthetic frames PER GPU (BASELINE.json configs[3]: batch_size = 32; the
+reference's multi-GPU mode is Lightning DDP, train.py:124,135, where batch_size is per process) - "scaling": "weak", the path shards over
+independent frames with no data-path collective.  `--scaling strong` shards ONE global batch of --batch frames over the GPUs instead
+(32/N frames per GPU: the configuration rounds 1-5 quoted; a 1-GPU run is the same workload either way).
 Inputs are generated once and are resident in HBM before the timed region.  For N>1 launch with
 torch.distributed.run (one rank per GPU, RCCL); the batch dimension is sharded, there is no data-path
 collective, and the only message is an all-gather of per-frame metric vectors after the timed region
@@ -53,7 +55,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="hot_path", choices=["hot_path", "warp_match_dot", "temporal", "fused_forward", "module_swap"])
-    ap.add_argument("--batch", type=int, default=32, help="GLOBAL frames per step (BASELINE.json configs[3]: batch_size=32), sharded over the GPUs")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step and GPU (BASELINE.json configs[3]: batch_size=32); with --scaling strong: the GLOBAL batch, sharded over the GPUs")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every GPU runs --batch frames, the job's batch grows with N (DDP semantics of the reference, batch_size per process); "
+                         "strong: --batch frames in total, sharded by frame (ragged shards allowed)")
     ap.add_argument("--views", type=int, default=0, help="source views K; 0 = 7 for --volume mlp (reference-native 8-frame tuple = 1 cur + 7 src), 8 for --volume dot (BASELINE.json literal)")
     ap.add_argument("--volume", default="mlp", choices=["mlp", "dot"], help="mlp = FeatureVolumeManager (every shipped BDModel config), dot = CostVolumeManager")
     ap.add_argument("--planes", type=int, default=0, help="depth planes D; 0 = 64 (96 for --workload temporal)")
@@ -886,9 +891,8 @@ def main():
         raise SystemExit(f"rank {rank}: cuda:{dev_index} does not exist ({torch.cuda.device_count()} GPU(s) visible)")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    # strong scaling: the global batch is fixed (32 ScanNet-shaped tuples) and sharded by frame
-    global_batch = args.batch
-    counts = shard_counts(global_batch, world)
+    # weak scaling (default): --batch frames per rank (every rank its own 32 ScanNet-shaped tuples, seed = rank); strong: ONE global batch sharded by frame
+    counts = [args.batch] * world if args.scaling == "weak" else shard_counts(args.batch, world)
     args.batch = counts[rank]  # frames of THIS rank
     # A process group always exists (a 1-rank RCCL group at N = 1 without a launcher: the N = 1 record then exercises the path's one
     # collective, ncclAllGather, too) unless --no-process-group asks for the bare single process.
@@ -911,8 +915,10 @@ def main():
     host_coll = use_dist and args.dist_backend == "gloo"
 
     wl = WORKLOADS[args.workload](args, device, rank)
-    if wl.scaling == "weak":  # temporal: one sequence per GPU
+    if wl.name == "temporal":  # one set of sequences per GPU: weak by construction (frames of a sequence are serially dependent)
         counts = [wl.frames_per_step()] * world
+    else:
+        wl.scaling = args.scaling
 
     def barrier():
         if use_dist:

@@ -73,7 +73,8 @@ def test_two_rank_gather_matches_single_process(B):
 
 
 def test_bench_shard_counts_cover_the_global_batch():
-    """bench.py's frame sharding (strong scaling of the fixed 32-frame batch) incl. ragged world sizes."""
+    """bench.py's frame sharding for --scaling strong (ONE global batch over the ranks) incl. ragged world sizes; the default is weak
+    scaling: --batch frames per rank."""
     import bench
 
     for world in (1, 2, 3, 4, 8):
@@ -82,7 +83,7 @@ def test_bench_shard_counts_cover_the_global_batch():
     assert bench.shard_counts(32, 3) == [11, 11, 10]
     assert bench.shard_counts(32, 8) == [4] * 8
     a = bench.parse([])
-    assert (a.workload, a.batch, a.views, a.planes, a.steps) == ("hot_path", 32, 7, 64, 100)
+    assert (a.workload, a.batch, a.views, a.planes, a.steps, a.scaling) == ("hot_path", 32, 7, 64, 100, "weak")
     assert bench.parse(["--workload", "temporal"]).planes == 96 and bench.parse(["--volume", "dot"]).views == 8
 
 

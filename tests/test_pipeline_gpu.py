@@ -238,7 +238,7 @@ def test_bench_n2_branch_on_one_gpu_over_gloo(tmp_path):
     rep = tmp_path / "ranks"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29613",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "7", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--ranks-on-device", "0",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "7", "--scaling", "strong", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--ranks-on-device", "0",
            "--no-extras", "--no-split-line", "--no-cpu-baseline", "--rank-report", str(rep)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -279,15 +279,20 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     import json
 
     rep = tmp_path / "ranks"
-    out, err = _bench_line(["--gpus", "2", "--batch", "5", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--ranks-on-device", "0",
+    out, err = _bench_line(["--gpus", "2", "--batch", "5", "--scaling", "strong", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--ranks-on-device", "0",
                             "--no-extras", "--no-cpu-baseline", "--no-parity", "--rank-report", str(rep)])
-    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["dist_backend"] == "gloo" and out["config"]["global_batch"] == 5
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["dist_backend"] == "gloo" and out["config"]["global_batch"] == 5 and out["scaling"] == "strong"
     assert out["gathered_metric_rows"] == 5 and out["allgather_us"] > 0 and out["launcher"].startswith("self")
     assert [d["rank"] for d in out["devices"]] == [0, 1] and [d["frames"] for d in out["devices"]] == [3, 2]
     assert len({d["pid"] for d in out["devices"]}) == 2, "one PROCESS per rank"
     ranks = [json.load(open(rep / f"rank{i}.json")) for i in range(2)]
     assert [r_["frames"] for r_ in ranks] == [[0, 3], [3, 5]] and all(r_["gathered_rows_match_local"] for r_ in ranks)
     assert "self-launch" in err
+    # the default: weak scaling, --batch frames on EVERY rank (DDP semantics: batch_size per process)
+    w, _ = _bench_line(["--gpus", "2", "--batch", "3", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--ranks-on-device", "0",
+                        "--no-extras", "--no-cpu-baseline", "--no-parity"])
+    assert w["scaling"] == "weak" and w["config"]["global_batch"] == 6 and w["config"]["per_gpu_batch"] == 3 and w["gathered_metric_rows"] == 6
+    assert [d["frames"] for d in w["devices"]] == [3, 3]
 
 
 def test_bench_refuses_more_gpus_than_the_box_has():
