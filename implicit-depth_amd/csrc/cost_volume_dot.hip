@@ -532,6 +532,8 @@ struct WinArgs {
     float *partial;                                 // [psplit][B N][2] (best cost, plane index) of each plane group, or null
     int cost_cs;
     CvExt ext;
+    const int *runs;                                // run lists left by cv_runs_k: [task][runs_stride] = {count, (xy, info) x count}, task = ((b ty) tx) sp; or null
+    int runs_stride;
 };
 
 // One entry of the flattened run list: a window serving L consecutive planes of one (super-group, view) pair, or one
@@ -543,81 +545,19 @@ struct RunEntry {
 constexpr int kRunsPerPair = 16;  // worst case: sixteen single planes
 constexpr int kCntOff = 16384;  // prologue scratch inside the window: PlaneBox at 0, per-pair counts here
 
-// PLANES: caller-supplied per-pixel depth planes (idh_volume_opts.planes) instead of the uniform plane table.
-// Four workgroups per CU (<= 128 VGPRs, <= 40 KiB of LDS for the bench shape): the kernel is a chain of latency-bound phases
-// (prologue, window copies, barriers, LDS reads) around VALU work, and other workgroups' waves are what fills them.
-template <bool PLANES>
-__global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *s_win = smem;                                                     // kWinBytes
-    RunEntry *s_list = reinterpret_cast<RunEntry *>(smem + kWinBytes);               // [pairs * kRunsPerPair]
-    int *s_cnt = reinterpret_cast<int *>(smem + kCntOff);                            // [pairs + 1], prologue only
-    float *s_planes = reinterpret_cast<float *>(smem + kWinBytes + a.list_bytes);    // [D]
-    float (*s_h)[12] = reinterpret_cast<float (*)[12]>(smem + kWinBytes + a.list_bytes + a.planes_bytes);  // [K][12]
-    __shared__ int s_total;
-
-    const int N = a.H * a.W, W = a.W, H = a.H, K = a.K, D = a.D;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef IDH_ABL_TRACE
-    const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
-    unsigned long long tr_wait = 0, tr_comp = 0, tr_prolog = 0;
-#endif
-    // Task order = dispatch order: each XCD (blocks b % 8) walks one contiguous range of tiles, the plane groups of a tile
-    // back to back (they share its source maps in that XCD's L2).  A plane group's work grows with its depth — near planes have
-    // the larger parallax, most of their samples leave the source images and are skipped: 50 k ... 235 k cycles per workgroup
-    // from the nearest to the farthest quarter of 64 planes — and the dispatcher hands consecutive workgroups of an XCD to its
-    // 32 CUs in turn, so with 2, 4 or 8 plane groups a CU would only ever see ONE group (a quarter of the CUs gets all the far
-    // planes).  Rotating the group order by one every 32 workgroups gives every CU every group in turn.
-    unsigned lin = idh_xcd_remap(blockIdx.x, gridDim.x);
-    int sp = lin % a.psplit;
-    lin /= a.psplit;
-#ifndef IDH_ABL_DOT_NOROTATE
-    sp = (int)((sp + lin * a.psplit / 32) % a.psplit);
-#endif
-#ifdef IDH_ABL_DOT_FARFIRST_CHUNKED  // all far-plane groups of a frame's tiles first: loses the interleave (D = 96: +12 %)
-    {
-        const unsigned ntiles = (unsigned)(a.B * a.tiles_x * a.tiles_y);
-        if ((ntiles & 7) == 0) {
-            const unsigned per = ntiles >> 3, slot = blockIdx.x >> 3;
-            const unsigned frame = (unsigned)(a.tiles_x * a.tiles_y);
-            const unsigned chunk = per % frame == 0 ? frame : per;
-            const unsigned c = slot / (chunk * a.psplit), within = slot - c * chunk * a.psplit;
-            sp = a.psplit - 1 - (int)(within / chunk);
-            lin = (blockIdx.x & 7) * per + c * chunk + within % chunk;
-        }
-    }
-#endif
-    int tx = lin % a.tiles_x; lin /= a.tiles_x;
-#ifndef IDH_ABL_DOT_NOROTATE_TX
-    // the same for the tile columns (a tile's work depends on where it lies in the image: here 70 k ... 205 k cycles from the left to
-    // the right column): the column order of a tile row advances by one every 32 tiles, i.e. once per full turn of the plane groups
-    tx = (int)((tx + lin * a.tiles_x / 32) % a.tiles_x);
-#endif
-    const int ty = lin % a.tiles_y;
-    const int b = lin / a.tiles_y;
-    const int nunits_all = (D + 3) >> 2;
-    const int ua = sp * a.units_per_split, ub = min(ua + a.units_per_split, nunits_all);  // this workgroup's 4-plane units
-    const int sg0 = ua >> 2;
-    const int nsg = ((ub + 3) >> 2) - sg0;
-    const int px0 = tx * kTileW, py0 = ty * kTileH;
+// The run list of one (frame, tile, plane group) task: pass 1 = per (pair, plane) the tap bounding box of the four tile corners, pass 2 = one
+// thread per (super-group, view) pair builds its run tree and walks it into the flat, ordered list (count in *s_total).  Called by the
+// workgroup that will consume the list (cv_dot_win_k without run-list scratch) or by cv_runs_k ahead of it.  `nthr` threads take part; the
+// caller's next __syncthreads() publishes list and count.  s_h / s_planes must be visible (a barrier behind their writers).
+template <typename Args>
+__device__ __forceinline__ void cv_build_runs(const Args &a, const float (*s_h)[12], const float *s_planes, PlaneBox *s_pb, int *s_cnt, RunEntry *s_list,
+                                              int *s_total, int b, int px0, int py0, int sg0, int nsg, int ua, int ub, int tid, int nthr) {
+    const int W = a.W, H = a.H, K = a.K, D = a.D;
     const float Wf = (float)W, Hf = (float)H;
-
-    if (tid < K)
-        build_homography(a.src_K + (size_t)(b * K + tid) * 16, a.src_E + (size_t)(b * K + tid) * 16, a.cur_invK + (size_t)b * 16, s_h[tid]);
-    for (int i = tid; i < D; i += 256) {
-        const float dp = depth_plane(i, D, a.dmin, a.dmax);
-        s_planes[i] = dp;
-        if (a.planes_out != nullptr && blockIdx.x == 0) a.planes_out[i] = dp;
-    }
-    __syncthreads();
-
+    const int npairs = nsg * K;
     // ---- window table, pass 1: per (pair, plane) the tap bounding box of the four tile corners ------------------
     const int px1 = min(px0 + kTileW, W) - 1, py1 = min(py0 + kTileH, H) - 1;  // last live pixel of the tile
-    const int npairs = nsg * K;
-    PlaneBox *s_pb = reinterpret_cast<PlaneBox *>(s_win);
-    for (int it = tid; it < npairs * kSG; it += 256) {
+    for (int it = tid; it < npairs * kSG; it += nthr) {
         const int pair = it / kSG, j = it - pair * kSG;
         const int sgi = pair / K, k = pair - sgi * K;
         const int dj = kSG * (sg0 + sgi) + j;
@@ -730,7 +670,7 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
     if (tid < npairs) {
         int off = 0;
         for (int i = 0; i < npairs; ++i) off += i < tid ? s_cnt[i] : 0;  // independent reads: one round trip
-        if (tid == npairs - 1) s_total = off + my_cnt;
+        if (tid == npairs - 1) *s_total = off + my_cnt;
         walk([&](const WinEntry &e, int j0, int L) {
             RunEntry r;
             r.xy = e.xy;
@@ -738,7 +678,89 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
             s_list[off++] = r;
         });
     }
-    if (npairs == 0 && tid == 0) s_total = 0;
+    if (npairs == 0 && tid == 0) *s_total = 0;
+
+}
+
+// PLANES: caller-supplied per-pixel depth planes (idh_volume_opts.planes) instead of the uniform plane table.
+// Four workgroups per CU (<= 128 VGPRs, <= 40 KiB of LDS for the bench shape): the kernel is a chain of latency-bound phases
+// (prologue, window copies, barriers, LDS reads) around VALU work, and other workgroups' waves are what fills them.
+template <bool PLANES>
+__global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *s_win = smem;                                                     // kWinBytes
+    RunEntry *s_list = reinterpret_cast<RunEntry *>(smem + kWinBytes);               // [pairs * kRunsPerPair]
+    int *s_cnt = reinterpret_cast<int *>(smem + kCntOff);                            // [pairs + 1], prologue only
+    float *s_planes = reinterpret_cast<float *>(smem + kWinBytes + a.list_bytes);    // [D]
+    float (*s_h)[12] = reinterpret_cast<float (*)[12]>(smem + kWinBytes + a.list_bytes + a.planes_bytes);  // [K][12]
+    __shared__ int s_total;
+
+    const int N = a.H * a.W, W = a.W, H = a.H, K = a.K, D = a.D;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef IDH_ABL_TRACE
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tr_wait = 0, tr_comp = 0, tr_prolog = 0;
+#endif
+    // Task order = dispatch order: each XCD (blocks b % 8) walks one contiguous range of tiles, the plane groups of a tile
+    // back to back (they share its source maps in that XCD's L2).  A plane group's work grows with its depth — near planes have
+    // the larger parallax, most of their samples leave the source images and are skipped: 50 k ... 235 k cycles per workgroup
+    // from the nearest to the farthest quarter of 64 planes — and the dispatcher hands consecutive workgroups of an XCD to its
+    // 32 CUs in turn, so with 2, 4 or 8 plane groups a CU would only ever see ONE group (a quarter of the CUs gets all the far
+    // planes).  Rotating the group order by one every 32 workgroups gives every CU every group in turn.
+    unsigned lin = idh_xcd_remap(blockIdx.x, gridDim.x);
+    int sp = lin % a.psplit;
+    lin /= a.psplit;
+#ifndef IDH_ABL_DOT_NOROTATE
+    sp = (int)((sp + lin * a.psplit / 32) % a.psplit);
+#endif
+#ifdef IDH_ABL_DOT_FARFIRST_CHUNKED  // all far-plane groups of a frame's tiles first: loses the interleave (D = 96: +12 %)
+    {
+        const unsigned ntiles = (unsigned)(a.B * a.tiles_x * a.tiles_y);
+        if ((ntiles & 7) == 0) {
+            const unsigned per = ntiles >> 3, slot = blockIdx.x >> 3;
+            const unsigned frame = (unsigned)(a.tiles_x * a.tiles_y);
+            const unsigned chunk = per % frame == 0 ? frame : per;
+            const unsigned c = slot / (chunk * a.psplit), within = slot - c * chunk * a.psplit;
+            sp = a.psplit - 1 - (int)(within / chunk);
+            lin = (blockIdx.x & 7) * per + c * chunk + within % chunk;
+        }
+    }
+#endif
+    int tx = lin % a.tiles_x; lin /= a.tiles_x;
+#ifndef IDH_ABL_DOT_NOROTATE_TX
+    // the same for the tile columns (a tile's work depends on where it lies in the image: here 70 k ... 205 k cycles from the left to
+    // the right column): the column order of a tile row advances by one every 32 tiles, i.e. once per full turn of the plane groups
+    tx = (int)((tx + lin * a.tiles_x / 32) % a.tiles_x);
+#endif
+    const int ty = lin % a.tiles_y;
+    const int b = lin / a.tiles_y;
+    const int nunits_all = (D + 3) >> 2;
+    const int ua = sp * a.units_per_split, ub = min(ua + a.units_per_split, nunits_all);  // this workgroup's 4-plane units
+    const int sg0 = ua >> 2;
+    const int nsg = ((ub + 3) >> 2) - sg0;
+    const int px0 = tx * kTileW, py0 = ty * kTileH;
+    const float Wf = (float)W, Hf = (float)H;
+
+    if (tid < K)
+        build_homography(a.src_K + (size_t)(b * K + tid) * 16, a.src_E + (size_t)(b * K + tid) * 16, a.cur_invK + (size_t)b * 16, s_h[tid]);
+    for (int i = tid; i < D; i += 256) {
+        const float dp = depth_plane(i, D, a.dmin, a.dmax);
+        s_planes[i] = dp;
+        if (a.planes_out != nullptr && blockIdx.x == 0) a.planes_out[i] = dp;
+    }
+    __syncthreads();
+
+    // ---- run list of this (tile, plane group): built here, or (a.runs: idh_volume_opts.scratch large enough) read from the list cv_runs_k left ----
+    if (a.runs != nullptr) {
+        const int *rl = a.runs + (size_t)((((size_t)b * a.tiles_y + ty) * a.tiles_x + tx) * a.psplit + sp) * a.runs_stride;
+        const int cnt = rl[0];
+        if (tid == 0) s_total = cnt;
+        if (tid < cnt) s_list[tid] = RunEntry{rl[1 + 2 * tid], rl[2 + 2 * tid]};
+    } else {
+        cv_build_runs(a, s_h, s_planes, reinterpret_cast<PlaneBox *>(s_win), s_cnt, s_list, &s_total, b, px0, py0, sg0, nsg, ua, ub, tid, 256);
+    }
 
     // ---- this lane's pixel: ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) -> 4x4 pixel blocks ----
     const int m5 = lane & 31, hi = lane >> 5;
@@ -930,12 +952,27 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
             add_unit(j0 >> 2, make_float4(jj == 0 ? v : 0.f, jj == 1 ? v : 0.f, jj == 2 ? v : 0.f, jj == 3 ? v : 0.f));
         } else {
             const int u0 = j0 >> 2, uend = min(u0 + (L >> 2), (nd + 3) >> 2);  // units with at least one real plane
+#ifdef IDH_DOT_DYNAMIC_UNITS  // (rounds 3-5: one loop body, the unit's accumulator picked with 16 selects + 16 adds)
 #pragma unroll 1
             for (int u = u0; u < uend; ++u) {
                 float4 rr;
                 rr.x = plane(4 * u); rr.y = plane(4 * u + 1); rr.z = plane(4 * u + 2); rr.w = plane(4 * u + 3);
                 add_unit(u, rr);
             }
+#else
+            // Four copies of the unit body behind wave-uniform guards: the unit index is a compile-time constant inside each copy, so its
+            // results go to acc[u] with 4 adds (the dynamic index cost 32 vector operations per unit = 8 of ~102 per plane) and the plane
+            // depths are v_readlane with an immediate lane.  Each copy is still ONE basic block of four planes (a branch INSIDE the unit
+            // body - round 3's variant of this idea - split it and lost 8 %).
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= u0 && u < uend) {
+                    float4 rr;
+                    rr.x = plane(4 * u); rr.y = plane(4 * u + 1); rr.z = plane(4 * u + 2); rr.w = plane(4 * u + 3);
+                    acc[u].x += rr.x; acc[u].y += rr.y; acc[u].z += rr.z; acc[u].w += rr.w;
+                }
+            }
+#endif
         }
 #endif
 #ifdef IDH_ABL_TRACE
@@ -966,6 +1003,38 @@ __global__ __launch_bounds__(256, 4) void cv_dot_win_k(const WinArgs a) {
     // instead of the pass re-reading the group's 4 D / psplit bytes of the volume
     if (a.partial != nullptr && a.psplit > 1 && live)
         *reinterpret_cast<float2 *>(a.partial + (((size_t)sp * a.B + b) * N + p) * 2) = make_float2(best, __builtin_bit_cast(float, bidx));
+}
+
+// Run lists ahead of the volume kernel (round 6).  cv_dot_win_k's workgroups spent ~10 % of their life building the list of their own (tile,
+// plane group) - three barrier-separated phases in front of the first window copy, on 8 of 256 threads in the last one.  One 64-thread workgroup
+// per task builds the same list here (the same code: cv_build_runs) and leaves it in the caller's scratch; the volume kernel then starts with one
+// coalesced read.  6144 tasks for 32 frames: a few microseconds for the whole batch.
+__global__ __launch_bounds__(64) void cv_runs_k(const WinArgs a, int *__restrict__ runs_out) {
+    __shared__ PlaneBox s_pb[kMaxPairs * kSG];
+    __shared__ int s_cnt[kMaxPairs + 1];
+    __shared__ RunEntry s_list[kMaxPairs * kRunsPerPair];
+    __shared__ float s_planes[kMaxPlanes];
+    __shared__ float s_h[IDH_MAX_SOURCE_VIEWS][12];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, K = a.K, D = a.D;
+    unsigned lin = blockIdx.x;
+    const int sp = lin % a.psplit; lin /= a.psplit;
+    const int tx = lin % a.tiles_x; lin /= a.tiles_x;
+    const int ty = lin % a.tiles_y;
+    const int b = lin / a.tiles_y;
+    const int nunits_all = (D + 3) >> 2;
+    const int ua = sp * a.units_per_split, ub = min(ua + a.units_per_split, nunits_all);
+    const int sg0 = ua >> 2, nsg = ((ub + 3) >> 2) - sg0;
+    if (tid < K)
+        build_homography(a.src_K + (size_t)(b * K + tid) * 16, a.src_E + (size_t)(b * K + tid) * 16, a.cur_invK + (size_t)b * 16, s_h[tid]);
+    for (int i = tid; i < D; i += 64) s_planes[i] = depth_plane(i, D, a.dmin, a.dmax);
+    __syncthreads();
+    cv_build_runs(a, s_h, s_planes, s_pb, s_cnt, s_list, &s_total, b, tx * kTileW, ty * kTileH, sg0, nsg, ua, ub, tid, 64);
+    __syncthreads();
+    int *o = runs_out + (size_t)blockIdx.x * a.runs_stride;
+    const int cnt = s_total;
+    if (tid == 0) o[0] = cnt;
+    for (int i = tid; i < cnt; i += 64) { o[1 + 2 * i] = s_list[i].xy; o[2 + 2 * i] = s_list[i].info; }
 }
 
 // lowest[b,p] = plane_{argmax_d cost[b,d,p]} (first maximum wins) for launches that split the planes over workgroups
@@ -1098,6 +1167,17 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
         a.partial = (opts && opts->struct_size >= (int64_t)(offsetof(idh_volume_opts, struct_size) + sizeof(int64_t)) && opts->scratch && lowest_bhw && a.psplit > 1 &&
                      opts->scratch_floats >= 2ll * a.psplit * B * H * W) ? opts->scratch : nullptr;
         a.list_bytes = ((a.units_per_split + 3) / 4) * K * kRunsPerPair * (int)sizeof(RunEntry);
+        // ... and, behind the arg-max partials, for the run lists of every (frame, tile, plane group) task, built by cv_runs_k ahead of the volume kernel
+        {
+            const bool scratch_ok = opts && opts->struct_size >= (int64_t)(offsetof(idh_volume_opts, struct_size) + sizeof(int64_t)) && opts->scratch;
+            const long long part = a.psplit > 1 ? 2ll * a.psplit * B * H * W : 0;
+            const long long tasks = (long long)B * a.tiles_x * a.tiles_y * a.psplit;
+            a.runs_stride = 1 + 2 * (a.list_bytes / (int)sizeof(RunEntry));
+            a.runs = (scratch_ok && tasks < (1ll << 31) && opts->scratch_floats >= part + tasks * a.runs_stride) ? reinterpret_cast<const int *>(opts->scratch + part) : nullptr;
+#ifdef IDH_DOT_NO_PREPASS
+            a.runs = nullptr;
+#endif
+        }
         a.planes_bytes = ((D + 3) & ~3) * (int)sizeof(float);
         const size_t lds = (size_t)kWinBytes + a.list_bytes + a.planes_bytes + (size_t)K * 12 * sizeof(float);
         const long long blocks = (long long)B * a.tiles_x * a.tiles_y * a.psplit;
@@ -1108,6 +1188,10 @@ extern "C" int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *sr
                 hipFuncSetAttribute(reinterpret_cast<const void *>(cv_dot_win_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
                 return IDH_ELAUNCH;
             attr_set.mark();
+        }
+        if (a.runs) {
+            hipLaunchKernelGGL(cv_runs_k, dim3((unsigned)blocks), dim3(64), 0, idh_stream(stream), a, const_cast<int *>(a.runs));
+            IDH_CHECK_LAUNCH();
         }
         if (ext.planes) hipLaunchKernelGGL(cv_dot_win_k<true>, dim3((unsigned)blocks), dim3(256), lds, idh_stream(stream), a);
         else hipLaunchKernelGGL(cv_dot_win_k<false>, dim3((unsigned)blocks), dim3(256), lds, idh_stream(stream), a);
@@ -1150,7 +1234,11 @@ extern "C" long long idh_cost_volume_dot_scratch_floats(int B, int K, int C, int
     if (B <= 0 || K < 0 || H <= 0 || W <= 0 || D <= 0 || cv_pick_kernel(0, B, K, H, W, D, C) != IDH_CV_KERNEL_WINDOW) return 0;
     int psplit = 1, per = 0;
     cv_win_split(B, K, H, W, D, &psplit, &per);
-    return psplit > 1 ? 2ll * psplit * B * H * W : 0;
+    // arg-max partials of the split planes + the run lists cv_runs_k builds ahead of the volume kernel (either part is optional: a shorter scratch
+    // only forgoes what does not fit)
+    const long long tasks = (long long)B * idh_cdiv(W, kTileW) * idh_cdiv(H, kTileH) * psplit;
+    const long long stride = 1 + 2ll * ((per + 3) / 4) * K * kRunsPerPair;
+    return (psplit > 1 ? 2ll * psplit * B * H * W : 0) + tasks * stride;
 }
 
 extern "C" const char *idh_cost_volume_dot_kernel_name(int B, int K, int H, int W, int D) {

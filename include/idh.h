@@ -120,7 +120,10 @@ int idh_cost_volume_dot_ex_fwd(const float *cur_nhwc, const float *src_nhwc, con
                                int B, int K, int C, int H, int W, int D, float *cost, int cost_nhwc_cs,
                                float *lowest_bhw, float *planes_d, const idh_volume_opts *opts, void *stream);
 
-/* Floats of idh_volume_opts.scratch that make the arg-max pass of this shape cheaper (0: the launch does not split planes). */
+/* Floats of idh_volume_opts.scratch the window kernel can use for this shape (0: another kernel takes it): the arg-max partials of a launch that
+ * splits the planes over workgroups (2 * groups * B * H * W), followed - since ABI 105 - by the run lists of every (frame, tile, plane group) task,
+ * which a small kernel (cv_runs_k) then builds AHEAD of the volume kernel instead of every workgroup in its own prologue (~10 % of its life).  Results
+ * are bit-identical with any scratch size: a scratch that only covers the first part just forgoes the second. */
 long long idh_cost_volume_dot_scratch_floats(int B, int K, int C, int H, int W, int D);
 
 /* Name of the kernel idh_cost_volume_dot*_fwd launches for this shape (what rocprofv3 --kernel-trace will show);

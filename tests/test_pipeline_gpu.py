@@ -331,3 +331,28 @@ def test_bench_n1_runs_under_a_one_rank_rccl_group():
 
     json.dump({"with_group": a, "bare": b, "ratio": ratio}, open(os.path.join(root, "gpurun_out", "bench_n1_rccl_vs_bare.json"), "w"), indent=1)
     assert 0.97 < ratio < 1.03, ratio
+
+
+def test_zero_cost_volume_through_the_pipeline():
+    """`feature_volume_type: zero_cost_volume` (reference modules/cost_volume.py:1307-1384: a volume of zeros, lowest cost = the first plane)
+    through HotPath - the one branch of pipeline.py that prepares the volume with torch ops instead of a volume kernel - against the oracle chain
+    fed with zeros, and against the module-level ZeroCostVolumeManager."""
+    from implicit_depth_amd.cost_volume import ZeroCostVolumeManager
+    from implicit_depth_amd.pipeline import HotPath
+
+    B, K, H, W, D, P = 2, 3, 24, 32, 16, 2
+    model, inp, pyr, rd = _build(B, K, H, W, D, P)
+    zero = HotPath(ZeroCostVolumeManager(H, W, D), model.cost_volume_net, model.depth_decoder, model.binary_mlp).cuda()
+    d = {k: v.cuda() for k, v in inp.items()}
+    out = zero(d["cur_feats"], d["src_feats"], [t.cuda() for t in pyr], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"], rendered_depth=rd.cuda())
+    out2 = zero(d["cur_feats"], d["src_feats"], [t.cuda() for t in pyr], d["src_extrinsics"], d["src_poses"], d["src_Ks"], d["cur_invK"], rendered_depth=rd.cuda())
+    assert torch.equal(out["pred_0"], out2["pred_0"])  # (the replay re-zeroes the volume buffer)
+    sd = lambda m: {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    p64 = [t.double() for t in pyr]
+    enc = onet.cv_encoder(torch.zeros(B, D, H, W, dtype=torch.float64), p64[1:], sd(model.cost_volume_net))
+    dec = onet.unetpp_decoder([p64[0]] + enc, sd(model.depth_decoder), depth_head=False)
+    ref = onet.occlusion_logits(dec["feature_s0_b1hw"], rd.double(), sd(model.binary_mlp), None)
+    assert rel_err(out["pred_0"].cpu(), ref) < TOL
+    cost, lowest, planes, mask = zero.cost_volume(**dict(d, min_depth=torch.tensor(0.25).view(1, 1, 1, 1).cuda(), max_depth=torch.tensor(5.0).view(1, 1, 1, 1).cuda()))
+    assert float(cost.abs().max()) == 0.0 and mask is None and out["overall_mask_bhw"] is None
+    assert torch.allclose(out["lowest_cost_bhw"], lowest) and abs(float(lowest.mean()) - 0.25) < 1e-6  # the nearest plane everywhere

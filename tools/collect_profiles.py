@@ -22,13 +22,21 @@ bench = json.loads(open(f"{D}/bench_hot_path_mlp_k7_gb32.json").read().strip().s
 pt = json.load(open("profiles/pmc_traffic.json"))
 rows = json.load(open(f"{D}/pmc_hbm_hot_path_mlp_b32.json"))
 dom = [r for r in rows if r["kernel"] == bench["roofline"]["kernel"]]
+rnd = int("".join(ch for ch in D.split("/")[-1] if ch.isdigit()) or 0)
 if dom:
-    pt["hot_path/mlp/b32"].update(kernel=dom[0]["kernel"], launches_profiled=dom[0]["calls"],
-                                  traffic_bytes_per_launch=(2 * dom[0]["fetch_KiB_per_call"] + dom[0]["write_KiB_per_call"]) * 1024)
+    # (notes are regenerated from the data: launches per step = profiled launches / the 4 steps (3 timed + 1 warm-up) x the roofline leg's replays are excluded by --no-extras? no:
+    # the conv replays of bench.py's roofline leg run in the profiled process too, so only the per-launch mean is quoted)
+    fam = {r["kernel"]: r["calls"] for r in rows if r["kernel"].startswith("conv3x3_wino4_k")}
+    pt["hot_path/mlp/b32"].update(kernel=dom[0]["kernel"], launches_profiled=dom[0]["calls"], round=rnd,
+                                  traffic_bytes_per_launch=(2 * dom[0]["fetch_KiB_per_call"] + dom[0]["write_KiB_per_call"]) * 1024,
+                                  note=f"mean over the {dom[0]['calls']} profiled launches of {dom[0]['kernel']} ({bench['roofline']['launches_per_step']} per step); "
+                                       f"profiled launches of the three F(4x4) instances: {fam}; rows of {D}/pmc_hbm_hot_path_mlp_b32.json")
 rows = json.load(open(f"{D}/pmc_hbm_warp_match_dot_b32.json"))
 w = [r for r in rows if r["kernel"].startswith("cv_dot_win_k")]
 if w:
-    pt["warp_match_dot/b32"].update(kernel=w[0]["kernel"], traffic_bytes_per_launch=(2 * w[0]["fetch_KiB_per_call"] + w[0]["write_KiB_per_call"]) * 1024)
+    pt["warp_match_dot/b32"].update(kernel=w[0]["kernel"], launches_profiled=w[0]["calls"], round=rnd,
+                                    traffic_bytes_per_launch=(2 * w[0]["fetch_KiB_per_call"] + w[0]["write_KiB_per_call"]) * 1024,
+                                    note="cv_dot_win_k alone (its run-list pre-pass cv_runs_k and the arg-max combine cv_argmax_partials_k are separate rows of the same file)")
 json.dump(pt, open("profiles/pmc_traffic.json", "w"), indent=1)
 lines = []
 for f in sorted(glob.glob(f"{D}/matrix/*.json")):
@@ -45,4 +53,4 @@ r = bench["roofline"]
 print(f"bench {bench['value']:.1f} fps {bench['ms_per_step']:.2f} ms; {r['kernel']} x{r['launches_per_step']} {r['kernel_ms']*1e3:.1f} us frac {r['frac']:.3f} alg {r['achieved_algorithmic']:.1f}; conv {r['all_conv_kernels']['ms_per_step']:.2f} ms")
 wm = bench["warp_match"]
 print(f"warp_match {wm['kernel_ms']:.4f} ms frac {wm['frac']:.4f}; temporal {[round(v['value'],1) for v in bench['temporal']['sequences_per_gpu'].values()]}; k8 {bench['k8']['value']:.1f}; "
-      f"f16x3 {bench['split_precision']['value']:.1f}; fv {bench['fv_mlp']['ms']:.2f} ms; cpu {bench['cpu_baseline']['value']:.3f}")
+      f"fv {bench['fv_mlp']['ms']:.2f} ms; cpu {bench['cpu_baseline']['value']:.3f}; extra {[(k, round(v['value'], 1)) for k, v in bench.get('extra', {}).items()]}")
