@@ -76,7 +76,8 @@ int idh_basic_block_fwd(const idh_block_params *blk, const float *weight_blob, i
 /* ---- CVEncoder (networks.py:186-215) ------------------------------------------------------------------------------------------------
  * blocks[3 i + 0 / 1 / 2] = convs["ds_conv_i"], convs["conv_i"][0], convs["conv_i"][1], i = 0 .. num_blocks - 1 (4 in every shipped config).
  * cost: the (N, D, H, W) cost / feature volume (NHWC (N,H,W,D) is what the volume kernels write); img_feats[i]: the image-encoder map
- * concatenated at level i (bd_model.py:253-258); outs[i]: level i's output, NHWC or NCHW. */
+ * concatenated at level i (bd_model.py:253-258), IDH_LAYOUT_NCHW as the reference's encoder hands it (the layout import writes it straight into
+ * its channel slice of the level's concat buffer; an NHWC map: IDH_EUNSUPPORTED); outs[i]: level i's output, NHWC or NCHW. */
 int idh_cvencoder_sizes(const idh_block_params *blocks, int num_blocks, int N, const idh_tensor *cost, const idh_tensor *img_feats,
                         const idh_tensor *outs, idh_net_sizes *sizes);
 int idh_cvencoder_pack(const idh_block_params *blocks, int num_blocks, int N, const idh_tensor *cost, const idh_tensor *img_feats,
