@@ -85,7 +85,8 @@ def _run_cvencoder(cve, cvol, img, out_layout="nhwc"):
     keep = []
     blocks = na.cvencoder_blocks(cve, keep)
     cost_nhwc = cvol.permute(0, 2, 3, 1).contiguous()
-    cost = na.nhwc(cost_nhwc)
+    cost_nchw = cvol.contiguous()
+    cost = na.nhwc(cost_nhwc) if out_layout == "nhwc" else na.nchw(cost_nchw)  # (the all-NCHW call imports the volume through the workspace)
     imgs = na.tensors([na.nchw(t) for t in img])
     chans = cve.num_ch_enc
     if out_layout == "nhwc":
