@@ -181,3 +181,26 @@ def test_network_entry_point_size_queries_run_without_a_gpu():
     img = na.tensors([na.nchw(None, c, 96 >> i, 128 >> i) for i, c in enumerate([48, 64, 160, 256])])
     outs = na.tensors([na.nhwc(None, c, 96 >> i, 128 >> i) for i, c in enumerate([64, 128, 256, 384])])
     assert L.idh_cvencoder_sizes(cb, 4, 32, C.byref(cost), img, outs, C.byref(s)) == 0 and s.ops == 28 and s.wino4 > 0
+
+
+def test_cpp_plan_builder_mirrors_the_python_thresholds():
+    """csrc/networks.hip (the C++ twin of nhwc.Plan behind idh_basic_block_fwd / idh_cvencoder_fwd / idh_unetpp_fwd) carries the kernel-selection
+    thresholds as constants: they must equal nhwc.py's defaults, or the two builders stop producing the same op lists."""
+    from implicit_depth_amd import nhwc
+
+    src = open(os.path.join(ROOT, "implicit-depth_amd", "csrc", "networks.hip")).read()
+
+    def const(name):
+        m = re.search(rf"\b{name}\s*=\s*([0-9.]+(?:ll)?(?:\s*<<\s*[0-9]+)?)", src)
+        assert m, name
+        return eval(m.group(1).replace("ll", ""))
+
+    assert const("kWinoMinTiles") == nhwc.WINO_MIN_TILES and const("kWinoMinFill") == nhwc.WINO_MIN_FILL
+    assert const("kWino4MinTiles") == nhwc.WINO4_MIN_TILES and const("kWino4MinFill") == nhwc.WINO4_MIN_FILL
+    assert const("kReuseMinBytes") == nhwc.REUSE_MIN_BYTES and const("kNarrowTileBelow") == nhwc.NARROW_TILE_BELOW
+    assert const("kSplitMinChunks") == nhwc.SPLIT_MIN_CHUNKS and const("kSplitMax") == nhwc.SPLIT_MAX
+    assert const("kProjChunkWeight") == nhwc.PROJ_CHUNK_WEIGHT and const("kS2FirstMinBlocks") == nhwc.S2_FIRST_MIN_BLOCKS
+    assert const("kTargetWaves") == nhwc.TARGET_WAVES and const("kMinWaves") == nhwc.MIN_WAVES
+    # switches the C++ builder assumes at their defaults
+    assert (nhwc.WINOGRAD, nhwc.WINOGRAD4, nhwc.WINOGRAD4_PROJ, nhwc.BUFFER_REUSE, nhwc.S2_FIRST, nhwc.MERGE_LEVELS, nhwc.WINO_GROUP) == (True,) * 7
+    assert (nhwc.FUSE_UPSAMPLE, nhwc.PROJ_LOWRES, nhwc.NARROWEST_TILE_BELOW, nhwc.DEFAULT_MATH) == (False, False, 0, "fp32")
