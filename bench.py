@@ -7,10 +7,10 @@ One "step" = one pass of the hot path over one batch of 32 synthetic frames PER 
 reference's multi-GPU mode is Lightning DDP, train.py:124,135, where batch_size is per process) - "scaling": "weak", the path shards over
 independent frames with no data-path collective.  `--scaling strong` shards ONE global batch of --batch frames over the GPUs instead
 (32/N frames per GPU: the configuration rounds 1-5 quoted; a 1-GPU run is the same workload either way).
-Inputs are generated once and are resident in HBM before the timed region.  For N>1 launch with
-torch.distributed.run (one rank per GPU, RCCL); the batch dimension is sharded, there is no data-path
-collective, and the only message is an all-gather of per-frame metric vectors after the timed region
-(SURVEY.md §8e).
+Inputs are generated once and are resident in HBM before the timed region.  `--gpus N` (N > 1) without a launcher starts its own
+ranks (python -m torch.distributed.run, one process per GPU, RCCL, 127.0.0.1 rendezvous) and forwards rank 0's line; under a launcher
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) it is one of the ranks.  There is no data-path collective; the only message
+is an all-gather of per-frame metric vectors after the timed region - at N = 1 through a 1-rank RCCL group.
 
 Workloads
   hot_path        (default) matching backbone's layer1 map -> encoder head -> fused volume -> CVEncoder ->
@@ -18,6 +18,9 @@ Workloads
   warp_match_dot  BASELINE.json configs[1]: the fused warp+match kernel alone (K=8, D=64)
   temporal        BASELINE.json configs[4]: one sequence per GPU, B=1, D=96, the previous frame's prediction
                   carried as the prior (inference/inference.py:139-157); a step = one frame
+  fused_forward   the reference's call shape (test_bd.py:196-212) from raw 512x384 images through dropin.fused_forward,
+                  stand-in backbones inside the timed region
+  module_swap     the same call through dropin.convert + the reference's own forward sequence (module by module)
 
 Prints ONE JSON line on rank 0 (see the driver contract) with extra objects:
   roofline     — dominant kernel, algorithmic flops (bytes) per launch ÷ HIP-event-measured average launch
@@ -27,6 +30,11 @@ Prints ONE JSON line on rank 0 (see the driver contract) with extra objects:
   temporal     — configs[4] frames/s on one GPU (rank 0, N=1 only)
   cpu_baseline — the oracle (CPU restatement) timed on this host's cores on a bounded sample of the same
                  workload (rank 0, N=1 only)
+  parity       — frames of the TIMED output against the same frames run alone (the timed plan's kernel mix and buffer
+                 aliasing exist at no other batch size); bar 1e-4 of scale
+  extra        — fused_forward / module_swap rates at the same batch (N=1 only)
+  dist_backend, ranks, devices, allgather_us, launcher — the process group behind the barriers and the metric all-gather
+stdout carries exactly this one line (native libraries' banners go to stderr).
 """
 from __future__ import annotations
 
