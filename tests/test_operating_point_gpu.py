@@ -113,3 +113,42 @@ def test_reference_golden_frame_inside_a_bench_sized_batch(B):
     assert (out["overall_mask_bhw"][:1].cpu()[:, ::3, ::4] != torch.as_tensor(g["head_mask_slice"])).float().mean().item() < 2e-3
     # the other frames are different tuples (not copies of frame 0) and finite
     assert torch.isfinite(out["pred_0"]).all() and not torch.equal(out["pred_0"][0], out["pred_0"][B - 1])
+
+
+def test_warp_match_bench_batch_properties():
+    """BASELINE.json configs[1] at the size bench.py times it (B = 32, K = 8, D = 64, 96x128 map: the window kernel with its run-list pre-pass,
+    planes split over workgroups, arg-max combined from the scratch): size-independent properties instead of an oracle that would take minutes -
+    (i) linearity: doubling the current features doubles the volume BIT FOR BIT (a power-of-two scale commutes with every fp32 rounding) and leaves
+    the arg-max depth untouched; (ii) frames 0, 13 and 31 equal their one-frame runs (another kernel: cv_dot_quad_k) to 1e-5 of scale;
+    (iii) a frame's volume does not depend on its neighbours in the batch (frame 5 alone in a 2-frame batch, bit for bit: same window kernel)."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from implicit_depth_amd import _lib
+    from implicit_depth_amd.cost_volume import volume_opts
+
+    args = bench.parse(["--workload", "warp_match_dot"])
+    w = bench.WarpMatchDot(args, torch.device("cuda", 0), 0)
+    assert (w.B, w.K, w.D, w.H, w.W) == (32, 8, 64, 96, 128) and w.dominant_kernel.startswith("cv_dot_win_k")
+    L, p = _lib.lib(), _lib.ptr
+
+    def run(cur, src, Ks, E, iK, B):
+        cost = torch.empty(B, w.D, w.H, w.W, device="cuda")
+        low = torch.empty(B, w.H, w.W, device="cuda")
+        opts, keep = volume_opts(B, w.K, w.C, w.H, w.W, w.D, dot_scratch_device=cost.device)
+        _lib.check(L.idh_cost_volume_dot_ex_fwd(p(cur), p(src), p(Ks), p(E), p(iK), 0.25, 5.0, B, w.K, w.C, w.H, w.W, w.D, p(cost), 0, p(low), None, opts,
+                                                _lib.stream_ptr()), "dot")
+        torch.cuda.synchronize()
+        return cost, low
+
+    cost, low = run(w.cur, w.src, w.Ks, w.E, w.invK, w.B)
+    cost2, low2 = run((2.0 * w.cur).contiguous(), w.src, w.Ks, w.E, w.invK, w.B)
+    assert torch.equal(cost2, 2.0 * cost) and torch.equal(low2, low)
+    scale = cost.abs().max().item()
+    for b in (0, 13, 31):
+        c1, l1 = run(w.cur[b:b + 1].contiguous(), w.src[b:b + 1].contiguous(), w.Ks[b:b + 1].contiguous(), w.E[b:b + 1].contiguous(), w.invK[b:b + 1].contiguous(), 1)
+        assert (c1[0] - cost[b]).abs().max().item() < 1e-5 * scale
+        assert ((l1[0] - low[b]).abs() > 1e-5).float().mean().item() < 5e-3
+    sl = slice(5, 7)
+    c2, l2 = run(w.cur[sl].contiguous(), w.src[sl].contiguous(), w.Ks[sl].contiguous(), w.E[sl].contiguous(), w.invK[sl].contiguous(), 2)
+    assert torch.equal(c2[0], cost[5]) and torch.equal(l2[0], low[5])
