@@ -1073,7 +1073,7 @@ def main():
             "dtype": {"fp32": "f32",
                       "f16x3": "f32 (3x3 convs: scaled f16x2-split operands, 3 products, f32 accumulate)"}[getattr(wl, "conv_math", "fp32")],
             "data": "synthetic",
-            "config": dict(wl.config(), global_batch=frames_per_step_total),
+            "config": dict(wl.config(), global_batch=frames_per_step_total, parallelism=f"dp{world}: frames sharded over {world} rank(s), one process per GPU, weights replicated, no data-path collective"),
             "roofline": roof,
             "gathered_metric_rows": int(m.shape[0]),
             # the process group behind the barriers / MAX all-reduce / metric all-gather of this run ("nccl" = RCCL)
