@@ -103,6 +103,17 @@ constexpr int kPanelFloats = 36 * 16 * 8;        // one stage's weights of one 1
 // position order of V / the packed weights / the accumulators: quadrant-major, p' = 9 (2 a + b) + 3 (xi % 3) + (nu % 3) with xi = 3 a + .., nu = 3 b + ..
 __host__ __device__ constexpr int w4_xi(int pp) { return 3 * ((pp / 9) >> 1) + (pp % 9) / 3; }
 __host__ __device__ constexpr int w4_nu(int pp) { return 3 * ((pp / 9) & 1) + (pp % 9) % 3; }
+// Slot order of a lane's 36 values in V (= the order of the packed weight rows and of the accumulators).  Round 6: a quadrant's nine values are the
+// aligned 32 bytes [8 q, 8 q + 8) plus slot 32 + q, so the wave that computed the quadrant stores it with two ds_write_b128 + one ds_write_b32 per k-step
+// (conflict-free: eight lanes x 16 bytes at a 144-byte pitch cover the 32 banks once) instead of nine ds_write_b32 that hit each bank four times - the V
+// writes were ~10 % of the K loop (tools/micro/wino4_mfma_shape.hip).  -DIDH_W4_NO_VPACK: the quadrant-major order of rounds 4-5 (slot = position).
+#ifdef IDH_W4_NO_VPACK
+__host__ __device__ constexpr int w4_v2p(int v) { return v; }
+__host__ __device__ constexpr int w4_p2v(int pp) { return pp; }
+#else
+__host__ __device__ constexpr int w4_v2p(int v) { return v < 32 ? 9 * (v / 8) + v % 8 : 9 * (v - 32) + 8; }
+__host__ __device__ constexpr int w4_p2v(int pp) { return pp % 9 < 8 ? 8 * (pp / 9) + pp % 9 : 32 + pp / 9; }
+#endif
 
 // OIHW 3x3 -> U = G g G^T as A fragments: dst[stage c][co block cb (16)][ks 2][g 9][lane 64][e 4] = U[p' = 4g + e][co = 16 cb + (lane & 15)][ci = 8c + 2 (lane >> 4) + ks]
 __global__ __launch_bounds__(256) void pack_wino4_weight_k(const float *__restrict__ w, float *__restrict__ dst, int Cout, int Cin, int nS, int nCB) {
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256) void pack_wino4_weight_k(const float *__restri
         const int g = (int)(r % 9); r /= 9;
         const int ks = (int)(r & 1); r >>= 1;
         const int cb = (int)(r % nCB), c = (int)(r / nCB);
-        const int pp = 4 * g + e, co = 16 * cb + (lane & 15), ci = 8 * c + 2 * (lane >> 4) + ks;
+        const int pp = w4_v2p(4 * g + e), co = 16 * cb + (lane & 15), ci = 8 * c + 2 * (lane >> 4) + ks;  // (row g, element e = V slot 4 g + e)
         double u = 0.0;
         if (co < Cout && ci < Cin) {
             const float *gw = w + ((size_t)co * Cin + ci) * 9;
@@ -319,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
         column(std::integral_constant<int, 3>{});
         column(std::integral_constant<int, 4>{});
         const int q = 2 * (HI_I ? 1 : 0) + (HI_J ? 1 : 0);
+#ifdef IDH_W4_NO_VPACK
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             float o0[3], o1[3];
@@ -330,6 +342,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
                 *(lds_float *)(lds + vbuf + 64 * 144 + vbase + 4 * (9 * q + 3 * r + cc)) = o1[cc];      // k-step 1: channel 2h + 1
             }
         }
+#else
+        // the quadrant's nine values per channel (index 3 r + cc) -> slots 8 q .. 8 q + 7 and 32 + q (w4_p2v): 2 x ds_write_b128 + ds_write_b32 per k-step
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {  // k-step ch: channel 2h + ch
+            float o[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) bt3_finish<HI_J>(S[r][ch][0], S[r][ch][1], S[r][ch][2], o[3 * r], o[3 * r + 1], o[3 * r + 2]);
+            lds_char *dst = lds + vbuf + ch * (64 * 144) + vbase;
+            *(lds_f32x4 *)(dst + 32 * q) = (f32x4){o[0], o[1], o[2], o[3]};
+            *(lds_f32x4 *)(dst + 32 * q + 16) = (f32x4){o[4], o[5], o[6], o[7]};
+            *(lds_float *)(dst + 128 + 4 * q) = o[8];
+        }
+#endif
     };
     auto transform_q = [&](int hoff, int vbuf) {  // (wave-uniform 4-way dispatch, once per stage)
 #ifdef IDH_ABL_W4_NOXFORM
@@ -510,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_k(const Wino4Args wa) {
             const bool elu = a.act == IDH_ACT_ELU;
             const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (n0 + 4 * h) * 4, 0, 0));
             // M[xi][nu] = acc[p'(xi, nu)]
-            auto M = [&](int xi, int nu) -> f32x4 & { return acc[9 * (2 * (xi / 3) + nu / 3) + 3 * (xi % 3) + nu % 3]; };
+            auto M = [&](int xi, int nu) -> f32x4 & { return acc[w4_p2v(9 * (2 * (xi / 3) + nu / 3) + 3 * (xi % 3) + nu % 3)]; };
             // pixel (i, j) of this lane's tile: element offset of its channel-0 value in an image of channel stride 1, or -1 outside the map
             auto pixel = [&](int i, int j) -> int { return ((oy0 + i < a.Ho) & (ox0 + j < a.Wo)) ? (oy0 + i) * a.Wo + ox0 + j : -1; };
             // residual loads run ahead of their use: column 0's are issued before the row pass (while the 144 accumulators are still live there is room

@@ -146,7 +146,8 @@ int idh_pack_conv_weight_wino(const float *w_oihw, float *dst, int Cout, int Cin
  * and input channel (1.78x fewer MFMAs than IDH_TILE_WINO), fp32 operands and accumulation, interpolation points {0, +-1/2, +-2, inf};
  * for the plain 3x3 stride-1 convs of BasicBlock / the decoders (layers.py:59-95, networks.py:20-215).  IDH_OP_CONV with
  * tile_m = IDH_TILE_WINO4; src[0].w = the output of idh_pack_conv_weight_wino4 (U = G g G^T per (co, ci) in MFMA A-fragment order:
- * [Cin_pad/8][Cout_pad/16][k-step 2][position group 9][lane 64][4], positions quadrant-major, ci = 8 stage + 2 (lane >> 4) + k-step);
+ * [Cin_pad/8][Cout_pad/16][k-step 2][position group 9][lane 64][4], ci = 8 stage + 2 (lane >> 4) + k-step; row g, element e = slot 4 g + e of the kernel's
+ * V layout - since ABI 105 a quadrant's nine positions are slots 8 q .. 8 q + 7 and 32 + q (csrc/conv_wino4.hip w4_v2p), quadrant-major before: repack after upgrading);
  * 32 x 8 pixel x 64 channel tiles, the input transform shared through LDS by the four 16-channel waves of a tile, two persistent
  * workgroups per CU.  Shape family: 3x3, stride 1, zero padding, Cin > 16, Cout % 64 == 0, split_k == 1, act NONE / LRELU / ELU; src[1] may be
  * a 1x1 stride-1 projection of a tensor of the output's size (weights packed by idh_pack_conv_weight as usual; then res must be NULL);

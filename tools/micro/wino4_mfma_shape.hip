@@ -19,7 +19,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) char lds_char;
 
-template <int SHAPE, int ABL>  // ABL bit 0: no A rows, bit 1: no transform, bit 2: no halo copies, bit 3: no B reads
+template <int SHAPE, int ABL>  // ABL bit 0: no A rows, bit 1: no transform, bit 2: no halo copies, bit 3: no B reads, bit 4: transform without its raw-halo reads, bit 5: ... without its V writes, bit 6: V writes as 2 x b128 + b32 per k-step
 __global__ __launch_bounds__(SHAPE == 16 ? 256 : 512, 2) void k(const float *__restrict__ panel, const float *__restrict__ act, float *out, int stages, int panel_rows, int act_floats) {
     constexpr int kV = 2 * 64 * 36 * 4 * (SHAPE == 16 ? 1 : 2);  // transformed input of one stage (bytes)
     constexpr int kHalo = (SHAPE == 16 ? 340 : 612) * 32 + 256;
@@ -98,7 +98,10 @@ __global__ __launch_bounds__(SHAPE == 16 ? 256 : 512, 2) void k(const float *__r
             for (int c5 = 0; c5 < 5; ++c5) {
                 f32x2 d[5];
 #pragma unroll
-                for (int r5 = 0; r5 < 5; ++r5) d[r5] = *(const __attribute__((address_space(3))) volatile f32x2 *)(lds + rb + 544 * (5 * c5 + r5) % (kHalo - 1024));
+                for (int r5 = 0; r5 < 5; ++r5) {
+                    if (ABL & 16) { d[r5] = (f32x2){S[r5] + 1.f, S[r5 + 5] - 1.f}; asm volatile("" : "+v"(d[r5])); }
+                    else d[r5] = *(const __attribute__((address_space(3))) volatile f32x2 *)(lds + rb + 544 * (5 * c5 + r5) % (kHalo - 1024));
+                }
 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch) {
                     const float a = __builtin_fmaf(-4.f, d[2][ch], d[4][ch]), b = __builtin_fmaf(-4.f, d[1][ch], d[3][ch]);
@@ -108,8 +111,21 @@ __global__ __launch_bounds__(SHAPE == 16 ? 256 : 512, 2) void k(const float *__r
                     S[9 * ch + 6] = __builtin_fmaf(-4.25f, w2, S[9 * ch + 6]); S[9 * ch + 7] = __builtin_fmaf(-4.f, S[9 * ch + 7], w2); S[9 * ch + 8] += w2;
                 }
             }
+            if (ABL & 32) {
 #pragma unroll
-            for (int i = 0; i < 18; ++i) *(__attribute__((address_space(3))) float *)(lds + vw + (i / 9) * (64 * 144) + vbase + 4 * ((wave & 3) * 9 + i % 9)) = S[i];
+                for (int i = 0; i < 18; ++i) asm volatile("" ::"v"(S[i]));
+            } else if (ABL & 64) {  // 8 + 1 floats per k-step: two aligned 16-byte stores + one dword
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    lds_char *o = lds + vw + ks * (64 * 144) + vbase;
+                    *(__attribute__((address_space(3))) f32x4 *)(o + 32 * (wave & 3)) = (f32x4){S[9 * ks], S[9 * ks + 1], S[9 * ks + 2], S[9 * ks + 3]};
+                    *(__attribute__((address_space(3))) f32x4 *)(o + 32 * (wave & 3) + 16) = (f32x4){S[9 * ks + 4], S[9 * ks + 5], S[9 * ks + 6], S[9 * ks + 7]};
+                    *(__attribute__((address_space(3))) float *)(o + 128 + 4 * (wave & 3)) = S[9 * ks + 8];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) *(__attribute__((address_space(3))) float *)(lds + vw + (i / 9) * (64 * 144) + vbase + 4 * ((wave & 3) * 9 + i % 9)) = S[i];
+            }
         }
         __syncthreads();
     }
@@ -157,6 +173,11 @@ int main() {
     run<16, 4>(panel, act, out, stages, panel_rows, act_floats, "S16 without the halo copies");
     run<32, 4>(panel, act, out, stages, panel_rows, act_floats, "S32 without the halo copies");
     run<16, 8>(panel, act, out, stages, panel_rows, act_floats, "S16 without the B reads");
+    run<16, 16>(panel, act, out, stages, panel_rows, act_floats, "S16 transform without its 25 halo reads");
+    run<16, 32>(panel, act, out, stages, panel_rows, act_floats, "S16 transform without its 18 V writes");
+    run<16, 48>(panel, act, out, stages, panel_rows, act_floats, "S16 transform: the 108 operations only");
+    run<16, 64>(panel, act, out, stages, panel_rows, act_floats, "S16 V writes as 2 x b128 + b32 per k-step");
+    run<16, 0>(panel, act, out, stages, panel_rows, act_floats, "S16 all streams (again)");
     run<32, 8>(panel, act, out, stages, panel_rows, act_floats, "S32 without the B reads");
     return 0;
 }
